@@ -1,0 +1,13 @@
+"""qat-vit_amd: MI355X-native QAT-ViT student training path (drop-in below the
+reference's ``src.models`` API).  Import as ``qat_vit_amd``."""
+from .model_registry import (  # noqa: F401
+    PLATFORM,
+    QATWrapper,
+    create_model,
+    create_student,
+    create_teacher,
+    list_available_models,
+    register_model,
+)
+
+__all__ = ["PLATFORM", "QATWrapper", "create_model", "create_student", "create_teacher", "list_available_models", "register_model"]

@@ -1,0 +1,86 @@
+// extern "C" surface of libqatvit.so: argument validation + error strings around the
+// launchers.  Declarations and the reference call sites they replace: include/qatvit.h.
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/qatvit.h"
+#include "qv_common.h"
+#include "qv_kernels.h"
+
+namespace qv {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace qv
+
+using namespace qv;
+
+extern "C" {
+
+int qatvit_abi_version(void) { return QATVIT_ABI_VERSION; }
+const char* qatvit_last_error(void) { return qv::g_err; }
+const char* qatvit_target_arch(void) { return "gfx950"; }
+
+int64_t qatvit_fq_workspace_bytes(int64_t channels) {
+    if (channels < 1) channels = 1;
+    return channels * (2 * (int64_t)sizeof(uint32_t) + 4 * (int64_t)sizeof(float));
+}
+
+int qatvit_fq_forward(const float* x, float* y, uint8_t* mask_bits, float* running_min, float* running_max, float* scale,
+                      int32_t* zero_point, const int64_t* observer_on, const int64_t* fake_quant_on, float averaging_const,
+                      int32_t qmin, int32_t qmax, int64_t channels, int64_t inner, int32_t per_channel, int32_t symmetric,
+                      void* workspace, void* stream) {
+    QV_CHECK_ARG(x && y && running_min && running_max && scale && zero_point && observer_on && fake_quant_on && workspace,
+                 "qatvit_fq_forward: null pointer argument");
+    QV_CHECK_ARG(channels >= 1 && inner >= 1, "qatvit_fq_forward: empty tensor (channels=%lld inner=%lld)", (long long)channels,
+                 (long long)inner);
+    QV_CHECK_ARG(qmin < qmax, "qatvit_fq_forward: qmin (%d) must be < qmax (%d)", qmin, qmax);
+    QV_CHECK_ARG(per_channel || channels == 1, "qatvit_fq_forward: per-tensor call must pass channels == 1");
+    launch_fq_forward(x, y, mask_bits, running_min, running_max, scale, zero_point, observer_on, fake_quant_on, averaging_const, qmin,
+                      qmax, channels, inner, per_channel != 0, symmetric != 0, workspace, (hipStream_t)stream);
+    QV_CHECK_LAUNCH("qatvit_fq_forward");
+    return 0;
+}
+
+int qatvit_fq_backward(const float* dy, const uint8_t* mask_bits, float* dx, int64_t n, void* stream) {
+    QV_CHECK_ARG(dy && mask_bits && dx, "qatvit_fq_backward: null pointer argument");
+    QV_CHECK_ARG(n >= 1, "qatvit_fq_backward: empty tensor");
+    launch_fq_backward(dy, mask_bits, dx, n, (hipStream_t)stream);
+    QV_CHECK_LAUNCH("qatvit_fq_backward");
+    return 0;
+}
+
+int qatvit_ln_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows,
+                      int64_t dim, float eps, void* stream) {
+    QV_CHECK_ARG(x && gamma && beta && y && mean && rstd, "qatvit_ln_forward: null pointer argument");
+    QV_CHECK_ARG(rows >= 1 && dim >= 1, "qatvit_ln_forward: empty tensor");
+    launch_ln_forward(x, gamma, beta, y, mean, rstd, rows, dim, eps, (hipStream_t)stream);
+    QV_CHECK_LAUNCH("qatvit_ln_forward");
+    return 0;
+}
+
+int qatvit_ln_backward(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                       float* dgamma, float* dbeta, int64_t rows, int64_t dim, void* stream) {
+    QV_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "qatvit_ln_backward: null pointer argument");
+    QV_CHECK_ARG(rows >= 1 && dim >= 1, "qatvit_ln_backward: empty tensor");
+    launch_ln_backward(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, dim, (hipStream_t)stream);
+    QV_CHECK_LAUNCH("qatvit_ln_backward");
+    return 0;
+}
+
+int qatvit_kd_ce_loss(const float* student, const float* teacher, const int64_t* labels, int64_t batch, int64_t classes,
+                      float kd_temp, float kd_alpha, float label_smoothing, float* out3, float* dlogits, void* stream) {
+    QV_CHECK_ARG(student && labels && out3 && dlogits, "qatvit_kd_ce_loss: null pointer argument");
+    QV_CHECK_ARG(batch >= 1 && classes >= 2 && classes <= 4096, "qatvit_kd_ce_loss: bad shape B=%lld C=%lld", (long long)batch,
+                 (long long)classes);
+    QV_CHECK_ARG(kd_temp > 0.f, "qatvit_kd_ce_loss: kd_temp must be > 0");
+    launch_kd_ce_loss(student, teacher, labels, batch, classes, kd_temp, kd_alpha, label_smoothing, out3, dlogits, (hipStream_t)stream);
+    QV_CHECK_LAUNCH("qatvit_kd_ce_loss");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,291 @@
+// Fused moving-average observer + fake-quantize for gfx950 (HBM-bound kernels).
+//
+// Replaces ATen's fused_moving_avg_obs_fake_quant, which the reference reaches via
+// prepare_qat (/root/reference/src/training/qat_trainer.py:304-307) and
+// FusedMovingAvgObsFakeQuantize.forward (torch/ao/quantization/fake_quantize.py:423-438).
+//
+// Three phases, all on one stream, no host sync:
+//   1. minmax    : 16 B/lane streaming loads, wave shuffles, one integer atomic per block
+//   2. qparams   : one thread per channel: EMA (fp32, unfused) + ChooseQuantizationParams
+//                  (torch/include/ATen/native/quantized/cpu/QuantUtils.h:71-186)
+//   3. quantize  : y = (clamp(rint(x*inv)+zp) - zp)*scale, 1-bit STE mask per element
+// Compiled with -ffp-contract=off: the EMA and the quantize arithmetic must round exactly
+// like the CPU kernel (separate multiply and add).
+#include "qv_common.h"
+#include "qv_kernels.h"
+
+namespace qv {
+
+// ------------------------------------------------------------------ phase 1: min/max
+__global__ void k_ws_init(uint32_t* ws, int64_t channels) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < channels) {
+        ws[2 * i] = kOrdPosInf;
+        ws[2 * i + 1] = kOrdNegInf;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_minmax_tensor(const float* __restrict__ x, int64_t n, uint32_t* ws) {
+    float mn = INFINITY, mx = -INFINITY;
+    const int64_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = x4[i];
+        mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+        mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        float v = x[(n4 << 2) + threadIdx.x];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    __shared__ float smn[4], smx[4];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) { smn[w] = mn; smx[w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        atomicMin(&ws[0], f2ord(mn));
+        atomicMax(&ws[1], f2ord(mx));
+    }
+}
+
+// per-channel (rows of `inner` contiguous floats): one wave per row, 4 rows per block
+__global__ __launch_bounds__(256) void k_minmax_rows(const float* __restrict__ x, int64_t channels, int64_t inner, uint32_t* ws) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    if (row >= channels) return;
+    const float* p = x + row * inner;
+    float mn = INFINITY, mx = -INFINITY;
+    if ((inner & 3) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int64_t i = l; i < (inner >> 2); i += 64) {
+            float4 v = p4[i];
+            mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+            mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+        }
+    } else {
+        for (int64_t i = l; i < inner; i += 64) {
+            float v = p[i];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (l == 0) {
+        ws[2 * row] = f2ord(mn);
+        ws[2 * row + 1] = f2ord(mx);
+    }
+}
+
+// ------------------------------------------------------------------ phase 2: qparams
+// Device restatement of ChooseQuantizationParams; see oracle/fq_ref.py for the probe
+// that fixed the one deviation from the header text (scale narrowed to fp32 before the
+// zero-point arithmetic).
+__device__ void choose_qparams(float mn, float mx, int qmin, int qmax, bool symmetric, float* scale_out, int32_t* zp_out) {
+    const bool preserve = symmetric && (mn < 0.f) && (mx > 0.f);
+    if (preserve) {
+        const int sq_min = -((qmax - qmin) / 2 + 1);
+        const int sq_max = (qmax - qmin) / 2;
+        const float a = fabsf(__fdiv_rn(mn, (float)sq_min));
+        const float b = fabsf(__fdiv_rn(mx, (float)sq_max));
+        const double max_scale = (double)fmaxf(a, b);
+        mn = (float)(max_scale * (double)sq_min);
+        mx = (float)(max_scale * (double)sq_max);
+    }
+    mn = fminf(mn, 0.f);
+    mx = fmaxf(mx, 0.f);
+    double scale = ((double)mx - (double)mn) / (double)(qmax - qmin);
+    scale = (double)(float)scale;
+    if ((float)scale == 0.0f || isinf(__fdiv_rn(1.0f, (float)scale))) scale = 0.1;
+    const float kSmall = 6.1e-5f;
+    if (scale < (double)kSmall) {
+        const float org = (float)scale;
+        scale = (double)kSmall;
+        if (mn == 0.0f) {
+            mx = __fmul_rn(kSmall, (float)(qmax - qmin));
+        } else if (mx == 0.0f) {
+            mn = __fmul_rn(-kSmall, (float)(qmax - qmin));
+        } else {
+            const float amp = __fdiv_rn(kSmall, org);
+            mn = __fmul_rn(mn, amp);
+            mx = __fmul_rn(mx, amp);
+        }
+    }
+    const double zmin = (double)qmin - (double)mn / scale;
+    const double zmax = (double)qmax - (double)mx / scale;
+    const double emin = fabs((double)qmin) - fabs((double)mn / scale);
+    const double emax = fabs((double)qmax) - fabs((double)mx / scale);
+    double init = emin < emax ? zmin : zmax;
+    if (preserve && mn < 0.f && mx > 0.f) init = (double)(qmin + qmax) / 2.0;
+    int32_t zp;
+    if (init < (double)qmin) zp = qmin;
+    else if (init > (double)qmax) zp = qmax;
+    else zp = (int32_t)rint(init);
+    *scale_out = (float)scale;
+    *zp_out = zp;
+}
+
+__device__ inline float ema(float running, float cur, float c) {
+    if (isinf(running)) return cur;
+    return __fadd_rn(running, __fmul_rn(c, __fsub_rn(cur, running)));
+}
+
+__global__ void k_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point,
+                          const int64_t* observer_on, const int64_t* fake_quant_on, float c, int qmin, int qmax,
+                          int64_t channels, int symmetric, float* qp_out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= channels) return;
+    float mn = running_min[i], mx = running_max[i];
+    if (*observer_on != 0) {
+        mn = ema(mn, ord2f(ws[2 * i]), c);
+        mx = ema(mx, ord2f(ws[2 * i + 1]), c);
+        running_min[i] = mn;
+        running_max[i] = mx;
+    }
+    float s = scale[i];
+    int32_t z = zero_point[i];
+    // (the reference raises when fake-quant runs with an unobserved min > max; a device
+    //  kernel cannot raise, so the previous scale/zero_point are kept in that case)
+    if (*fake_quant_on != 0 && mn <= mx) {
+        choose_qparams(mn, mx, qmin, qmax, symmetric != 0, &s, &z);
+        scale[i] = s;
+        zero_point[i] = z;
+    }
+    if (qp_out) {  // {scale, 1/scale, zp, enabled} for the quantize pass
+        qp_out[4 * i + 0] = s;
+        qp_out[4 * i + 1] = __fdiv_rn(1.0f, s);
+        qp_out[4 * i + 2] = (float)z;
+        qp_out[4 * i + 3] = (*fake_quant_on != 0) ? 1.f : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ phase 3: quantize
+// 8 consecutive elements per lane -> one mask byte per lane, 64 contiguous bytes per wave.
+__device__ inline void fq8(const float* __restrict__ px, float* __restrict__ py, uint8_t* __restrict__ pm, float s, float inv, float fzp,
+                           float fqmin, float fqmax, bool enabled) {
+    const float4 a = reinterpret_cast<const float4*>(px)[0];
+    const float4 b = reinterpret_cast<const float4*>(px)[1];
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bool in;
+        float y = fq_one(v[j], inv, s, fzp, fqmin, fqmax, in);
+        v[j] = enabled ? y : v[j];
+        bits |= (uint32_t)(in || !enabled) << j;
+    }
+    reinterpret_cast<float4*>(py)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(py)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    if (pm) *pm = (uint8_t)bits;
+}
+
+__global__ __launch_bounds__(256) void k_quantize(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
+                                                  const float* __restrict__ qp, int qmin, int qmax, int64_t channels, int64_t inner) {
+    // grid.y = channel (1 for per-tensor); grid.x strides over the row in groups of 8
+    const int64_t ch = blockIdx.y;
+    const float s = qp[4 * ch], inv = qp[4 * ch + 1], fzp = qp[4 * ch + 2];
+    const bool enabled = qp[4 * ch + 3] != 0.f;
+    const float fqmin = (float)qmin, fqmax = (float)qmax;
+    const int64_t base = ch * inner;
+    const int64_t n8 = inner >> 3;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // the mask byte layout is global (bit i of the flat tensor); rows must start byte-aligned
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n8; g += stride) {
+        const int64_t e = base + (g << 3);
+        fq8(x + e, y + e, mask ? mask + (e >> 3) : nullptr, s, inv, fzp, fqmin, fqmax, enabled);
+    }
+    // tail (< 8 elements): one thread, read-modify-write of the last mask byte is private to it
+    const int64_t rem = inner & 7;
+    if (rem && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t e0 = base + (n8 << 3);
+        uint32_t bits = 0;
+        for (int64_t j = 0; j < rem; ++j) {
+            bool in;
+            float v = x[e0 + j];
+            float r = fq_one(v, inv, s, fzp, fqmin, fqmax, in);
+            y[e0 + j] = enabled ? r : v;
+            bits |= (uint32_t)(in || !enabled) << j;
+        }
+        if (mask) mask[e0 >> 3] = (uint8_t)bits;
+    }
+}
+
+// generic (unaligned rows) fallback: one element per thread, mask bits via atomicOr on bytes'
+// containing 32-bit word.  Only used when inner % 8 != 0 with channels > 1.
+__global__ __launch_bounds__(256) void k_quantize_generic(const float* __restrict__ x, float* __restrict__ y, uint32_t* __restrict__ mask_words,
+                                                          const float* __restrict__ qp, int qmin, int qmax, int64_t channels, int64_t inner) {
+    const int64_t n = channels * inner;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t ch = i / inner;
+        const bool enabled = qp[4 * ch + 3] != 0.f;
+        bool in;
+        const float v = x[i];
+        const float r = fq_one(v, qp[4 * ch + 1], qp[4 * ch], qp[4 * ch + 2], (float)qmin, (float)qmax, in);
+        y[i] = enabled ? r : v;
+        if (mask_words && (in || !enabled)) atomicOr(&mask_words[i >> 5], 1u << (i & 31));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fq_backward(const float* __restrict__ dy, const uint8_t* __restrict__ mask, float* __restrict__ dx, int64_t n) {
+    const int64_t n8 = n >> 3;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n8; g += stride) {
+        const float4 a = reinterpret_cast<const float4*>(dy + (g << 3))[0];
+        const float4 b = reinterpret_cast<const float4*>(dy + (g << 3))[1];
+        const uint32_t m = mask[g];
+        reinterpret_cast<float4*>(dx + (g << 3))[0] =
+            make_float4(m & 1 ? a.x : 0.f, m & 2 ? a.y : 0.f, m & 4 ? a.z : 0.f, m & 8 ? a.w : 0.f);
+        reinterpret_cast<float4*>(dx + (g << 3))[1] =
+            make_float4(m & 16 ? b.x : 0.f, m & 32 ? b.y : 0.f, m & 64 ? b.z : 0.f, m & 128 ? b.w : 0.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int64_t i = n8 << 3; i < n; ++i) dx[i] = (mask[i >> 3] >> (i & 7)) & 1 ? dy[i] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ host launchers
+static inline int stream_grid(int64_t items_per_thread_groups) {
+    int64_t b = (items_per_thread_groups + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+    return (int)b;
+}
+
+int launch_fq_forward(const float* x, float* y, uint8_t* mask_bits, float* running_min, float* running_max, float* scale,
+                      int32_t* zero_point, const int64_t* observer_on, const int64_t* fake_quant_on, float c, int qmin, int qmax,
+                      int64_t channels, int64_t inner, bool per_channel, bool symmetric, void* workspace, hipStream_t st) {
+    uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
+    float* qp = reinterpret_cast<float*>(ws + 2 * channels);
+    const int64_t n = channels * inner;
+    if (per_channel) {
+        k_minmax_rows<<<cdiv(channels, 4), 256, 0, st>>>(x, channels, inner, ws);
+    } else {
+        k_ws_init<<<1, 64, 0, st>>>(ws, 1);
+        k_minmax_tensor<<<stream_grid(n >> 2), 256, 0, st>>>(x, n, ws);
+    }
+    k_qparams<<<cdiv(channels, 64), 64, 0, st>>>(ws, running_min, running_max, scale, zero_point, observer_on, fake_quant_on, c, qmin,
+                                                  qmax, channels, symmetric ? 1 : 0, qp);
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+    if (aligned && (channels == 1 || (inner & 7) == 0)) {
+        dim3 grid(stream_grid(inner >> 3), (unsigned)channels);
+        k_quantize<<<grid, 256, 0, st>>>(x, y, mask_bits, qp, qmin, qmax, channels, inner);
+    } else {
+        if (mask_bits) hipMemsetAsync(mask_bits, 0, (size_t)((n + 31) / 32) * 4, st);
+        k_quantize_generic<<<stream_grid(n), 256, 0, st>>>(x, y, reinterpret_cast<uint32_t*>(mask_bits), qp, qmin, qmax, channels, inner);
+    }
+    return 0;
+}
+
+int launch_fq_backward(const float* dy, const uint8_t* mask_bits, float* dx, int64_t n, hipStream_t st) {
+    k_fq_backward<<<stream_grid(n >> 3), 256, 0, st>>>(dy, mask_bits, dx, n);
+    return 0;
+}
+
+}  // namespace qv

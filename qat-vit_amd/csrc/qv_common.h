@@ -1,0 +1,70 @@
+// Shared device/host helpers for libqatvit (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace qv {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+
+#define QV_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            qv::set_error(__VA_ARGS__);         \
+            return 1;                           \
+        }                                       \
+    } while (0)
+
+#define QV_CHECK_LAUNCH(name)                                                     \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            qv::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+            return 2;                                                             \
+        }                                                                         \
+    } while (0)
+
+// Order-preserving float <-> uint32 map so min/max can use integer atomics.
+__host__ __device__ inline uint32_t f2ord(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+constexpr uint32_t kOrdPosInf = 0xff800000u;  // f2ord(+inf)
+constexpr uint32_t kOrdNegInf = 0x007fffffu;  // f2ord(-inf)
+
+__device__ inline float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// The one rounding rule of fake-quant (ATen cachemask kernels):
+//   q = nearbyint(x * inv_scale) + zp ; y = (clamp(q) - zp) * scale ; mask = q in [qmin,qmax]
+// fq/fzp/fqmin/fqmax are small integers held in fp32 (exact).
+__device__ inline float fq_one(float x, float inv_scale, float scale, float fzp, float fqmin, float fqmax, bool& in_range) {
+    float q = rintf(x * inv_scale) + fzp;
+    in_range = (q >= fqmin) && (q <= fqmax);
+    float qc = fminf(fmaxf(q, fqmin), fqmax);
+    return (qc - fzp) * scale;
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace qv

@@ -1,0 +1,148 @@
+"""Model registry + QATWrapper: the host-side mirror of the reference's model API.
+
+Same names, argument meaning and error behaviour as
+/root/reference/src/models/model_registry.py for the ViT QAT path:
+
+* ``QATWrapper``                (:99-124)   children ``quant`` / ``model`` / ``dequant``, attr ``task``
+* ``register_model``            (:134-146)
+* ``vit_base_patch16_224_teacher`` / ``vit_small_patch16_224_student`` (:152-261)
+* ``create_model`` / ``create_teacher`` / ``create_student`` / ``list_available_models`` (:333-440)
+
+Out of scope here: Jetson detection, the OWL-ViT detection
+entries and ``get_model_complexity``'s constants.  ``PLATFORM`` is the constant "mi355x".
+
+The difference that matters: once ``prepare_qat`` has run on the wrapper and the input is
+a CUDA(HIP) tensor, ``QATWrapper.forward`` executes in libqatvit.so.  CPU tensors are
+refused - there is no CPU fallback in this package.
+"""
+from __future__ import annotations
+
+import warnings
+from pathlib import Path
+from typing import Callable, Dict, Optional, Union
+
+import torch
+import torch.nn as nn
+from torch.ao.quantization import DeQuantStub, QuantStub
+
+from . import qat_forward
+from .vit import create_vit
+
+PLATFORM = "mi355x"
+
+_MODEL_REGISTRY: Dict[str, Callable[..., nn.Module]] = {}
+_MODEL_INFO: Dict[str, Dict] = {}
+
+
+class QATWrapper(nn.Module):
+    """quant -> model -> dequant (classification).  Mirrors model_registry.py:99-124."""
+
+    def __init__(self, model: nn.Module, task: str = "classification"):
+        super().__init__()
+        self.quant = QuantStub()
+        self.model = model
+        self.dequant = DeQuantStub()
+        self.task = task
+
+    def forward(self, x: torch.Tensor, **kwargs):
+        if self.task != "classification":
+            raise ValueError("only the classification task is on the MI355X QAT path")
+        if not x.is_cuda:
+            raise RuntimeError("qat-vit_amd executes on MI355X only; got a CPU tensor (no CPU fallback exists)")
+        if qat_forward.is_prepared(self):
+            return self.dequant(qat_forward.student_forward(self, x))
+        # float (pre-QAT) model: stubs are identities (torch/ao/quantization/stubs.py:25-26,43-44)
+        return self.dequant(self.model(self.quant(x)))
+
+    def fuse_model(self) -> None:
+        """No-op for ViT; kept for parity with common quantization flows."""
+        return
+
+
+def register_model(name: str, task: str = "classification", input_size: int = 224):
+    def decorator(fn):
+        _MODEL_REGISTRY[name] = fn
+        _MODEL_INFO[name] = {"task": task, "input_size": input_size, "description": (fn.__doc__ or "").strip()}
+        return fn
+
+    return decorator
+
+
+def _load_state(path) -> dict:
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and isinstance(sd.get("state_dict"), dict):
+        sd = sd["state_dict"]
+    if isinstance(sd, dict) and sd and next(iter(sd)).startswith("module."):
+        sd = {k.replace("module.", "", 1): v for k, v in sd.items()}
+    return sd
+
+
+@register_model(name="vit_base_patch16_224_teacher")
+def _create_vit_base_teacher(pretrained: bool = True, num_classes: int = 10,
+                             checkpoint_path: Optional[Union[str, Path]] = None, **kwargs) -> nn.Module:
+    """ViT-Base/16 teacher (frozen KD target)."""
+    model = create_vit("vit_base_patch16_224", pretrained=False, num_classes=num_classes, **kwargs)
+    if not pretrained:
+        return model
+    if checkpoint_path is None:
+        # the reference downloads CIFAR-10 fine-tuned weights here (:186-194); no network on this system
+        warnings.warn("teacher weights cannot be downloaded offline; teacher stays randomly initialised", RuntimeWarning)
+        return model
+    p = Path(checkpoint_path)
+    if not p.exists():
+        raise FileNotFoundError(f"Checkpoint not found: {p}")
+    model.load_state_dict(_load_state(p), strict=True)
+    return model
+
+
+@register_model(name="vit_small_patch16_224_student")
+def _create_vit_small_student(pretrained: bool = False, num_classes: int = 10,
+                              checkpoint_path: Optional[Union[str, Path]] = None, **kwargs) -> nn.Module:
+    """ViT-Small/16 student for QAT distillation."""
+    model = create_vit("vit_small_patch16_224", pretrained=pretrained, num_classes=num_classes, **kwargs)
+    if checkpoint_path is None:
+        return model
+    p = Path(checkpoint_path)
+    if not p.exists():
+        warnings.warn(f"Checkpoint not found: {p} - using current weights", RuntimeWarning)
+        return model
+    sd = _load_state(p)
+    if isinstance(sd, dict) and sd and next(iter(sd)).startswith(("quant.", "dequant.")):
+        sd = {k: v for k, v in sd.items() if not k.startswith(("quant.", "dequant."))}
+    model.load_state_dict(sd, strict=False)
+    return model
+
+
+def create_model(name: str, pretrained: bool = True, num_classes: int = 10,
+                 checkpoint_path: Optional[Union[str, Path]] = None, qat_wrapper: bool = False, **kwargs) -> nn.Module:
+    if name not in _MODEL_REGISTRY:
+        raise ValueError(f"Model '{name}' not found. Available on {PLATFORM}: {', '.join(_MODEL_REGISTRY)}")
+    fn_kwargs = {"pretrained": pretrained, **kwargs}
+    if _MODEL_INFO[name]["task"] == "classification":
+        fn_kwargs["num_classes"] = num_classes
+    model = _MODEL_REGISTRY[name](checkpoint_path=checkpoint_path, **fn_kwargs)
+    if qat_wrapper:
+        model = QATWrapper(model, task=_MODEL_INFO[name]["task"])
+    return model
+
+
+def create_teacher(model_family: str = "vit", num_classes: int = 10,
+                   checkpoint_path: Optional[Union[str, Path]] = None, **kwargs) -> nn.Module:
+    if model_family == "vit":
+        return create_model("vit_base_patch16_224_teacher", pretrained=True, num_classes=num_classes,
+                            checkpoint_path=checkpoint_path, **kwargs)
+    raise ValueError(f"Unsupported teacher family: {model_family}")
+
+
+def create_student(model_family: str = "vit", num_classes: int = 10, checkpoint_path: Optional[Union[str, Path]] = None,
+                   qat_wrapper: bool = False, **kwargs) -> nn.Module:
+    if model_family == "vit":
+        return create_model("vit_small_patch16_224_student", pretrained=False, num_classes=num_classes,
+                            checkpoint_path=checkpoint_path, qat_wrapper=qat_wrapper, **kwargs)
+    raise ValueError(f"Unsupported student family: {model_family}")
+
+
+def list_available_models(jetson_only: bool = False) -> Dict[str, Dict]:
+    return {n: {"task": i["task"], "input_size": i["input_size"], "jetson_compatible": True,
+                "description": (i["description"].splitlines()[0] if i["description"] else "No description")}
+            for n, i in _MODEL_INFO.items()}

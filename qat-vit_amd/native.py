@@ -1,0 +1,69 @@
+"""ctypes binding of libqatvit.so (C ABI: include/qatvit.h).
+
+There is no CPU implementation behind this module: if the shared library is
+missing or a call fails, the caller gets a RuntimeError - never a silent
+PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqatvit.so")
+CSRC = os.path.join(_HERE, "csrc")
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/qatvit.h declares
+SIGNATURES = {
+    "qatvit_abi_version": (c_int, []),
+    "qatvit_last_error": (c_char_p, []),
+    "qatvit_target_arch": (c_char_p, []),
+    "qatvit_fq_workspace_bytes": (c_int64, [c_int64]),
+    "qatvit_fq_forward": (c_int, [c_void_p] * 9 + [c_float, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "qatvit_fq_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "qatvit_ln_forward": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_float, c_void_p]),
+    "qatvit_ln_backward": (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_void_p]),
+    "qatvit_kd_ce_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libqatvit.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libqatvit.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MI355X path has no fallback. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library drift
+            fn.restype, fn.argtypes = res, args
+        if L.qatvit_abi_version() != 1:
+            raise RuntimeError("libqatvit.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"{what} failed ({status}): {lib().qatvit_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
