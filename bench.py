@@ -80,7 +80,8 @@ def cpu_baseline(seconds=15.0):
     host cores, BASELINE config C1 shapes (ViT-S, batch 8, qnnpack)."""
     from oracle import step_ref
 
-    cores = os.cpu_count() or 1
+    # a 1-GPU box owns a 16-core share of the host; more threads than that only oversubscribe
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     p = step_ref.enable_qat(step_ref.build_student("vit_small_patch16_224", seed=0), "qnnpack")
     x = torch.randn(8, 3, 224, 224)

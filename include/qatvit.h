@@ -84,6 +84,86 @@ int qatvit_kd_ce_loss(const float* student, const float* teacher, const int64_t*
                       int64_t batch, int64_t classes, float kd_temp, float kd_alpha,
                       float label_smoothing, float* out3, float* dlogits, void* stream);
 
+/* ===========================================================================
+ * Building blocks of the step, exported for kernel-level parity tests.
+ * All matrices row-major; "bf16" = IEEE bfloat16 bit patterns (uint16).
+ */
+
+/* C[M,N] = (A[M,K] . B[N,K]^T) * (*s1) * (*s2) * col_scale[n] + bias[n]   (fp32 out)
+ * Replaces: F.linear inside nnqat.Linear.forward (torch/ao/nn/qat/modules/linear.py:49-50) and its dgrad.
+ *  a_is_f32 = 0: A is bf16 (exact grid integers); 1: A is fp32 and is split hi/lo bf16 in the loader
+ *  (optionally multiplied by a_colscale[k] first).  B is bf16.  s1,s2,col_scale,bias,stats,a_colscale may be NULL.
+ *  stats: 2 x uint32 order-preserving min/max accumulator of the stored values (see qatvit_fq_workspace_bytes).
+ *  Shapes: N % 64 == 0, K % 64 == 0. */
+int qatvit_gemm_nt(int32_t a_is_f32, const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K,
+                   int32_t lda, int32_t ldb, int32_t ldc, const float* s1, const float* s2, const float* col_scale,
+                   const float* bias, uint32_t* stats, const float* a_colscale, void* stream);
+
+/* C[N,Kw] += sum_m P[m,N] * Q[m,Kw] * (*s1), masked by the weight fake-quant STE mask of W; dbias[N] += sum_m P[m,N].
+ * Replaces: the weight/bias gradient of nnqat.Linear / nnqat.Conv2d (autograd of linear.py:49-50, conv.py:54-55,
+ * followed by the weight_fake_quant backward).  P fp32; Q bf16 (q_is_f32=0) or fp32 (1).  C, dbias are accumulated
+ * with atomics (caller zeroes).  W (fp32 [N,Kw]) + w_scale/w_zp ([1] or [N]) may be NULL = no mask. */
+int qatvit_gemm_tn(int32_t q_is_f32, const float* P, const void* Q, float* C, int32_t M, int32_t N, int32_t Kw,
+                   int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale,
+                   const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias, void* stream);
+
+/* Attention core between attn.qkv and attn.proj (timm Attention; no fake-quant inside).
+ *  qkv: PRE-fake-quant fp32 [B*T, 3*D]; qp: {scale, 1/scale, zero_point, enabled} of the qkv activation FQ
+ *  (quantize-on-load).  O fp32 [B*T, D]; lse fp32 [B*H, qatvit_attn_padded_tokens(T)].
+ *  backward writes dqkv = d/d(pre-FQ qkv), i.e. including the FQ STE mask; delta is scratch like lse. */
+int32_t qatvit_attn_padded_tokens(int32_t T);
+int qatvit_attn_forward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
+                        int32_t D, float* O, float* lse, void* stream);
+int qatvit_attn_backward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
+                         int32_t D, const float* O, const float* lse, float* delta, const float* dO, float* dqkv, void* stream);
+
+/* ===========================================================================
+ * The whole student step.
+ * Replaces: `student_out = ddp_model(images)` ... `loss.backward()` of
+ * /root/reference/src/training/qat_trainer.py:341-359 for a prepare_qat()-ed QATWrapper(vit_*_patch16_224).
+ */
+typedef struct qatvit_cfg {
+    int32_t batch, img_size, patch_size, in_chans;
+    int32_t embed_dim, depth, num_heads, mlp_hidden, num_classes;
+    int32_t act_qmin, act_qmax;      /* 0,255 (qnnpack) or 0,127 (x86/fbgemm) */
+    int32_t w_qmin, w_qmax;          /* -128,127 */
+    int32_t w_per_channel;           /* 0: per-tensor symmetric, 1: per-output-channel symmetric */
+    float averaging_const;           /* 0.01 */
+    float ln_eps;                    /* 1e-6 */
+} qatvit_cfg;
+
+/* One fake-quant module's buffers (device pointers into the tensors prepare_qat registered). */
+typedef struct qatvit_fq {
+    float* min_val;
+    float* max_val;
+    float* scale;
+    int32_t* zero_point;
+    const int64_t* observer_on;
+    const int64_t* fake_quant_on;
+} qatvit_fq;
+
+/* Orders (host arrays):
+ *  params / grads: patch_embed.proj.{weight,bias}, cls_token, pos_embed, then per block
+ *    norm1.{w,b}, attn.qkv.{w,b}, attn.proj.{w,b}, norm2.{w,b}, mlp.fc1.{w,b}, mlp.fc2.{w,b}, then norm.{w,b}, head.{w,b}
+ *  act_fq: quant, patch_embed.proj, per block norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2, then norm, head
+ *  weight_fq: patch_embed.proj, per block attn.qkv, attn.proj, mlp.fc1, mlp.fc2, then head */
+int32_t qatvit_student_num_params(const qatvit_cfg* cfg);
+int32_t qatvit_student_num_act_fq(const qatvit_cfg* cfg);
+int32_t qatvit_student_num_weight_fq(const qatvit_cfg* cfg);
+int64_t qatvit_student_workspace_bytes(const qatvit_cfg* cfg);
+/* once per workspace, before the first forward */
+int qatvit_student_init(const qatvit_cfg* cfg, void* workspace, void* stream);
+int qatvit_student_forward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
+                           const float* images, float* logits, void* workspace, void* stream);
+/* grads: fp32 buffers, ZEROED by the caller, same order as params.  Stages: 0 = head + final norm,
+ * 1..depth = blocks depth-1..0, depth+1 = embedding; run them in order (possibly over several calls, so the
+ * caller can start the all-reduce of finished buckets in between). */
+int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
+                            const float* dlogits, void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to,
+                            void* stream);
+/* byte offset of a named intermediate tensor inside the workspace (tests); -1 if unknown */
+int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, int32_t block);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,434 @@
+// Fused multi-head attention core of the QAT student (between attn.qkv and attn.proj), gfx950.
+//
+// Reference: timm Attention as called under QATWrapper (/root/reference/src/models/model_registry.py:113-120):
+//   q,k,v = slices of the fake-quantized qkv output; softmax(q*hd^-0.5 @ k^T) @ v; no fake-quant inside.
+// Every q/k/v value is s*(integer in [-255,255]) with ONE scale s (per-tensor activation FQ), so
+//   * the kernels quantize-on-load from the pre-FQ fp32 qkv tensor (no separate quantize pass),
+//   * Q.K^T runs on bf16 MFMA over exact integers (exact in the fp32 accumulator),
+//   * P, dO, dS are floats: split hi/lo bf16 (2^-17) -> extra MFMA passes, fp32 accumulate.
+// T = 197 tokens: a head's K/V fit in LDS; one workgroup per (image, head).
+// Orientation trick (no LDS round trip for P): S^T = K.Q^T puts the query on the lane, so the
+// accumulator registers ARE the next MFMA's A operand with k-slot -> key map
+//   kappa(g, j) = 16*(t0 + (j>>2)) + 4*g + (j&3); the other operand is read with the same map
+// through ds_read_b64_tr_b16 from a [token][d] LDS image.
+#include "qv_common.h"
+#include "qv_kernels.h"
+
+namespace qv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct AQP { float s, inv, zp; float fqmin, fqmax; };
+__device__ inline float qint(float x, const AQP& q) { return fminf(fmaxf(rintf(x * q.inv) + q.zp, q.fqmin), q.fqmax) - q.zp; }
+__device__ inline bool qin(float x, const AQP& q) {
+    const float t = rintf(x * q.inv) + q.zp;
+    return t >= q.fqmin && t <= q.fqmax;
+}
+
+// ---- LDS images of a [tokens][HD] bf16 tile
+template <int HD> __device__ inline int row_off(int row, int chunk) {   // for ds_read_b128 row fragments
+    if constexpr (HD == 64) return row * 128 + ((chunk ^ (row & 7)) << 4);
+    else return row * (HD * 2) + (chunk << 4);
+}
+template <int HD> __device__ inline int tr_off(int row, int chunk) {    // for ds_read_b64_tr_b16 blocks of 4 rows
+    if constexpr (HD == 64) return row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4);
+    else return row * (HD * 2) + (chunk << 4);
+}
+
+// fragment whose k-slots (g, j) are tokens tokA + 4g + (0..3) [j<4] and tokB + 4g + (0..3) [j>=4],
+// and whose row/col index is feature col0 + (lane & 15)
+template <int HD> __device__ inline bf16x8 tr_frag2(const char* img, int tokA, int tokB, int col0, int lane) {
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+    const int chunk = (col0 >> 3) + (pp >> 1);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tr_off<HD>(tokA + 4 * g + q, chunk) + (pp & 1) * 8));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tr_off<HD>(tokB + 4 * g + q, chunk) + (pp & 1) * 8));
+    // whole-vector bit cast: per-element short->__bf16 inserts are miscompiled by hipcc 7.2 (every element becomes a[0])
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// 8 consecutive features of one token row -> quantized-integer bf16 fragment
+__device__ inline bf16x8 load_q8(const float* p, const AQP& q) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    bf16x8 f;
+    f[0] = (__bf16)qint(a.x, q); f[1] = (__bf16)qint(a.y, q); f[2] = (__bf16)qint(a.z, q); f[3] = (__bf16)qint(a.w, q);
+    f[4] = (__bf16)qint(b.x, q); f[5] = (__bf16)qint(b.y, q); f[6] = (__bf16)qint(b.z, q); f[7] = (__bf16)qint(b.w, q);
+    return f;
+}
+__device__ inline void load_split8(const float* p, bf16x8& hi, bf16x8& lo) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = (__bf16)v[j];
+        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+}
+__device__ inline void split_acc2(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (__bf16)a[j]; lo[j] = (__bf16)(a[j] - (float)hi[j]);
+        hi[j + 4] = (__bf16)b[j]; lo[j + 4] = (__bf16)(b[j] - (float)hi[j + 4]);
+    }
+}
+
+struct AttnArgs {
+    const float* qkv;   // pre-FQ fp32 [B*T, 3*D]
+    const float* qp;    // {scale, 1/scale, zp, enabled} of the qkv activation FQ
+    int qmin, qmax;
+    int B, T, H, D;     // D = H*HD
+    float softmax_scale;
+    float* O;           // fwd out / bwd in: [B*T, D]
+    float* lse;         // [B*H, TP]  (TP = padded tokens)
+    float* delta;       // [B*H, TP]
+    const float* dO;    // [B*T, D]
+    float* dqkv;        // [B*T, 3*D]  d(loss)/d(pre-FQ qkv), i.e. already multiplied by the FQ mask
+};
+
+// stage one [T][HD] slice (q, k or v of head h) into an LDS image; `which`: 0 q, 1 k, 2 v
+template <int HD, bool TR, int NKT>
+__device__ inline void stage_tokens(char* img, const float* base, int T, int ld, const AQP& q) {
+    constexpr int CH = HD / 8;  // 16-B chunks per token row
+    for (int i = threadIdx.x; i < NKT * 16 * CH; i += 256) {
+        const int tok = i / CH, ch = i % CH;
+        bf16x8 f;
+        if (tok < T) f = load_q8(base + (int64_t)tok * ld + ch * 8, q);
+        else
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f;
+        *reinterpret_cast<bf16x8*>(img + (TR ? tr_off<HD>(tok, ch) : row_off<HD>(tok, ch))) = f;
+    }
+}
+template <int HD, int NKT>
+__device__ inline void stage_split_tr(char* img_hi, char* img_lo, const float* base, int T, int ld) {
+    constexpr int CH = HD / 8;
+    for (int i = threadIdx.x; i < NKT * 16 * CH; i += 256) {
+        const int tok = i / CH, ch = i % CH;
+        bf16x8 hi, lo;
+        if (tok < T) load_split8(base + (int64_t)tok * ld + ch * 8, hi, lo);
+        else
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hi[j] = lo[j] = (__bf16)0.f;
+        *reinterpret_cast<bf16x8*>(img_hi + tr_off<HD>(tok, ch)) = hi;
+        *reinterpret_cast<bf16x8*>(img_lo + tr_off<HD>(tok, ch)) = lo;
+    }
+}
+
+__device__ inline AQP make_aqp(const float* qp, int qmin, int qmax) { return AQP{qp[0], qp[1], qp[2], (float)qmin, (float)qmax}; }
+
+// ============================================================================ forward
+template <int HD, int NKT>
+__global__ __launch_bounds__(256) void k_attn_fwd(const AttnArgs p) {
+    constexpr int IMG = NKT * 16 * HD * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;         // row image
+    char* sV = smem + IMG;   // tr image
+    const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
+    const float* base = p.qkv + (int64_t)b * T * ld + h * HD;
+    stage_tokens<HD, false, NKT>(sK, base + D, T, ld, q);
+    stage_tokens<HD, true, NKT>(sV, base + 2 * D, T, ld, q);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const float c = q.s * q.s * p.softmax_scale;
+    const int nqt = (T + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int qrow = min(qt * 16 + r, T - 1);
+        bf16x8 qf[HD / 32];
+#pragma unroll
+        for (int kk = 0; kk < HD / 32; ++kk) qf[kk] = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
+        f32x4 s[NKT];
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < HD / 32; ++kk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + row_off<HD>(16 * j + r, 4 * kk + g));
+                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[j], 0, 0, 0);
+            }
+        }
+        // softmax over keys: key = 16j + 4g + e, this lane's query = r
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool valid = 16 * j + 4 * g + e < T;
+                s[j][e] = valid ? s[j][e] * c : -INFINITY;
+                m = fmaxf(m, s[j][e]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[j][e] = expf(s[j][e] - m);
+                l += s[j][e];
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float invl = 1.0f / l;
+        if (g == 0 && qt * 16 + r < T) p.lse[(int64_t)blockIdx.x * TP + qt * 16 + r] = m + logf(l);
+        f32x4 o[HD / 16];
+#pragma unroll
+        for (int jd = 0; jd < HD / 16; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKT / 2; ++ks) {
+            bf16x8 ph, pl;
+            const f32x4 pa = s[2 * ks] * invl, pb = s[2 * ks + 1] * invl;
+            split_acc2(pa, pb, ph, pl);
+#pragma unroll
+            for (int jd = 0; jd < HD / 16; ++jd) {
+                const bf16x8 vf = tr_frag2<HD>(sV, 32 * ks, 32 * ks + 16, 16 * jd, lane);
+                o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vf, o[jd], 0, 0, 0);
+                o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vf, o[jd], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jd = 0; jd < HD / 16; ++jd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qq = qt * 16 + 4 * g + e;
+                if (qq < T) p.O[((int64_t)b * T + qq) * D + h * HD + 16 * jd + r] = o[jd][e] * q.s;
+            }
+    }
+}
+
+// ============================================================================ backward, dQ (+ delta)
+template <int HD, int NKT>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnArgs p) {
+    constexpr int IMG = NKT * 16 * HD * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;             // row image (A operand of S^T)
+    char* sKt = smem + IMG;      // tr image (B operand of dQ)
+    char* sV = smem + 2 * IMG;   // row image (A operand of dP^T)
+    const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
+    const float* base = p.qkv + (int64_t)b * T * ld + h * HD;
+    stage_tokens<HD, false, NKT>(sK, base + D, T, ld, q);
+    stage_tokens<HD, true, NKT>(sKt, base + D, T, ld, q);
+    stage_tokens<HD, false, NKT>(sV, base + 2 * D, T, ld, q);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const float c = q.s * q.s * p.softmax_scale;
+    const int nqt = (T + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int qrow = min(qt * 16 + r, T - 1);
+        const bool qvalid = qt * 16 + r < T;
+        bf16x8 qf[HD / 32], dh[HD / 32], dl[HD / 32];
+        float dpart = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < HD / 32; ++kk) {
+            qf[kk] = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
+            const float* pd = p.dO + ((int64_t)b * T + qrow) * D + h * HD + 32 * kk + 8 * g;
+            const float* po = p.O + ((int64_t)b * T + qrow) * D + h * HD + 32 * kk + 8 * g;
+            load_split8(pd, dh[kk], dl[kk]);
+            const float4 d0 = reinterpret_cast<const float4*>(pd)[0], d1 = reinterpret_cast<const float4*>(pd)[1];
+            const float4 o0 = reinterpret_cast<const float4*>(po)[0], o1 = reinterpret_cast<const float4*>(po)[1];
+            dpart += (d0.x * o0.x + d0.y * o0.y) + (d0.z * o0.z + d0.w * o0.w) + (d1.x * o1.x + d1.y * o1.y) + (d1.z * o1.z + d1.w * o1.w);
+        }
+        dpart += __shfl_xor(dpart, 16, 64);
+        dpart += __shfl_xor(dpart, 32, 64);
+        const float delta = dpart;
+        const float lse = p.lse[(int64_t)blockIdx.x * TP + qrow];
+        if (g == 0 && qvalid) p.delta[(int64_t)blockIdx.x * TP + qt * 16 + r] = delta;
+        f32x4 dq[HD / 16];
+#pragma unroll
+        for (int jd = 0; jd < HD / 16; ++jd) dq[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ks = 0; ks < NKT / 2; ++ks) {
+            f32x4 ds2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * ks + u;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < HD / 32; ++kk) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + row_off<HD>(16 * j + r, 4 * kk + g));
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + row_off<HD>(16 * j + r, 4 * kk + g));
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dh[kk], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dl[kk], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool valid = 16 * j + 4 * g + e < T;
+                    const float pr = valid ? expf(s[e] * c - lse) : 0.f;
+                    ds2[u][e] = pr * (dp[e] * q.s - delta);
+                }
+            }
+            bf16x8 sh, sl;
+            split_acc2(ds2[0], ds2[1], sh, sl);
+#pragma unroll
+            for (int jd = 0; jd < HD / 16; ++jd) {
+                const bf16x8 kt = tr_frag2<HD>(sKt, 32 * ks, 32 * ks + 16, 16 * jd, lane);
+                dq[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh, kt, dq[jd], 0, 0, 0);
+                dq[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl, kt, dq[jd], 0, 0, 0);
+            }
+        }
+        const float a = q.s * p.softmax_scale;
+#pragma unroll
+        for (int jd = 0; jd < HD / 16; ++jd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qq = qt * 16 + 4 * g + e;
+                if (qq < T) {
+                    const int64_t off = ((int64_t)b * T + qq) * ld + h * HD + 16 * jd + r;
+                    p.dqkv[off] = qin(p.qkv[off], q) ? dq[jd][e] * a : 0.f;
+                }
+            }
+    }
+}
+
+// ============================================================================ backward, dK and dV
+template <int HD, int NKT>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnArgs p) {
+    constexpr int IMG = NKT * 16 * HD * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQt = smem;             // tr image of Q integers
+    char* sDh = smem + IMG;       // tr images of dO hi / lo
+    char* sDl = smem + 2 * IMG;
+    const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
+    const float* base = p.qkv + (int64_t)b * T * ld + h * HD;
+    const float* dObase = p.dO + (int64_t)b * T * D + h * HD;
+    stage_tokens<HD, true, NKT>(sQt, base, T, ld, q);
+    stage_split_tr<HD, NKT>(sDh, sDl, dObase, T, D);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const float c = q.s * q.s * p.softmax_scale;
+    const int nkt = (T + 15) / 16;
+    const float* lse = p.lse + (int64_t)blockIdx.x * TP;
+    const float* delta = p.delta + (int64_t)blockIdx.x * TP;
+    for (int j = wave; j < nkt; j += 4) {
+        const int krow = min(16 * j + r, T - 1);
+        bf16x8 kf[HD / 32], vf[HD / 32];
+#pragma unroll
+        for (int kk = 0; kk < HD / 32; ++kk) {
+            kf[kk] = load_q8(base + D + (int64_t)krow * ld + 32 * kk + 8 * g, q);
+            vf[kk] = load_q8(base + 2 * D + (int64_t)krow * ld + 32 * kk + 8 * g, q);
+        }
+        const bool kvalid = 16 * j + r < T;
+        f32x4 dk[HD / 16], dv[HD / 16];
+#pragma unroll
+        for (int id = 0; id < HD / 16; ++id) dk[id] = dv[id] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int qs = 0; qs < NKT / 2; ++qs) {
+            f32x4 p2[2], ds2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qt = 2 * qs + u;
+                const int qrow = min(16 * qt + r, T - 1);
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < HD / 32; ++kk) {
+                    const bf16x8 qa = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
+                    bf16x8 da, db;
+                    load_split8(dObase + (int64_t)qrow * D + 32 * kk + 8 * g, da, db);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kk], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kk], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db, vf[kk], dp, 0, 0, 0);
+                }
+                // S orientation: this lane's key = 16j + r, query = 16qt + 4g + e
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qq = 16 * qt + 4 * g + e;
+                    const bool valid = qq < T && kvalid;
+                    const int qc = min(qq, T - 1);
+                    const float pr = valid ? expf(s[e] * c - lse[qc]) : 0.f;
+                    p2[u][e] = pr;
+                    ds2[u][e] = pr * (dp[e] * q.s - delta[qc]);
+                }
+            }
+            bf16x8 ph, pl, sh, sl;
+            split_acc2(p2[0], p2[1], ph, pl);
+            split_acc2(ds2[0], ds2[1], sh, sl);
+#pragma unroll
+            for (int id = 0; id < HD / 16; ++id) {
+                const bf16x8 dth = tr_frag2<HD>(sDh, 32 * qs, 32 * qs + 16, 16 * id, lane);
+                const bf16x8 dtl = tr_frag2<HD>(sDl, 32 * qs, 32 * qs + 16, 16 * id, lane);
+                const bf16x8 qtf = tr_frag2<HD>(sQt, 32 * qs, 32 * qs + 16, 16 * id, lane);
+                dv[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth, ph, dv[id], 0, 0, 0);
+                dv[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth, pl, dv[id], 0, 0, 0);
+                dv[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtl, ph, dv[id], 0, 0, 0);
+                dk[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, sh, dk[id], 0, 0, 0);
+                dk[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, sl, dk[id], 0, 0, 0);
+            }
+        }
+        // accumulators: row = feature 16id + 4g + e, col = key 16j + r  -> 16-B stores along d
+        if (kvalid) {
+            const float a = q.s * p.softmax_scale;
+#pragma unroll
+            for (int id = 0; id < HD / 16; ++id) {
+                const int64_t offk = ((int64_t)b * T + 16 * j + r) * ld + D + h * HD + 16 * id + 4 * g;
+                const int64_t offv = offk + D;
+                const float4 xk = *reinterpret_cast<const float4*>(p.qkv + offk), xv = *reinterpret_cast<const float4*>(p.qkv + offv);
+                *reinterpret_cast<float4*>(p.dqkv + offk) =
+                    make_float4(qin(xk.x, q) ? dk[id][0] * a : 0.f, qin(xk.y, q) ? dk[id][1] * a : 0.f, qin(xk.z, q) ? dk[id][2] * a : 0.f,
+                                qin(xk.w, q) ? dk[id][3] * a : 0.f);
+                *reinterpret_cast<float4*>(p.dqkv + offv) =
+                    make_float4(qin(xv.x, q) ? dv[id][0] : 0.f, qin(xv.y, q) ? dv[id][1] : 0.f, qin(xv.z, q) ? dv[id][2] : 0.f,
+                                qin(xv.w, q) ? dv[id][3] : 0.f);
+            }
+        }
+    }
+}
+
+// ============================================================================ launchers
+static int check_shape(int T, int D, int H, int* nkt) {
+    const int hd = D / H;
+    if (D % H != 0 || (hd != 64 && hd != 32)) { set_error("attention: head_dim %d unsupported (64 or 32)", hd); return 1; }
+    if (T <= 32) *nkt = 2;
+    else if (T <= 224) *nkt = 14;
+    else { set_error("attention: T=%d unsupported (<= 224 tokens)", T); return 1; }
+    return 0;
+}
+
+template <int HD, int NKT>
+static void launch3(int which, const AttnArgs& a, hipStream_t st) {
+    const size_t img = (size_t)NKT * 16 * HD * 2;
+    const int grid = a.B * a.H;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img)),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)), true);
+    (void)once;
+    if (which == 0) k_attn_fwd<HD, NKT><<<grid, 256, 2 * img, st>>>(a);
+    else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, 256, 3 * img, st>>>(a);
+    else k_attn_bwd_dkv<HD, NKT><<<grid, 256, 3 * img, st>>>(a);
+}
+
+static int dispatch(int which, const AttnArgs& a, hipStream_t st) {
+    int nkt;
+    if (check_shape(a.T, a.D, a.H, &nkt)) return 1;
+    const int hd = a.D / a.H;
+    if (hd == 64 && nkt == 14) launch3<64, 14>(which, a, st);
+    else if (hd == 64) launch3<64, 2>(which, a, st);
+    else if (nkt == 14) launch3<32, 14>(which, a, st);
+    else launch3<32, 2>(which, a, st);
+    return 0;
+}
+
+int attn_padded_tokens(int T) { return T <= 32 ? 32 : 224; }
+
+int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, float* O, float* lse, hipStream_t st) {
+    AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), O, lse, nullptr, nullptr, nullptr};
+    return dispatch(0, a, st);
+}
+
+int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const float* O, const float* lse,
+                    float* delta, const float* dO, float* dqkv, hipStream_t st) {
+    AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), const_cast<float*>(O), const_cast<float*>(lse), delta, dO, dqkv};
+    if (dispatch(1, a, st)) return 1;
+    return dispatch(2, a, st);
+}
+
+}  // namespace qv

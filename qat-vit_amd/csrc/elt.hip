@@ -1,0 +1,511 @@
+// HBM-bound fused stages between the GEMMs of the QAT student step (gfx950).
+//
+// Fake-quant needs the tensor's min/max before it can quantize (EMA observer,
+// torch/ao/quantization/observer.py:668-683), so every activation quantizer is split as
+//   producer (GEMM epilogue or a kernel here): writes the pre-FQ fp32 tensor + min/max atomics
+//   k_qparams (fq.hip): EMA + scale/zero_point, publishes {scale, 1/scale, zp, enabled}
+//   consumer (a kernel here, or a GEMM/attention loader): quantizes on load.
+// Backward never stores masks: the STE mask (qmin <= rint(x/s)+zp <= qmax) is recomputed from the
+// saved pre-FQ tensor and the module's (scale, zp), which stay valid until the next forward.
+// Row kernels: one wave per row, 16 B per lane per load; all are single-pass over HBM.
+#include "qv_common.h"
+#include "qv_kernels.h"
+
+namespace qv {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct QP { float s, inv, zp, on; };
+__device__ inline QP load_qp(const float* qp) { return QP{qp[0], qp[1], qp[2], qp[3]}; }
+// fake-quantized value and in-range flag
+__device__ inline float fqv(float x, const QP& q, float fqmin, float fqmax, bool& in) {
+    const float t = rintf(x * q.inv) + q.zp;
+    in = (t >= fqmin && t <= fqmax) || q.on == 0.f;
+    const float y = (fminf(fmaxf(t, fqmin), fqmax) - q.zp) * q.s;
+    return q.on != 0.f ? y : x;
+}
+// grid integer q - zp (exact in bf16, |.| <= 255)
+__device__ inline float fqi(float x, const QP& q, float fqmin, float fqmax) {
+    return fminf(fmaxf(rintf(x * q.inv) + q.zp, fqmin), fqmax) - q.zp;
+}
+
+static inline int rows_grid(int64_t rows) {
+    int64_t b = (rows + 3) / 4;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+static inline int flat_grid(int64_t n4) {
+    int64_t b = (n4 + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// ---------------------------------------------------------------- K0: image -> patch rows
+// out[(b*gh+py)*gw+px][c*P*P + i*P + j] = q(img[b][c][py*P+i][px*P+j]) - zp   (bf16)
+__global__ __launch_bounds__(256) void k_img_patches(const float* __restrict__ img, __bf16* __restrict__ out, const float* __restrict__ qp,
+                                                     int qmin, int qmax, int B, int C, int H, int W, int P) {
+    const QP q = load_qp(qp);
+    const int gw = W / P, gh = H / P, K = C * P * P;
+    const int64_t n8 = (int64_t)B * gh * gw * K / 8;
+    for (int64_t e8 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e8 < n8; e8 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = e8 * 8;
+        const int col = (int)(e % K);
+        const int64_t prow = e / K;
+        const int px = (int)(prow % gw), py = (int)((prow / gw) % gh), b = (int)(prow / ((int64_t)gw * gh));
+        const int j = col % P, i = (col / P) % P, c = col / (P * P);
+        const float* src = img + (((int64_t)b * C + c) * H + py * P + i) * W + px * P + j;
+        const float4 a = reinterpret_cast<const float4*>(src)[0], bb = reinterpret_cast<const float4*>(src)[1];
+        bf16x8 o;
+        o[0] = (__bf16)fqi(a.x, q, qmin, qmax); o[1] = (__bf16)fqi(a.y, q, qmin, qmax);
+        o[2] = (__bf16)fqi(a.z, q, qmin, qmax); o[3] = (__bf16)fqi(a.w, q, qmin, qmax);
+        o[4] = (__bf16)fqi(bb.x, q, qmin, qmax); o[5] = (__bf16)fqi(bb.y, q, qmin, qmax);
+        o[6] = (__bf16)fqi(bb.z, q, qmin, qmax); o[7] = (__bf16)fqi(bb.w, q, qmin, qmax);
+        *reinterpret_cast<bf16x8*>(out + e) = o;
+    }
+}
+
+// ---------------------------------------------------------------- residual + FQ + LN statistics
+// MODE 0: x_new[b,0,:] = cls + pos[0];  x_new[b,1+p,:] = fq(Y[b*np+p,:]) + pos[1+p,:]
+// MODE 1: x_new = x_prev + fq(Y)
+// then: mean/rstd of the x_new row and min/max of LN(x_new)*gamma+beta (the next aFQ's observer input).
+constexpr int kMaxV = 3;  // float4 per lane per row: D <= 768
+template <int MODE>
+__global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restrict__ x_prev, const float* __restrict__ Y, const float* __restrict__ qpY,
+                                                          int qmin, int qmax, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                          float* __restrict__ x_new, float* __restrict__ mean, float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          uint32_t* __restrict__ stats, int64_t M, int D, int T) {
+    const QP q = load_qp(qpY);
+    const int lane = threadIdx.x & 63;
+    const int nv = (D + 255) / 256;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
+        float4 v[kMaxV];
+        float s = 0.f;
+        const int t = (int)(row % T);
+        const int64_t b = row / T;
+#pragma unroll
+        for (int j = 0; j < kMaxV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (j < nv && c < D) {
+                float4 y = make_float4(0.f, 0.f, 0.f, 0.f), base;
+                bool in;
+                if (MODE == 0) {
+                    base = *reinterpret_cast<const float4*>(pos + (int64_t)t * D + c);
+                    if (t == 0) {
+                        y = *reinterpret_cast<const float4*>(cls + c);
+                    } else {
+                        const float4 r = *reinterpret_cast<const float4*>(Y + (b * (T - 1) + (t - 1)) * D + c);
+                        y = make_float4(fqv(r.x, q, qmin, qmax, in), fqv(r.y, q, qmin, qmax, in), fqv(r.z, q, qmin, qmax, in), fqv(r.w, q, qmin, qmax, in));
+                    }
+                } else {
+                    base = *reinterpret_cast<const float4*>(x_prev + row * D + c);
+                    const float4 r = *reinterpret_cast<const float4*>(Y + row * D + c);
+                    y = make_float4(fqv(r.x, q, qmin, qmax, in), fqv(r.y, q, qmin, qmax, in), fqv(r.z, q, qmin, qmax, in), fqv(r.w, q, qmin, qmax, in));
+                }
+                v[j] = make_float4(base.x + y.x, base.y + y.y, base.z + y.z, base.w + y.w);
+                *reinterpret_cast<float4*>(x_new + row * D + c) = v[j];
+                s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            } else {
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float mu = wave_sum(s) / (float)D;
+        float qq = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (j < nv && c < D) {
+                v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+                qq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+            }
+        }
+        const float rs = rsqrtf(wave_sum(qq) / (float)D + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+        for (int j = 0; j < kMaxV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (j < nv && c < D) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c), bb = *reinterpret_cast<const float4*>(beta + c);
+                const float o0 = v[j].x * rs * g.x + bb.x, o1 = v[j].y * rs * g.y + bb.y, o2 = v[j].z * rs * g.z + bb.z, o3 = v[j].w * rs * g.w + bb.w;
+                mn = fminf(fminf(mn, o0), fminf(o1, fminf(o2, o3)));
+                mx = fmaxf(fmaxf(mx, o0), fmaxf(o1, fmaxf(o2, o3)));
+            }
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (lane == 0) {
+        atomicMin(&stats[0], f2ord(mn));
+        atomicMax(&stats[1], f2ord(mx));
+    }
+}
+
+// h_q[row][c] = q(LN(x)[row][c]) - zp  as bf16 (the exact A operand of the following GEMM)
+__global__ __launch_bounds__(256) void k_ln_apply_quant(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ qp,
+                                                        int qmin, int qmax, __bf16* __restrict__ out, int64_t M, int D) {
+    const QP q = load_qp(qp);
+    const int d4 = D / 4;
+    const int64_t n4 = M * d4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / d4;
+        const int c = (int)(i % d4) * 4;
+        const float mu = mean[row], rs = rstd[row];
+        const float4 v = *reinterpret_cast<const float4*>(x + row * D + c);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+        bf16x4 o;
+        o[0] = (__bf16)fqi((v.x - mu) * rs * g.x + b.x, q, qmin, qmax);
+        o[1] = (__bf16)fqi((v.y - mu) * rs * g.y + b.y, q, qmin, qmax);
+        o[2] = (__bf16)fqi((v.z - mu) * rs * g.z + b.z, q, qmin, qmax);
+        o[3] = (__bf16)fqi((v.w - mu) * rs * g.w + b.w, q, qmin, qmax);
+        *reinterpret_cast<bf16x4*>(out + row * D + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------- GELU(fq(Y)) forward / backward
+__device__ inline float gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ inline float dgelu(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+__global__ __launch_bounds__(256) void k_fq_gelu(const float* __restrict__ Y, const float* __restrict__ qp, int qmin, int qmax,
+                                                 float* __restrict__ G, int64_t n4) {
+    const QP q = load_qp(qp);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(Y)[i];
+        bool in;
+        reinterpret_cast<float4*>(G)[i] = make_float4(gelu(fqv(v.x, q, qmin, qmax, in)), gelu(fqv(v.y, q, qmin, qmax, in)),
+                                                      gelu(fqv(v.z, q, qmin, qmax, in)), gelu(fqv(v.w, q, qmin, qmax, in)));
+    }
+}
+
+// GELU_BWD=0: dst = d * mask(Y);  GELU_BWD=1: dst = d * gelu'(fq(Y)) * mask(Y)
+template <int GELU_BWD>
+__global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ d, const float* __restrict__ Y, const float* __restrict__ qp,
+                                                  int qmin, int qmax, float* __restrict__ dst, int64_t n4) {
+    const QP q = load_qp(qp);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(Y)[i];
+        const float4 g = reinterpret_cast<const float4*>(d)[i];
+        const float in4[4] = {v.x, v.y, v.z, v.w}, g4[4] = {g.x, g.y, g.z, g.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bool in;
+            const float f = fqv(in4[e], q, qmin, qmax, in);
+            o[e] = in ? (GELU_BWD ? g4[e] * dgelu(f) : g4[e]) : 0.f;
+        }
+        reinterpret_cast<float4*>(dst)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm backward with the aFQ mask of its output
+// g_in = dH * mask(LN(x));  dx_out = (ACC ? dx_in : 0) + LNbwd(g_in);  dgamma/dbeta += column sums
+// rows_sel: if non-null only rows listed there carry a gradient (final norm: cls tokens); others get dx_out = dx_in/0.
+template <int ACC>
+__global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH, int64_t dH_row_stride_rows, const float* __restrict__ x,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ qp, int qmin, int qmax,
+                                                   const float* __restrict__ dx_in, float* __restrict__ dx_out, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, int64_t M, int D, int T, int cls_only) {
+    const QP q = load_qp(qp);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = (D + 255) / 256;
+    float4 ag[kMaxV], ab[kMaxV];
+#pragma unroll
+    for (int j = 0; j < kMaxV; ++j) ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const bool live = !cls_only || (row % T) == 0;
+        if (!live) {
+            // no gradient reaches this token through the (cls-pooled) head
+#pragma unroll
+            for (int j = 0; j < kMaxV; ++j) {
+                const int c = lane * 4 + 256 * j;
+                if (j < nv && c < D)
+                    *reinterpret_cast<float4*>(dx_out + row * D + c) =
+                        ACC ? *reinterpret_cast<const float4*>(dx_in + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            continue;
+        }
+        const float mu = mean[row], rs = rstd[row];
+        const int64_t drow = cls_only ? row / T : row;  // dH is [B, D] for the cls-only case
+        float4 xh[kMaxV], gy[kMaxV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (j < nv && c < D) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c);
+                float4 dv = *reinterpret_cast<const float4*>(dH + drow * D + c);
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+                xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                bool i0, i1, i2, i3;
+                fqv(xh[j].x * g.x + b.x, q, qmin, qmax, i0);
+                fqv(xh[j].y * g.y + b.y, q, qmin, qmax, i1);
+                fqv(xh[j].z * g.z + b.z, q, qmin, qmax, i2);
+                fqv(xh[j].w * g.w + b.w, q, qmin, qmax, i3);
+                dv.x = i0 ? dv.x : 0.f; dv.y = i1 ? dv.y : 0.f; dv.z = i2 ? dv.z : 0.f; dv.w = i3 ? dv.w : 0.f;
+                gy[j] = make_float4(dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w);
+                ag[j].x += dv.x * xh[j].x; ag[j].y += dv.y * xh[j].y; ag[j].z += dv.z * xh[j].z; ag[j].w += dv.w * xh[j].w;
+                ab[j].x += dv.x; ab[j].y += dv.y; ab[j].z += dv.z; ab[j].w += dv.w;
+                s1 += (gy[j].x + gy[j].y) + (gy[j].z + gy[j].w);
+                s2 += (gy[j].x * xh[j].x + gy[j].y * xh[j].y) + (gy[j].z * xh[j].z + gy[j].w * xh[j].w);
+            } else {
+                xh[j] = gy[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int j = 0; j < kMaxV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (j < nv && c < D) {
+                float4 o = make_float4((gy[j].x - m1 - xh[j].x * m2) * rs, (gy[j].y - m1 - xh[j].y * m2) * rs,
+                                       (gy[j].z - m1 - xh[j].z * m2) * rs, (gy[j].w - m1 - xh[j].w * m2) * rs);
+                if (ACC) {
+                    const float4 p = *reinterpret_cast<const float4*>(dx_in + row * D + c);
+                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                }
+                *reinterpret_cast<float4*>(dx_out + row * D + c) = o;
+            }
+        }
+    }
+    // column sums: 4 waves through LDS, one atomic per column per block
+    __shared__ float sg[4][768 + 8], sb[4][768 + 8];
+#pragma unroll
+    for (int j = 0; j < kMaxV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (j < nv && c < D) {
+            sg[wave][c] = ag[j].x; sg[wave][c + 1] = ag[j].y; sg[wave][c + 2] = ag[j].z; sg[wave][c + 3] = ag[j].w;
+            sb[wave][c] = ab[j].x; sb[wave][c + 1] = ab[j].y; sb[wave][c + 2] = ab[j].z; sb[wave][c + 3] = ab[j].w;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(&dgamma[c], (sg[0][c] + sg[1][c]) + (sg[2][c] + sg[3][c]));
+        atomicAdd(&dbeta[c], (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]));
+    }
+}
+
+// ---------------------------------------------------------------- head (cls pooling): tiny kernels, one block per image
+// hq[b,:] = q(LN(x[b,0,:])) - zp ; logits_pre[b,c] = s_a*s_w[c] * sum_k hq[k]*wq[c,k] + bias[c]; stats of logits_pre
+__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ qp_norm,
+                                                  int qmin, int qmax, const __bf16* __restrict__ wq, const float* __restrict__ w_scale,
+                                                  int w_per_channel, const float* __restrict__ bias, float* __restrict__ hq_out,
+                                                  float* __restrict__ logits_pre, uint32_t* __restrict__ stats, int D, int T, int C) {
+    extern __shared__ float sh[];  // D floats
+    const QP q = load_qp(qp_norm);
+    const int b = blockIdx.x;
+    const int64_t row = (int64_t)b * T;
+    const float mu = mean[row], rs = rstd[row];
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        const float h = fqi((x[row * D + c] - mu) * rs * gamma[c] + beta[c], q, qmin, qmax);
+        sh[c] = h;
+        hq_out[(int64_t)b * D + c] = h;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < C; c += 4) {
+        float acc = 0.f;
+        for (int k = lane; k < D; k += 64) acc += sh[k] * (float)wq[(int64_t)c * D + k];  // exact integers in fp32
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float v = acc * (q.s * w_scale[w_per_channel ? c : 0]) + bias[c];
+            logits_pre[(int64_t)b * C + c] = v;
+            atomicMin(&stats[0], f2ord(v));
+            atomicMax(&stats[1], f2ord(v));
+        }
+    }
+}
+
+__global__ void k_logits_fq(const float* __restrict__ pre, const float* __restrict__ qp, int qmin, int qmax, float* __restrict__ out, int n) {
+    const QP q = load_qp(qp);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        bool in;
+        out[i] = fqv(pre[i], q, qmin, qmax, in);
+    }
+}
+
+// dl = dlogits * mask(logits_pre); dW[c,:] += sum_b dl[b,c]*hq[b,:]*s_norm (masked by the weight FQ); db[c] += sum_b dl;
+// dh[b,:] = sum_c dl[b,c] * wq[c,:] * s_w[c]     (gradient w.r.t. the fake-quantized final-norm output, cls rows)
+__global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dlogits, const float* __restrict__ logits_pre, const float* __restrict__ qp_logits,
+                                                  int qmin, int qmax, const float* __restrict__ hq, const float* __restrict__ qp_norm,
+                                                  const __bf16* __restrict__ wq, const float* __restrict__ W, const float* __restrict__ w_scale,
+                                                  const int32_t* __restrict__ w_zp, int w_per_channel, int w_qmin, int w_qmax,
+                                                  float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ dh, int B, int D, int C) {
+    // grid: (C + B) blocks: blocks [0,C) compute dW row c and db[c]; blocks [C, C+B) compute dh row b
+    const QP ql = load_qp(qp_logits);
+    if ((int)blockIdx.x < C) {
+        const int c = blockIdx.x;
+        const float s_norm = qp_norm[0];
+        const int ci = w_per_channel ? c : 0;
+        const float inv = __fdiv_rn(1.0f, w_scale[ci]), fzp = (float)w_zp[ci];
+        float dbacc = 0.f;
+        for (int k = threadIdx.x; k < D; k += blockDim.x) {
+            float acc = 0.f;
+            for (int b = 0; b < B; ++b) {
+                bool in;
+                fqv(logits_pre[(int64_t)b * C + c], ql, qmin, qmax, in);
+                const float dl = in ? dlogits[(int64_t)b * C + c] : 0.f;
+                acc += dl * hq[(int64_t)b * D + k];
+                if (k == 0) dbacc += dl;
+            }
+            const float t = rintf(W[(int64_t)c * D + k] * inv) + fzp;
+            const bool win = t >= (float)w_qmin && t <= (float)w_qmax;
+            dW[(int64_t)c * D + k] = win ? acc * s_norm : 0.f;
+            if (k == 0) dbias[c] = dbacc;
+        }
+    } else {
+        const int b = blockIdx.x - C;
+        for (int k = threadIdx.x; k < D; k += blockDim.x) {
+            float acc = 0.f;
+            for (int c = 0; c < C; ++c) {
+                bool in;
+                fqv(logits_pre[(int64_t)b * C + c], ql, qmin, qmax, in);
+                const float dl = in ? dlogits[(int64_t)b * C + c] : 0.f;
+                acc += dl * (float)wq[(int64_t)c * D + k] * w_scale[w_per_channel ? c : 0];
+            }
+            dh[(int64_t)b * D + k] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- embedding backward
+// dx0 [B,T,D] -> dpos[t,:] = sum_b dx0[b,t,:]; dcls = sum_b dx0[b,0,:]; dY0[b*np+p,:] = dx0[b,1+p,:] * mask(Y0)
+__global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dx0, const float* __restrict__ Y0, const float* __restrict__ qp,
+                                                   int qmin, int qmax, float* __restrict__ dpos, float* __restrict__ dcls,
+                                                   float* __restrict__ dY0, int B, int T, int D) {
+    const QP q = load_qp(qp);
+    const int d4 = D / 4;
+    const int64_t n4 = (int64_t)T * d4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / d4), c = (int)(i % d4) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < B; ++b) {
+            const float4 g = *reinterpret_cast<const float4*>(dx0 + ((int64_t)b * T + t) * D + c);
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+            if (t > 0) {
+                const int64_t yo = ((int64_t)b * (T - 1) + (t - 1)) * D + c;
+                const float4 y = *reinterpret_cast<const float4*>(Y0 + yo);
+                bool i0, i1, i2, i3;
+                fqv(y.x, q, qmin, qmax, i0); fqv(y.y, q, qmin, qmax, i1); fqv(y.z, q, qmin, qmax, i2); fqv(y.w, q, qmin, qmax, i3);
+                *reinterpret_cast<float4*>(dY0 + yo) = make_float4(i0 ? g.x : 0.f, i1 ? g.y : 0.f, i2 ? g.z : 0.f, i3 ? g.w : 0.f);
+            }
+        }
+        *reinterpret_cast<float4*>(dpos + (int64_t)t * D + c) = acc;
+        if (t == 0) *reinterpret_cast<float4*>(dcls + c) = acc;
+    }
+}
+
+// ---------------------------------------------------------------- weight fake-quant -> GEMM operands
+// wq[n][k] = q(W[n][k]) - zp (bf16), wqT[k][n] = same, transposed (dgrad's B operand)
+__global__ __launch_bounds__(256) void k_wquant(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
+                                                __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K) {
+    // 32x32 tile transpose through LDS
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, k = k0 + tx;
+        float v = 0.f;
+        if (n < N && k < K) {
+            const QP q = load_qp(qp + 4 * (per_channel ? n : 0));
+            v = q.on != 0.f ? fqi(W[(int64_t)n * K + k], q, qmin, qmax) : W[(int64_t)n * K + k];
+            wq[(int64_t)n * K + k] = (__bf16)v;
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+    if (wqT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ty + 8 * i, n = n0 + tx;
+            if (n < N && k < K) wqT[(int64_t)k * N + n] = (__bf16)tile[tx][ty + 8 * i];
+        }
+    }
+}
+
+// ============================================================================ launchers
+int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st) {
+    if (P % 8 != 0 || H % P != 0 || W % P != 0) { set_error("img_patches: patch %d must be a multiple of 8 and divide %dx%d", P, H, W); return 1; }
+    const int64_t n8 = (int64_t)B * C * H * W / 8;
+    k_img_patches<<<flat_grid(n8), 256, 0, st>>>(img, reinterpret_cast<__bf16*>(out_bf16), qp, qmin, qmax, B, C, H, W, P);
+    return 0;
+}
+
+int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
+                            float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int64_t M,
+                            int D, int T, hipStream_t st) {
+    if (D % 4 != 0 || D > 256 * kMaxV) { set_error("resid_fq_lnstats: D=%d unsupported (need D%%4==0, D<=768)", D); return 1; }
+    if (mode == 0)
+        k_resid_fq_lnstats<0><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, M, D, T);
+    else
+        k_resid_fq_lnstats<1><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, M, D, T);
+    return 0;
+}
+
+int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
+                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st) {
+    k_ln_apply_quant<<<flat_grid(M * (D / 4)), 256, 0, st>>>(x, mean, rstd, gamma, beta, qp, qmin, qmax, reinterpret_cast<__bf16*>(out_bf16), M, D);
+    return 0;
+}
+
+int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, float* G, int64_t n, hipStream_t st) {
+    k_fq_gelu<<<flat_grid(n / 4), 256, 0, st>>>(Y, qp, qmin, qmax, G, n / 4);
+    return 0;
+}
+
+int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, float* dst, int64_t n, hipStream_t st) {
+    if (gelu_bwd) k_mask_bwd<1><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, dst, n / 4);
+    else k_mask_bwd<0><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, dst, n / 4);
+    return 0;
+}
+
+int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                     const float* qp, int qmin, int qmax, const float* dx_in, float* dx_out, float* dgamma, float* dbeta, int64_t M, int D, int T,
+                     int cls_only, hipStream_t st) {
+    if (D % 4 != 0 || D > 256 * kMaxV) { set_error("ln_bwd_fq: D=%d unsupported", D); return 1; }
+    int grid = (int)((M + 63) / 64);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    if (acc) k_ln_bwd_fq<1><<<grid, 256, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only);
+    else k_ln_bwd_fq<0><<<grid, 256, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only);
+    return 0;
+}
+
+int launch_head_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp_norm, int qmin,
+                    int qmax, const void* wq, const float* w_scale, int w_per_channel, const float* bias, float* hq, float* logits_pre,
+                    uint32_t* stats, int B, int D, int T, int C, hipStream_t st) {
+    k_head_fwd<<<B, 256, D * sizeof(float), st>>>(x, mean, rstd, gamma, beta, qp_norm, qmin, qmax, reinterpret_cast<const __bf16*>(wq), w_scale,
+                                                   w_per_channel, bias, hq, logits_pre, stats, D, T, C);
+    return 0;
+}
+
+int launch_logits_fq(const float* pre, const float* qp, int qmin, int qmax, float* out, int n, hipStream_t st) {
+    k_logits_fq<<<cdiv(n, 256), 256, 0, st>>>(pre, qp, qmin, qmax, out, n);
+    return 0;
+}
+
+int launch_head_bwd(const float* dlogits, const float* logits_pre, const float* qp_logits, int qmin, int qmax, const float* hq, const float* qp_norm,
+                    const void* wq, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dW,
+                    float* dbias, float* dh, int B, int D, int C, hipStream_t st) {
+    k_head_bwd<<<C + B, 256, 0, st>>>(dlogits, logits_pre, qp_logits, qmin, qmax, hq, qp_norm, reinterpret_cast<const __bf16*>(wq), W, w_scale, w_zp,
+                                      w_per_channel, w_qmin, w_qmax, dW, dbias, dh, B, D, C);
+    return 0;
+}
+
+int launch_embed_bwd(const float* dx0, const float* Y0, const float* qp, int qmin, int qmax, float* dpos, float* dcls, float* dY0, int B, int T, int D,
+                     hipStream_t st) {
+    k_embed_bwd<<<flat_grid((int64_t)T * (D / 4)), 256, 0, st>>>(dx0, Y0, qp, qmin, qmax, dpos, dcls, dY0, B, T, D);
+    return 0;
+}
+
+int launch_wquant(const float* W, const float* qp, int per_channel, int qmin, int qmax, void* wq, void* wqT, int N, int K, hipStream_t st) {
+    dim3 grid(cdiv(K, 32), cdiv(N, 32));
+    k_wquant<<<grid, 256, 0, st>>>(W, qp, per_channel, qmin, qmax, reinterpret_cast<__bf16*>(wq), reinterpret_cast<__bf16*>(wqT), N, K);
+    return 0;
+}
+
+}  // namespace qv

@@ -1,0 +1,405 @@
+// The QAT student step as ONE native forward and ONE native backward (host-side enqueue only).
+//
+// Mirrors the dataflow of a prepare_qat()-ed QATWrapper(ViT)
+// (/root/reference/src/models/model_registry.py:113-120 under qat_trainer.py:304-307):
+// every weight_fake_quant / activation_post_process sits at the same point, its buffers
+// (min/max/scale/zero_point) are updated in place, and backward applies the same STE masks.
+// Everything is enqueued on the caller's stream; no allocation, no host sync, no thread-local
+// device state (backward runs on autograd's worker thread).
+#include <string.h>
+
+#include "../../include/qatvit.h"
+#include "qv_common.h"
+#include "qv_kernels.h"
+
+namespace qv {
+
+enum { P_PE_W = 0, P_PE_B, P_CLS, P_POS, P_BLOCK0 };                        // then 12 per block, then 4 tail
+enum { B_N1W = 0, B_N1B, B_QKVW, B_QKVB, B_PROJW, B_PROJB, B_N2W, B_N2B, B_FC1W, B_FC1B, B_FC2W, B_FC2B, B_COUNT };
+enum { A_IN = 0, A_PE, A_BLOCK0 };                                           // act FQ: then 6 per block, then norm, head
+enum { AB_N1 = 0, AB_QKV, AB_PROJ, AB_N2, AB_FC1, AB_FC2, AB_COUNT };
+enum { WB_QKV = 0, WB_PROJ, WB_FC1, WB_FC2, WB_COUNT };                      // weight FQ: pe, 4 per block, head
+
+struct Dims {
+    int B, T, np, D, H, Hd, C, depth, Kpe, img, patch, chans;
+    int64_t M;
+    int n_act, n_w;
+};
+
+static Dims dims_of(const qatvit_cfg& c) {
+    Dims d;
+    d.B = c.batch; d.img = c.img_size; d.patch = c.patch_size; d.chans = c.in_chans;
+    d.np = (c.img_size / c.patch_size) * (c.img_size / c.patch_size);
+    d.T = d.np + 1; d.D = c.embed_dim; d.H = c.num_heads; d.Hd = c.mlp_hidden; d.C = c.num_classes; d.depth = c.depth;
+    d.Kpe = c.in_chans * c.patch_size * c.patch_size;
+    d.M = (int64_t)d.B * d.T;
+    d.n_act = 2 + AB_COUNT * d.depth + 2;
+    d.n_w = 1 + WB_COUNT * d.depth + 1;
+    return d;
+}
+
+// weight shapes by weight-FQ index
+static void wshape(const Dims& d, int wi, int* N, int* K) {
+    if (wi == 0) { *N = d.D; *K = d.Kpe; return; }
+    if (wi == d.n_w - 1) { *N = d.C; *K = d.D; return; }
+    switch ((wi - 1) % WB_COUNT) {
+        case WB_QKV: *N = 3 * d.D; *K = d.D; break;
+        case WB_PROJ: *N = d.D; *K = d.D; break;
+        case WB_FC1: *N = d.Hd; *K = d.D; break;
+        default: *N = d.D; *K = d.Hd; break;
+    }
+}
+static int wparam(const Dims& d, int wi) {  // index of the weight tensor in params[]
+    if (wi == 0) return P_PE_W;
+    if (wi == d.n_w - 1) return P_BLOCK0 + B_COUNT * d.depth + 2;
+    const int blk = (wi - 1) / WB_COUNT, k = (wi - 1) % WB_COUNT;
+    static const int map[WB_COUNT] = {B_QKVW, B_PROJW, B_FC1W, B_FC2W};
+    return P_BLOCK0 + B_COUNT * blk + map[k];
+}
+
+struct Plan {
+    // byte offsets into the workspace
+    int64_t stats, qp_act, qp_w, imgq, Y0, meanF, rstdF, hq, logits_pre;
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O, lse, Yproj, h2q, Y1, G, Y2;  // per-block base, stride blk
+    int64_t blk_stride;
+    int64_t wq, wqT;                // per weight: offsets table below
+    int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
+    int64_t dxA, dxB, dYs, dG, dY1, dH, dO, dqkv, delta, dh, dY0;
+    int64_t total;
+    int TP;
+};
+
+static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static int make_plan(const qatvit_cfg& c, Plan* p) {
+    const Dims d = dims_of(c);
+    if (d.depth > 64) { set_error("engine: depth %d > 64", d.depth); return 1; }
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { int64_t r = o; o += al(bytes); return r; };
+    const int64_t M = d.M, D = d.D, Hd = d.Hd;
+    p->TP = attn_padded_tokens(d.T);
+    // stats: act FQs (2 words each) then per weight (2 * channels)
+    int64_t wstat_words = 0, wqp_floats = 0;
+    for (int wi = 0; wi < d.n_w; ++wi) {
+        int N, K; wshape(d, wi, &N, &K);
+        const int ch = c.w_per_channel ? N : 1;
+        p->w_stats[wi] = 2 * d.n_act + wstat_words; wstat_words += 2 * ch;
+        p->w_qp[wi] = wqp_floats; wqp_floats += 4 * ch;
+    }
+    p->stats = take((2 * d.n_act + wstat_words) * 4);
+    p->qp_act = take((int64_t)d.n_act * 4 * 4);
+    p->qp_w = take(wqp_floats * 4);
+    p->imgq = take((int64_t)d.B * d.np * d.Kpe * 2);
+    p->Y0 = take((int64_t)d.B * d.np * D * 4);
+    p->meanF = take(M * 4); p->rstdF = take(M * 4);
+    p->hq = take((int64_t)d.B * D * 4);
+    p->logits_pre = take((int64_t)d.B * d.C * 4);
+    // per block
+    const int64_t b0 = o;
+    p->x_in = take(M * D * 4);
+    p->x_mid = take(M * D * 4);
+    p->mean1 = take(M * 4); p->rstd1 = take(M * 4); p->mean2 = take(M * 4); p->rstd2 = take(M * 4);
+    p->h1q = take(M * D * 2);
+    p->qkv = take(M * 3 * D * 4);
+    p->O = take(M * D * 4);
+    p->lse = take((int64_t)d.B * d.H * p->TP * 4);
+    p->Yproj = take(M * D * 4);
+    p->h2q = take(M * D * 2);
+    p->Y1 = take(M * Hd * 4);
+    p->G = take(M * Hd * 4);
+    p->Y2 = take(M * D * 4);
+    p->blk_stride = o - b0;
+    o = b0 + p->blk_stride * d.depth;
+    // x_in[depth] (input of the final norm) lives where block `depth` would start
+    const int64_t xfinal = take(M * D * 4);
+    (void)xfinal;  // == x_in + depth*blk_stride by construction
+    for (int wi = 0; wi < d.n_w; ++wi) {
+        int N, K; wshape(d, wi, &N, &K);
+        p->w_off[wi] = take((int64_t)N * K * 2);
+        p->wT_off[wi] = take((int64_t)N * K * 2);
+    }
+    p->dxA = take(M * D * 4); p->dxB = take(M * D * 4);
+    p->dYs = take(M * D * 4);
+    p->dG = take(M * Hd * 4); p->dY1 = take(M * Hd * 4);
+    p->dH = take(M * D * 4); p->dO = take(M * D * 4);
+    p->dqkv = take(M * 3 * D * 4);
+    p->delta = take((int64_t)d.B * d.H * p->TP * 4);
+    p->dh = take((int64_t)d.B * D * 4);
+    p->dY0 = take((int64_t)d.B * d.np * D * 4);
+    p->total = o;
+    return 0;
+}
+
+static int check_cfg(const qatvit_cfg& c) {
+    if (c.batch < 1 || c.depth < 1 || c.embed_dim % 64 != 0 || c.mlp_hidden % 64 != 0 || c.embed_dim % c.num_heads != 0 ||
+        c.img_size % c.patch_size != 0 || (c.in_chans * c.patch_size * c.patch_size) % 64 != 0 || c.embed_dim > 768) {
+        set_error("engine: unsupported config (batch %d depth %d dim %d hidden %d heads %d img %d patch %d)", c.batch, c.depth, c.embed_dim,
+                  c.mlp_hidden, c.num_heads, c.img_size, c.patch_size);
+        return 1;
+    }
+    return 0;
+}
+
+struct Ctx {
+    const qatvit_cfg& c;
+    Dims d;
+    Plan p;
+    char* ws;
+    void* const* params;
+    const qatvit_fq* act;
+    const qatvit_fq* wfq;
+    hipStream_t st;
+    template <typename T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
+    template <typename T> T* blk(int64_t off, int i) const { return reinterpret_cast<T*>(ws + off + p.blk_stride * i); }
+    const float* prm(int i) const { return reinterpret_cast<const float*>(params[i]); }
+    const float* bprm(int blk_i, int k) const { return prm(P_BLOCK0 + B_COUNT * blk_i + k); }
+    uint32_t* act_stats(int ai) const { return at<uint32_t>(p.stats) + 2 * ai; }
+    float* act_qp(int ai) const { return at<float>(p.qp_act) + 4 * ai; }
+    float* w_qp(int wi) const { return at<float>(p.qp_w) + p.w_qp[wi]; }
+    int aidx(int blk_i, int k) const { return A_BLOCK0 + AB_COUNT * blk_i + k; }
+    int a_norm() const { return A_BLOCK0 + AB_COUNT * d.depth; }
+    int a_head() const { return a_norm() + 1; }
+    int widx(int blk_i, int k) const { return 1 + WB_COUNT * blk_i + k; }
+    void qparams_act(int ai) const {
+        const qatvit_fq& f = act[ai];
+        launch_qparams(act_stats(ai), f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const,
+                       c.act_qmin, c.act_qmax, 1, 0, act_qp(ai), 1, st);
+    }
+    // forward GEMM against fake-quantized weight wi: C = (A . wq^T) * s_act * s_w + bias, stats -> act FQ `ai_out`
+    int linear_fwd(int a_is_f32, const void* A, int M, int wi, const float* s_act, const float* bias, float* C, int ai_out) const {
+        int N, K; wshape(d, wi, &N, &K);
+        const qatvit_fq& f = wfq[wi];
+        return launch_gemm_nt(a_is_f32, A, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
+                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), nullptr, st);
+    }
+    // dgrad: dX[M,K] = dY[M,N] . W_fq[N,K]
+    int linear_dgrad(const float* dY, int M, int wi, float* dX) const {
+        int N, K; wshape(d, wi, &N, &K);
+        const qatvit_fq& f = wfq[wi];
+        return launch_gemm_nt(1, dY, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr, nullptr,
+                              nullptr, c.w_per_channel ? f.scale : nullptr, st);
+    }
+    // wgrad: dW[N,K] += sum_m dY[m,N] X[m,K] * s_x, masked by the weight FQ; db[N] += sum_m dY
+    int linear_wgrad(const float* dY, int M, int wi, int x_is_f32, const void* X, const float* s_x, float* dW, float* db) const {
+        int N, K; wshape(d, wi, &N, &K);
+        const qatvit_fq& f = wfq[wi];
+        return launch_gemm_tn(x_is_f32, dY, X, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel, c.w_qmin,
+                              c.w_qmax, db, st);
+    }
+};
+
+static int fwd(const Ctx& x, const float* images, float* logits) {
+    const Dims& d = x.d;
+    const Plan& p = x.p;
+    const qatvit_cfg& c = x.c;
+    hipStream_t st = x.st;
+    const int qa = c.act_qmin, qb = c.act_qmax;
+    // ---- weights: observe, qparams, integer operands (row-major and transposed)
+    for (int wi = 0; wi < d.n_w; ++wi) {
+        int N, K; wshape(d, wi, &N, &K);
+        const qatvit_fq& f = x.wfq[wi];
+        const float* W = x.prm(wparam(d, wi));
+        uint32_t* ws = x.at<uint32_t>(p.stats) + p.w_stats[wi];
+        launch_minmax(W, c.w_per_channel ? N : 1, c.w_per_channel ? K : (int64_t)N * K, c.w_per_channel, ws, st);
+        launch_qparams(ws, f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const, c.w_qmin, c.w_qmax,
+                       c.w_per_channel ? N : 1, 1, x.w_qp(wi), 1, st);
+        launch_wquant(W, x.w_qp(wi), c.w_per_channel, c.w_qmin, c.w_qmax, x.at<void>(p.w_off[wi]), x.at<void>(p.wT_off[wi]), N, K, st);
+    }
+    // ---- input image FQ + patch rows
+    launch_minmax(images, 1, (int64_t)d.B * d.chans * d.img * d.img, 0, x.act_stats(A_IN), st);
+    x.qparams_act(A_IN);
+    if (launch_img_patches(images, x.at<void>(p.imgq), x.act_qp(A_IN), qa, qb, d.B, d.chans, d.img, d.img, d.patch, st)) return 1;
+    if (x.linear_fwd(0, x.at<void>(p.imgq), d.B * d.np, 0, x.act_qp(A_IN), x.prm(P_PE_B), x.at<float>(p.Y0), A_PE)) return 1;
+    x.qparams_act(A_PE);
+    if (launch_resid_fq_lnstats(0, nullptr, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, x.prm(P_CLS), x.prm(P_POS), x.blk<float>(p.x_in, 0),
+                                x.blk<float>(p.mean1, 0), x.blk<float>(p.rstd1, 0), x.bprm(0, B_N1W), x.bprm(0, B_N1B), c.ln_eps,
+                                x.act_stats(x.aidx(0, AB_N1)), d.M, d.D, d.T, st))
+        return 1;
+    const int M = (int)d.M;
+    for (int i = 0; i < d.depth; ++i) {
+        float* xin = x.blk<float>(p.x_in, i);
+        float* xmid = x.blk<float>(p.x_mid, i);
+        // norm1 -> qkv
+        x.qparams_act(x.aidx(i, AB_N1));
+        launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
+                              qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st);
+        if (x.linear_fwd(0, x.blk<void>(p.h1q, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), x.blk<float>(p.qkv, i),
+                         x.aidx(i, AB_QKV)))
+            return 1;
+        x.qparams_act(x.aidx(i, AB_QKV));
+        if (launch_attn_fwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<float>(p.O, i),
+                            x.blk<float>(p.lse, i), st))
+            return 1;
+        if (x.linear_fwd(1, x.blk<void>(p.O, i), M, x.widx(i, WB_PROJ), nullptr, x.bprm(i, B_PROJB), x.blk<float>(p.Yproj, i), x.aidx(i, AB_PROJ)))
+            return 1;
+        x.qparams_act(x.aidx(i, AB_PROJ));
+        launch_resid_fq_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, nullptr, nullptr, xmid,
+                                x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B), c.ln_eps,
+                                x.act_stats(x.aidx(i, AB_N2)), d.M, d.D, d.T, st);
+        // norm2 -> fc1 -> gelu -> fc2
+        x.qparams_act(x.aidx(i, AB_N2));
+        launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
+                              x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st);
+        if (x.linear_fwd(0, x.blk<void>(p.h2q, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), x.blk<float>(p.Y1, i),
+                         x.aidx(i, AB_FC1)))
+            return 1;
+        x.qparams_act(x.aidx(i, AB_FC1));
+        launch_fq_gelu(x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.blk<float>(p.G, i), d.M * d.Hd, st);
+        if (x.linear_fwd(1, x.blk<void>(p.G, i), M, x.widx(i, WB_FC2), nullptr, x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i), x.aidx(i, AB_FC2)))
+            return 1;
+        x.qparams_act(x.aidx(i, AB_FC2));
+        // residual + statistics of the NEXT LayerNorm (block i+1's norm1, or the final norm)
+        const bool last = (i + 1 == d.depth);
+        const float* g = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth) : x.bprm(i + 1, B_N1W);
+        const float* bt = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth + 1) : x.bprm(i + 1, B_N1B);
+        float* mean = last ? x.at<float>(p.meanF) : x.blk<float>(p.mean1, i + 1);
+        float* rstd = last ? x.at<float>(p.rstdF) : x.blk<float>(p.rstd1, i + 1);
+        launch_resid_fq_lnstats(1, xmid, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, nullptr, nullptr, x.blk<float>(p.x_in, i + 1),
+                                mean, rstd, g, bt, c.ln_eps, x.act_stats(last ? x.a_norm() : x.aidx(i + 1, AB_N1)), d.M, d.D, d.T, st);
+    }
+    // ---- final norm (observer saw all tokens), cls pooling, head
+    x.qparams_act(x.a_norm());
+    const int base = P_BLOCK0 + B_COUNT * d.depth;
+    const int wh = d.n_w - 1;
+    launch_head_fwd(x.blk<float>(p.x_in, d.depth), x.at<float>(p.meanF), x.at<float>(p.rstdF), x.prm(base), x.prm(base + 1), x.act_qp(x.a_norm()),
+                    qa, qb, x.at<void>(p.w_off[wh]), x.wfq[wh].scale, c.w_per_channel, x.prm(base + 3), x.at<float>(p.hq), x.at<float>(p.logits_pre),
+                    x.act_stats(x.a_head()), d.B, d.D, d.T, d.C, st);
+    x.qparams_act(x.a_head());
+    launch_logits_fq(x.at<float>(p.logits_pre), x.act_qp(x.a_head()), qa, qb, logits, d.B * d.C, st);
+    return 0;
+}
+
+// stages: 0 = head + final norm; 1..depth = blocks depth-1..0; depth+1 = embedding
+static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage_from, int stage_to) {
+    const Dims& d = x.d;
+    const Plan& p = x.p;
+    const qatvit_cfg& c = x.c;
+    hipStream_t st = x.st;
+    const int qa = c.act_qmin, qb = c.act_qmax;
+    const int M = (int)d.M;
+    auto G = [&](int i) { return reinterpret_cast<float*>(grads[i]); };
+    auto BG = [&](int blk_i, int k) { return reinterpret_cast<float*>(grads[P_BLOCK0 + B_COUNT * blk_i + k]); };
+    // residual-stream gradient ping-pongs between dxA and dxB; stage s starts with it in buffer (s & 1 ? A : B)... keep it simple:
+    // dxA always holds the gradient w.r.t. the current block's OUTPUT at stage entry.
+    float* dxA = x.at<float>(p.dxA);
+    float* dxB = x.at<float>(p.dxB);
+    for (int s = stage_from; s <= stage_to; ++s) {
+        if (s == 0) {
+            const int base = P_BLOCK0 + B_COUNT * d.depth;
+            const int wh = d.n_w - 1;
+            launch_head_bwd(dlogits, x.at<float>(p.logits_pre), x.act_qp(x.a_head()), qa, qb, x.at<float>(p.hq), x.act_qp(x.a_norm()),
+                            x.at<void>(p.w_off[wh]), x.prm(base + 2), x.wfq[wh].scale, x.wfq[wh].zero_point, c.w_per_channel, c.w_qmin, c.w_qmax,
+                            G(base + 2), G(base + 3), x.at<float>(p.dh), d.B, d.D, d.C, st);
+            if (launch_ln_bwd_fq(0, x.at<float>(p.dh), x.blk<float>(p.x_in, d.depth), x.at<float>(p.meanF), x.at<float>(p.rstdF), x.prm(base),
+                                 x.prm(base + 1), x.act_qp(x.a_norm()), qa, qb, nullptr, dxA, G(base), G(base + 1), d.M, d.D, d.T, 1, st))
+                return 1;
+        } else if (s <= d.depth) {
+            const int i = d.depth - s;
+            float* dYs = x.at<float>(p.dYs);
+            // ---- MLP branch
+            launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, dYs, d.M * d.D, st);
+            if (x.linear_wgrad(dYs, M, x.widx(i, WB_FC2), 1, x.blk<void>(p.G, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
+            if (x.linear_dgrad(dYs, M, x.widx(i, WB_FC2), x.at<float>(p.dG))) return 1;
+            launch_mask_bwd(1, x.at<float>(p.dG), x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.at<float>(p.dY1), d.M * d.Hd, st);
+            if (x.linear_wgrad(x.at<float>(p.dY1), M, x.widx(i, WB_FC1), 0, x.blk<void>(p.h2q, i), x.act_qp(x.aidx(i, AB_N2)), BG(i, B_FC1W),
+                               BG(i, B_FC1B)))
+                return 1;
+            if (x.linear_dgrad(x.at<float>(p.dY1), M, x.widx(i, WB_FC1), x.at<float>(p.dH))) return 1;
+            if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_mid, i), x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i),
+                                 x.bprm(i, B_N2W), x.bprm(i, B_N2B), x.act_qp(x.aidx(i, AB_N2)), qa, qb, dxA, dxB, BG(i, B_N2W), BG(i, B_N2B), d.M,
+                                 d.D, d.T, 0, st))
+                return 1;
+            // ---- attention branch (dxB = gradient w.r.t. x_mid)
+            launch_mask_bwd(0, dxB, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, dYs, d.M * d.D, st);
+            if (x.linear_wgrad(dYs, M, x.widx(i, WB_PROJ), 1, x.blk<void>(p.O, i), nullptr, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
+            if (x.linear_dgrad(dYs, M, x.widx(i, WB_PROJ), x.at<float>(p.dO))) return 1;
+            if (launch_attn_bwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<float>(p.O, i),
+                                x.blk<float>(p.lse, i), x.at<float>(p.delta), x.at<float>(p.dO), x.at<float>(p.dqkv), st))
+                return 1;
+            if (x.linear_wgrad(x.at<float>(p.dqkv), M, x.widx(i, WB_QKV), 0, x.blk<void>(p.h1q, i), x.act_qp(x.aidx(i, AB_N1)), BG(i, B_QKVW),
+                               BG(i, B_QKVB)))
+                return 1;
+            if (x.linear_dgrad(x.at<float>(p.dqkv), M, x.widx(i, WB_QKV), x.at<float>(p.dH))) return 1;
+            if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_in, i), x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i),
+                                 x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)), qa, qb, dxB, dxA, BG(i, B_N1W), BG(i, B_N1B), d.M,
+                                 d.D, d.T, 0, st))
+                return 1;
+        } else {
+            launch_embed_bwd(dxA, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, G(P_POS), G(P_CLS), x.at<float>(p.dY0), d.B, d.T, d.D, st);
+            if (x.linear_wgrad(x.at<float>(p.dY0), d.B * d.np, 0, 0, x.at<void>(p.imgq), x.act_qp(A_IN), G(P_PE_W), G(P_PE_B))) return 1;
+        }
+    }
+    return 0;
+}
+
+}  // namespace qv
+
+using namespace qv;
+
+extern "C" {
+
+int64_t qatvit_student_workspace_bytes(const qatvit_cfg* cfg) {
+    if (!cfg || check_cfg(*cfg)) return -1;
+    Plan p;
+    if (make_plan(*cfg, &p)) return -1;
+    return p.total;
+}
+
+int32_t qatvit_student_num_params(const qatvit_cfg* cfg) { return cfg ? P_BLOCK0 + B_COUNT * cfg->depth + 4 : -1; }
+int32_t qatvit_student_num_act_fq(const qatvit_cfg* cfg) { return cfg ? 2 + AB_COUNT * cfg->depth + 2 : -1; }
+int32_t qatvit_student_num_weight_fq(const qatvit_cfg* cfg) { return cfg ? 1 + WB_COUNT * cfg->depth + 1 : -1; }
+
+int qatvit_student_init(const qatvit_cfg* cfg, void* workspace, void* stream) {
+    QV_CHECK_ARG(cfg && workspace, "qatvit_student_init: null argument");
+    if (check_cfg(*cfg)) return 1;
+    Plan p;
+    if (make_plan(*cfg, &p)) return 1;
+    const Dims d = dims_of(*cfg);
+    int64_t words = 2 * d.n_act;
+    for (int wi = 0; wi < d.n_w; ++wi) { int N, K; wshape(d, wi, &N, &K); words += 2 * (cfg->w_per_channel ? N : 1); }
+    launch_ws_init(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + p.stats), words / 2, (hipStream_t)stream);
+    QV_CHECK_LAUNCH("qatvit_student_init");
+    return 0;
+}
+
+int qatvit_student_forward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, const float* images,
+                           float* logits, void* workspace, void* stream) {
+    QV_CHECK_ARG(cfg && params && act_fq && weight_fq && images && logits && workspace, "qatvit_student_forward: null argument");
+    if (check_cfg(*cfg)) return 1;
+    Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream};
+    if (make_plan(*cfg, &x.p)) return 1;
+    if (fwd(x, images, logits)) return 1;
+    QV_CHECK_LAUNCH("qatvit_student_forward");
+    return 0;
+}
+
+int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, const float* dlogits,
+                            void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to, void* stream) {
+    QV_CHECK_ARG(cfg && params && act_fq && weight_fq && dlogits && grads && workspace, "qatvit_student_backward: null argument");
+    if (check_cfg(*cfg)) return 1;
+    QV_CHECK_ARG(stage_from >= 0 && stage_to <= cfg->depth + 1 && stage_from <= stage_to, "qatvit_student_backward: bad stage range [%d,%d]",
+                 stage_from, stage_to);
+    Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream};
+    if (make_plan(*cfg, &x.p)) return 1;
+    if (bwd(x, dlogits, grads, stage_from, stage_to)) return 1;
+    QV_CHECK_LAUNCH("qatvit_student_backward");
+    return 0;
+}
+
+// debug/test access to intermediate tensors of the last forward/backward: byte offset of a named buffer
+int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, int32_t block) {
+    if (!cfg || !name || check_cfg(*cfg)) return -1;
+    Plan p;
+    if (make_plan(*cfg, &p)) return -1;
+    struct { const char* n; int64_t off; bool per_block; } tab[] = {
+        {"Y0", p.Y0, false}, {"imgq", p.imgq, false}, {"hq", p.hq, false}, {"logits_pre", p.logits_pre, false}, {"x_in", p.x_in, true},
+        {"x_mid", p.x_mid, true}, {"h1q", p.h1q, true}, {"qkv", p.qkv, true}, {"O", p.O, true}, {"Yproj", p.Yproj, true}, {"h2q", p.h2q, true},
+        {"Y1", p.Y1, true}, {"G", p.G, true}, {"Y2", p.Y2, true}, {"dxA", p.dxA, false}, {"dqkv", p.dqkv, false}, {"dO", p.dO, false},
+        {"dH", p.dH, false}, {"lse", p.lse, true},
+    };
+    for (auto& t : tab)
+        if (strcmp(t.n, name) == 0) return t.off + (t.per_block ? p.blk_stride * block : 0);
+    return -1;
+}
+
+}  // extern "C"

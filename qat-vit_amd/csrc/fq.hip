@@ -138,7 +138,7 @@ __device__ inline float ema(float running, float cur, float c) {
 
 __global__ void k_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point,
                           const int64_t* observer_on, const int64_t* fake_quant_on, float c, int qmin, int qmax,
-                          int64_t channels, int symmetric, float* qp_out) {
+                          int64_t channels, int symmetric, float* qp_out, int reset_ws) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= channels) return;
     float mn = running_min[i], mx = running_max[i];
@@ -147,6 +147,10 @@ __global__ void k_qparams(uint32_t* ws, float* running_min, float* running_max, 
         mx = ema(mx, ord2f(ws[2 * i + 1]), c);
         running_min[i] = mn;
         running_max[i] = mx;
+    }
+    if (reset_ws) {  // the slot is an atomic min/max accumulator: re-arm it for the next step
+        ws[2 * i] = kOrdPosInf;
+        ws[2 * i + 1] = kOrdNegInf;
     }
     float s = scale[i];
     int32_t z = zero_point[i];
@@ -240,13 +244,14 @@ __global__ __launch_bounds__(256) void k_fq_backward(const float* __restrict__ d
         const float4 a = reinterpret_cast<const float4*>(dy + (g << 3))[0];
         const float4 b = reinterpret_cast<const float4*>(dy + (g << 3))[1];
         const uint32_t m = mask[g];
+        // dy * mask (mask in {0,1}) like ATen: a masked-out negative dy gives -0.0f
         reinterpret_cast<float4*>(dx + (g << 3))[0] =
-            make_float4(m & 1 ? a.x : 0.f, m & 2 ? a.y : 0.f, m & 4 ? a.z : 0.f, m & 8 ? a.w : 0.f);
+            make_float4(a.x * (float)(m & 1), a.y * (float)((m >> 1) & 1), a.z * (float)((m >> 2) & 1), a.w * (float)((m >> 3) & 1));
         reinterpret_cast<float4*>(dx + (g << 3))[1] =
-            make_float4(m & 16 ? b.x : 0.f, m & 32 ? b.y : 0.f, m & 64 ? b.z : 0.f, m & 128 ? b.w : 0.f);
+            make_float4(b.x * (float)((m >> 4) & 1), b.y * (float)((m >> 5) & 1), b.z * (float)((m >> 6) & 1), b.w * (float)((m >> 7) & 1));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int64_t i = n8 << 3; i < n; ++i) dx[i] = (mask[i >> 3] >> (i & 7)) & 1 ? dy[i] : 0.f;
+        for (int64_t i = n8 << 3; i < n; ++i) dx[i] = dy[i] * (float)((mask[i >> 3] >> (i & 7)) & 1);
     }
 }
 
@@ -271,7 +276,7 @@ int launch_fq_forward(const float* x, float* y, uint8_t* mask_bits, float* runni
         k_minmax_tensor<<<stream_grid(n >> 2), 256, 0, st>>>(x, n, ws);
     }
     k_qparams<<<cdiv(channels, 64), 64, 0, st>>>(ws, running_min, running_max, scale, zero_point, observer_on, fake_quant_on, c, qmin,
-                                                  qmax, channels, symmetric ? 1 : 0, qp);
+                                                  qmax, channels, symmetric ? 1 : 0, qp, 0);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
     if (aligned && (channels == 1 || (inner & 7) == 0)) {
         dim3 grid(stream_grid(inner >> 3), (unsigned)channels);
@@ -280,6 +285,24 @@ int launch_fq_forward(const float* x, float* y, uint8_t* mask_bits, float* runni
         if (mask_bits) hipMemsetAsync(mask_bits, 0, (size_t)((n + 31) / 32) * 4, st);
         k_quantize_generic<<<stream_grid(n), 256, 0, st>>>(x, y, reinterpret_cast<uint32_t*>(mask_bits), qp, qmin, qmax, channels, inner);
     }
+    return 0;
+}
+
+// engine entry points: observer statistics and qparams as separate launches
+int launch_minmax(const float* x, int64_t channels, int64_t inner, int per_channel, uint32_t* ws, hipStream_t st) {
+    if (per_channel) k_minmax_rows<<<cdiv(channels, 4), 256, 0, st>>>(x, channels, inner, ws);
+    else k_minmax_tensor<<<stream_grid((channels * inner) >> 2), 256, 0, st>>>(x, channels * inner, ws);
+    return 0;
+}
+int launch_ws_init(uint32_t* ws, int64_t slots, hipStream_t st) {
+    k_ws_init<<<cdiv(slots, 256), 256, 0, st>>>(ws, slots);
+    return 0;
+}
+int launch_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point, const int64_t* observer_on,
+                   const int64_t* fake_quant_on, float c, int qmin, int qmax, int64_t channels, int symmetric, float* qp_out, int reset_ws,
+                   hipStream_t st) {
+    k_qparams<<<cdiv(channels, 64), 64, 0, st>>>(ws, running_min, running_max, scale, zero_point, observer_on, fake_quant_on, c, qmin, qmax,
+                                                  channels, symmetric, qp_out, reset_ws);
     return 0;
 }
 

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 from torch.ao.quantization import DeQuantStub, QuantStub
 
-from . import qat_forward
+from . import engine
 from .vit import create_vit
 
 PLATFORM = "mi355x"
@@ -49,8 +49,8 @@ class QATWrapper(nn.Module):
             raise ValueError("only the classification task is on the MI355X QAT path")
         if not x.is_cuda:
             raise RuntimeError("qat-vit_amd executes on MI355X only; got a CPU tensor (no CPU fallback exists)")
-        if qat_forward.is_prepared(self):
-            return self.dequant(qat_forward.student_forward(self, x))
+        if hasattr(self.quant, "activation_post_process"):  # prepare_qat() has run: native step
+            return self.dequant(engine.student_forward(self, x))
         # float (pre-QAT) model: stubs are identities (torch/ao/quantization/stubs.py:25-26,43-44)
         return self.dequant(self.model(self.quant(x)))
 

@@ -27,7 +27,32 @@ SIGNATURES = {
     "qatvit_ln_forward": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_float, c_void_p]),
     "qatvit_ln_backward": (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_void_p]),
     "qatvit_kd_ce_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "qatvit_gemm_nt": (c_int, [c_int32, c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 7),
+    "qatvit_gemm_tn": (c_int, [c_int32, c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p, c_void_p]),
+    "qatvit_attn_padded_tokens": (c_int32, [c_int32]),
+    "qatvit_attn_forward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 3),
+    "qatvit_attn_backward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 6),
+    "qatvit_student_num_params": (c_int32, [c_void_p]),
+    "qatvit_student_num_act_fq": (c_int32, [c_void_p]),
+    "qatvit_student_num_weight_fq": (c_int32, [c_void_p]),
+    "qatvit_student_workspace_bytes": (c_int64, [c_void_p]),
+    "qatvit_student_init": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "qatvit_student_forward": (c_int, [c_void_p] * 8),
+    "qatvit_student_backward": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_void_p]),
+    "qatvit_student_tensor_offset": (c_int64, [c_void_p, c_char_p, c_int32]),
 }
+
+
+class Cfg(ctypes.Structure):
+    """struct qatvit_cfg (include/qatvit.h)."""
+    _fields_ = [(n, c_int32) for n in ("batch", "img_size", "patch_size", "in_chans", "embed_dim", "depth", "num_heads", "mlp_hidden",
+                                       "num_classes", "act_qmin", "act_qmax", "w_qmin", "w_qmax", "w_per_channel")] + \
+               [("averaging_const", c_float), ("ln_eps", c_float)]
+
+
+class FQ(ctypes.Structure):
+    """struct qatvit_fq (include/qatvit.h)."""
+    _fields_ = [(n, c_void_p) for n in ("min_val", "max_val", "scale", "zero_point", "observer_on", "fake_quant_on")]
 
 
 def build(verbose: bool = False) -> str:

@@ -6,8 +6,10 @@ Walks the tree ``prepare_qat`` produced (qat_trainer.py:304-307): every
 conv.py:54-55) is applied at exactly the same point of the dataflow, but through
 libqatvit.so, and the modules' FQ buffers are updated in place.
 
-Stage 1 (this file): fake-quant, LayerNorm and the loss are native HIP kernels; GEMM /
-attention still go through torch's ROCm ops.  The step engine (engine.py) replaces those.
+NOT the product path (QATWrapper.forward never comes here; it calls engine.py).  This is the
+stage-1 bring-up composition kept as a diagnostic: fake-quant and LayerNorm go through the per-op
+C ABI while GEMM / attention use torch's ROCm ops, which makes it a convenient A/B partner when
+bisecting a difference between the native engine and the oracle (tests/diag_*.py).
 """
 from __future__ import annotations
 

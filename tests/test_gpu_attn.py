@@ -1,0 +1,57 @@
+"""Fused attention kernels (quantize-on-load from the pre-FQ qkv tensor) against an fp64 torch
+reference that fake-quantizes qkv the same way.  P, dO, dS are split hi/lo bf16 (2^-17), the
+integer Q.K^T is exact -> 3e-5 relative L2 asserted."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import rel_l2  # noqa: E402
+
+
+def _ref(qkv_pre, scale, zp, qmin, qmax, B, T, H, D, dO):
+    inv = (torch.ones(1, device=qkv_pre.device) / scale).item()  # fp32 reciprocal like the kernel
+    q = torch.round(qkv_pre * inv) + zp
+    mask = ((q >= qmin) & (q <= qmax))
+    fq = ((q.clamp(qmin, qmax) - zp) * scale).double().requires_grad_(True)
+    hd = D // H
+    x = fq.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    qq, kk, vv = x[0], x[1], x[2]
+    a = torch.softmax((qq * hd ** -0.5) @ kk.transpose(-2, -1), dim=-1)
+    o = (a @ vv).transpose(1, 2).reshape(B * T, D)
+    o.backward(dO.double())
+    return o.detach(), fq.grad * mask
+
+
+@pytest.mark.parametrize("B,T,H,D", [(3, 197, 6, 384), (2, 5, 2, 64), (2, 197, 12, 768), (1, 17, 2, 128)])
+def test_attention_fwd_bwd(native_lib, B, T, H, D):
+    torch.manual_seed(B * T + D)
+    dev = "cuda"
+    qkv = torch.randn(B * T, 3 * D, device=dev) * 1.5
+    qkv[0, :7] = 40.0  # clipped elements -> masked gradient
+    scale, zp, qmin, qmax = 8.0 / 255, 120, 0, 255
+    qp = torch.tensor([scale, 1.0, float(zp), 1.0], device=dev)
+    qp[1] = torch.ones(1, device=dev)[0] / qp[0]
+    TP = native_lib.qatvit_attn_padded_tokens(T)
+    O = torch.full((B * T, D), float("nan"), device=dev)
+    lse = torch.zeros(B * H, TP, device=dev)
+    delta = torch.zeros(B * H, TP, device=dev)
+    dO = torch.randn(B * T, D, device=dev)
+    dqkv = torch.full((B * T, 3 * D), float("nan"), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert native_lib.qatvit_attn_forward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, O.data_ptr(), lse.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+    assert native_lib.qatvit_attn_backward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, O.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                           dO.data_ptr(), dqkv.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+    ro, rg = _ref(qkv, qp[0], zp, qmin, qmax, B, T, H, D, dO)
+    assert not torch.isnan(O).any() and not torch.isnan(dqkv).any()
+    assert rel_l2(O.cpu(), ro.cpu()) < 3e-5
+    assert rel_l2(dqkv[:, :D].cpu(), rg[:, :D].cpu()) < 3e-5           # dQ
+    assert rel_l2(dqkv[:, D:2 * D].cpu(), rg[:, D:2 * D].cpu()) < 3e-5  # dK
+    assert rel_l2(dqkv[:, 2 * D:].cpu(), rg[:, 2 * D:].cpu()) < 3e-5    # dV
+    assert (dqkv[0, :7] == 0).all()
+
+
+def test_attention_rejects_unsupported(native_lib):
+    x = torch.zeros(8, device="cuda")
+    assert native_lib.qatvit_attn_forward(x.data_ptr(), x.data_ptr(), 0, 255, 1, 300, 1, 64, x.data_ptr(), x.data_ptr(), None) != 0
+    assert b"unsupported" in native_lib.qatvit_last_error()

@@ -90,7 +90,7 @@ def test_random_shapes_bit_exact_vs_oracle(native_lib, qmin, qmax, sym, pc):
             dy = rng.standard_normal(shape).astype(np.float32)
             dx = dev.backward(torch.from_numpy(dy).cuda())
             assert np.array_equal(_bits(y.cpu().numpy()), _bits(yr)), (shape, t)
-            assert np.array_equal(dx.cpu().numpy() != 0, mr & (dy != 0)), (shape, t)
+            assert np.array_equal(_bits(dx.cpu().numpy()), _bits(dy * mr.astype(np.float32))), (shape, t)
             assert np.array_equal(_bits(dev.sc.cpu().numpy()), _bits(st.scale)) and np.array_equal(dev.zp.cpu().numpy(), st.zero_point)
             assert np.array_equal(_bits(dev.mn.cpu().numpy().ravel()), _bits(st.min_val.ravel()))
 
