@@ -107,6 +107,10 @@ int qatvit_gemm_tn(int32_t q_is_f32, const float* P, const void* Q, float* C, in
                    int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale,
                    const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias, void* stream);
 
+/* timing-only ablation of the GEMM kernels (tools/bench_gemm.py): bit0 no stores, bit1 no MFMA, bit2 no k-loop loads.
+ * Results are invalid while nonzero; never set by the product path. */
+int qatvit_debug_gemm_ablate(int32_t flags);
+
 /* Attention core between attn.qkv and attn.proj (timm Attention; no fake-quant inside).
  *  qkv: PRE-fake-quant fp32 [B*T, 3*D]; qp: {scale, 1/scale, zero_point, enabled} of the qkv activation FQ
  *  (quantize-on-load).  O fp32 [B*T, D]; lse fp32 [B*H, qatvit_attn_padded_tokens(T)].

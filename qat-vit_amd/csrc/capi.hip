@@ -87,7 +87,7 @@ int qatvit_gemm_nt(int32_t a_is_f32, const void* A, const void* B, float* C, int
                    int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats,
                    const float* a_colscale, void* stream) {
     QV_CHECK_ARG(A && B && C, "qatvit_gemm_nt: null pointer argument");
-    if (launch_gemm_nt(a_is_f32, A, B, C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, a_colscale, (hipStream_t)stream)) return 1;
+    if (launch_gemm_nt(a_is_f32, A, B, C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, 1, a_colscale, (hipStream_t)stream)) return 1;
     QV_CHECK_LAUNCH("qatvit_gemm_nt");
     return 0;
 }
@@ -103,6 +103,8 @@ int qatvit_gemm_tn(int32_t q_is_f32, const float* P, const void* Q, float* C, in
     QV_CHECK_LAUNCH("qatvit_gemm_tn");
     return 0;
 }
+
+int qatvit_debug_gemm_ablate(int32_t flags) { return set_gemm_debug(flags); }
 
 int32_t qatvit_attn_padded_tokens(int32_t T) { return attn_padded_tokens(T); }
 

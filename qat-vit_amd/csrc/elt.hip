@@ -32,7 +32,7 @@ __device__ inline float fqi(float x, const QP& q, float fqmin, float fqmax) {
 
 static inline int rows_grid(int64_t rows) {
     int64_t b = (rows + 3) / 4;
-    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 static inline int flat_grid(int64_t n4) {
     int64_t b = (n4 + 255) / 256;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
                                                           int qmin, int qmax, const float* __restrict__ cls, const float* __restrict__ pos,
                                                           float* __restrict__ x_new, float* __restrict__ mean, float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                          uint32_t* __restrict__ stats, int64_t M, int D, int T) {
+                                                          uint32_t* __restrict__ stats, int stat_slots, int64_t M, int D, int T) {
     const QP q = load_qp(qpY);
     const int lane = threadIdx.x & 63;
     const int nv = (D + 255) / 256;
@@ -134,10 +134,11 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
     }
     mn = wave_min(mn);
     mx = wave_max(mx);
-    if (lane == 0) {
-        atomicMin(&stats[0], f2ord(mn));
-        atomicMax(&stats[1], f2ord(mx));
-    }
+    __shared__ float smn[4], smx[4];
+    if (lane == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        stat_atomic(stats, stat_slots, fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3])), fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3])));
 }
 
 // h_q[row][c] = q(LN(x)[row][c]) - zp  as bf16 (the exact A operand of the following GEMM)
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, c
                                                   const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ qp_norm,
                                                   int qmin, int qmax, const __bf16* __restrict__ wq, const float* __restrict__ w_scale,
                                                   int w_per_channel, const float* __restrict__ bias, float* __restrict__ hq_out,
-                                                  float* __restrict__ logits_pre, uint32_t* __restrict__ stats, int D, int T, int C) {
+                                                  float* __restrict__ logits_pre, uint32_t* __restrict__ stats, int stat_slots, int D, int T, int C) {
     extern __shared__ float sh[];  // D floats
     const QP q = load_qp(qp_norm);
     const int b = blockIdx.x;
@@ -312,8 +313,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, c
         if (lane == 0) {
             const float v = acc * (q.s * w_scale[w_per_channel ? c : 0]) + bias[c];
             logits_pre[(int64_t)b * C + c] = v;
-            atomicMin(&stats[0], f2ord(v));
-            atomicMax(&stats[1], f2ord(v));
+            stat_atomic(stats, stat_slots, v, v);
         }
     }
 }
@@ -436,13 +436,13 @@ int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qm
 }
 
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
-                            float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int64_t M,
-                            int D, int T, hipStream_t st) {
+                            float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
+                            int64_t M, int D, int T, hipStream_t st) {
     if (D % 4 != 0 || D > 256 * kMaxV) { set_error("resid_fq_lnstats: D=%d unsupported (need D%%4==0, D<=768)", D); return 1; }
     if (mode == 0)
-        k_resid_fq_lnstats<0><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, M, D, T);
+        k_resid_fq_lnstats<0><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T);
     else
-        k_resid_fq_lnstats<1><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, M, D, T);
+        k_resid_fq_lnstats<1><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T);
     return 0;
 }
 
@@ -477,9 +477,9 @@ int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean
 
 int launch_head_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp_norm, int qmin,
                     int qmax, const void* wq, const float* w_scale, int w_per_channel, const float* bias, float* hq, float* logits_pre,
-                    uint32_t* stats, int B, int D, int T, int C, hipStream_t st) {
+                    uint32_t* stats, int stat_slots, int B, int D, int T, int C, hipStream_t st) {
     k_head_fwd<<<B, 256, D * sizeof(float), st>>>(x, mean, rstd, gamma, beta, qp_norm, qmin, qmax, reinterpret_cast<const __bf16*>(wq), w_scale,
-                                                   w_per_channel, bias, hq, logits_pre, stats, D, T, C);
+                                                   w_per_channel, bias, hq, logits_pre, stats, stat_slots, D, T, C);
     return 0;
 }
 

@@ -65,7 +65,7 @@ struct Plan {
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
     int64_t dxA, dxB, dYs, dG, dY1, dH, dO, dqkv, delta, dh, dY0;
-    int64_t total;
+    int64_t total, stats_words;
     int TP;
 };
 
@@ -83,10 +83,12 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     for (int wi = 0; wi < d.n_w; ++wi) {
         int N, K; wshape(d, wi, &N, &K);
         const int ch = c.w_per_channel ? N : 1;
-        p->w_stats[wi] = 2 * d.n_act + wstat_words; wstat_words += 2 * ch;
+        p->w_stats[wi] = (int64_t)d.n_act * kStatSlots * kStatStride + wstat_words;
+        wstat_words += c.w_per_channel ? 2 * ch : kStatSlots * kStatStride;
         p->w_qp[wi] = wqp_floats; wqp_floats += 4 * ch;
     }
-    p->stats = take((2 * d.n_act + wstat_words) * 4);
+    p->stats_words = (int64_t)d.n_act * kStatSlots * kStatStride + wstat_words;
+    p->stats = take(p->stats_words * 4);
     p->qp_act = take((int64_t)d.n_act * 4 * 4);
     p->qp_w = take(wqp_floats * 4);
     p->imgq = take((int64_t)d.B * d.np * d.Kpe * 2);
@@ -153,7 +155,7 @@ struct Ctx {
     template <typename T> T* blk(int64_t off, int i) const { return reinterpret_cast<T*>(ws + off + p.blk_stride * i); }
     const float* prm(int i) const { return reinterpret_cast<const float*>(params[i]); }
     const float* bprm(int blk_i, int k) const { return prm(P_BLOCK0 + B_COUNT * blk_i + k); }
-    uint32_t* act_stats(int ai) const { return at<uint32_t>(p.stats) + 2 * ai; }
+    uint32_t* act_stats(int ai) const { return at<uint32_t>(p.stats) + (int64_t)ai * kStatSlots * kStatStride; }
     float* act_qp(int ai) const { return at<float>(p.qp_act) + 4 * ai; }
     float* w_qp(int wi) const { return at<float>(p.qp_w) + p.w_qp[wi]; }
     int aidx(int blk_i, int k) const { return A_BLOCK0 + AB_COUNT * blk_i + k; }
@@ -163,21 +165,21 @@ struct Ctx {
     void qparams_act(int ai) const {
         const qatvit_fq& f = act[ai];
         launch_qparams(act_stats(ai), f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const,
-                       c.act_qmin, c.act_qmax, 1, 0, act_qp(ai), 1, st);
+                       c.act_qmin, c.act_qmax, 1, 0, act_qp(ai), 1, kStatSlots, st);
     }
     // forward GEMM against fake-quantized weight wi: C = (A . wq^T) * s_act * s_w + bias, stats -> act FQ `ai_out`
     int linear_fwd(int a_is_f32, const void* A, int M, int wi, const float* s_act, const float* bias, float* C, int ai_out) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
         return launch_gemm_nt(a_is_f32, A, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
-                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), nullptr, st);
+                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, nullptr, st);
     }
     // dgrad: dX[M,K] = dY[M,N] . W_fq[N,K]
     int linear_dgrad(const float* dY, int M, int wi, float* dX) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
         return launch_gemm_nt(1, dY, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr, nullptr,
-                              nullptr, c.w_per_channel ? f.scale : nullptr, st);
+                              nullptr, 1, c.w_per_channel ? f.scale : nullptr, st);
     }
     // wgrad: dW[N,K] += sum_m dY[m,N] X[m,K] * s_x, masked by the weight FQ; db[N] += sum_m dY
     int linear_wgrad(const float* dY, int M, int wi, int x_is_f32, const void* X, const float* s_x, float* dW, float* db) const {
@@ -200,20 +202,20 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         const qatvit_fq& f = x.wfq[wi];
         const float* W = x.prm(wparam(d, wi));
         uint32_t* ws = x.at<uint32_t>(p.stats) + p.w_stats[wi];
-        launch_minmax(W, c.w_per_channel ? N : 1, c.w_per_channel ? K : (int64_t)N * K, c.w_per_channel, ws, st);
+        launch_minmax(W, c.w_per_channel ? N : 1, c.w_per_channel ? K : (int64_t)N * K, c.w_per_channel, ws, kStatSlots, st);
         launch_qparams(ws, f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const, c.w_qmin, c.w_qmax,
-                       c.w_per_channel ? N : 1, 1, x.w_qp(wi), 1, st);
+                       c.w_per_channel ? N : 1, 1, x.w_qp(wi), 1, c.w_per_channel ? 1 : kStatSlots, st);
         launch_wquant(W, x.w_qp(wi), c.w_per_channel, c.w_qmin, c.w_qmax, x.at<void>(p.w_off[wi]), x.at<void>(p.wT_off[wi]), N, K, st);
     }
     // ---- input image FQ + patch rows
-    launch_minmax(images, 1, (int64_t)d.B * d.chans * d.img * d.img, 0, x.act_stats(A_IN), st);
+    launch_minmax(images, 1, (int64_t)d.B * d.chans * d.img * d.img, 0, x.act_stats(A_IN), kStatSlots, st);
     x.qparams_act(A_IN);
     if (launch_img_patches(images, x.at<void>(p.imgq), x.act_qp(A_IN), qa, qb, d.B, d.chans, d.img, d.img, d.patch, st)) return 1;
     if (x.linear_fwd(0, x.at<void>(p.imgq), d.B * d.np, 0, x.act_qp(A_IN), x.prm(P_PE_B), x.at<float>(p.Y0), A_PE)) return 1;
     x.qparams_act(A_PE);
     if (launch_resid_fq_lnstats(0, nullptr, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, x.prm(P_CLS), x.prm(P_POS), x.blk<float>(p.x_in, 0),
                                 x.blk<float>(p.mean1, 0), x.blk<float>(p.rstd1, 0), x.bprm(0, B_N1W), x.bprm(0, B_N1B), c.ln_eps,
-                                x.act_stats(x.aidx(0, AB_N1)), d.M, d.D, d.T, st))
+                                x.act_stats(x.aidx(0, AB_N1)), kStatSlots, d.M, d.D, d.T, st))
         return 1;
     const int M = (int)d.M;
     for (int i = 0; i < d.depth; ++i) {
@@ -235,7 +237,7 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         x.qparams_act(x.aidx(i, AB_PROJ));
         launch_resid_fq_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, nullptr, nullptr, xmid,
                                 x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B), c.ln_eps,
-                                x.act_stats(x.aidx(i, AB_N2)), d.M, d.D, d.T, st);
+                                x.act_stats(x.aidx(i, AB_N2)), kStatSlots, d.M, d.D, d.T, st);
         // norm2 -> fc1 -> gelu -> fc2
         x.qparams_act(x.aidx(i, AB_N2));
         launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
@@ -255,7 +257,7 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         float* mean = last ? x.at<float>(p.meanF) : x.blk<float>(p.mean1, i + 1);
         float* rstd = last ? x.at<float>(p.rstdF) : x.blk<float>(p.rstd1, i + 1);
         launch_resid_fq_lnstats(1, xmid, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, nullptr, nullptr, x.blk<float>(p.x_in, i + 1),
-                                mean, rstd, g, bt, c.ln_eps, x.act_stats(last ? x.a_norm() : x.aidx(i + 1, AB_N1)), d.M, d.D, d.T, st);
+                                mean, rstd, g, bt, c.ln_eps, x.act_stats(last ? x.a_norm() : x.aidx(i + 1, AB_N1)), kStatSlots, d.M, d.D, d.T, st);
     }
     // ---- final norm (observer saw all tokens), cls pooling, head
     x.qparams_act(x.a_norm());
@@ -263,7 +265,7 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
     const int wh = d.n_w - 1;
     launch_head_fwd(x.blk<float>(p.x_in, d.depth), x.at<float>(p.meanF), x.at<float>(p.rstdF), x.prm(base), x.prm(base + 1), x.act_qp(x.a_norm()),
                     qa, qb, x.at<void>(p.w_off[wh]), x.wfq[wh].scale, c.w_per_channel, x.prm(base + 3), x.at<float>(p.hq), x.at<float>(p.logits_pre),
-                    x.act_stats(x.a_head()), d.B, d.D, d.T, d.C, st);
+                    x.act_stats(x.a_head()), kStatSlots, d.B, d.D, d.T, d.C, st);
     x.qparams_act(x.a_head());
     launch_logits_fq(x.at<float>(p.logits_pre), x.act_qp(x.a_head()), qa, qb, logits, d.B * d.C, st);
     return 0;
@@ -354,10 +356,7 @@ int qatvit_student_init(const qatvit_cfg* cfg, void* workspace, void* stream) {
     if (check_cfg(*cfg)) return 1;
     Plan p;
     if (make_plan(*cfg, &p)) return 1;
-    const Dims d = dims_of(*cfg);
-    int64_t words = 2 * d.n_act;
-    for (int wi = 0; wi < d.n_w; ++wi) { int N, K; wshape(d, wi, &N, &K); words += 2 * (cfg->w_per_channel ? N : 1); }
-    launch_ws_init(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + p.stats), words / 2, (hipStream_t)stream);
+    launch_ws_init(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + p.stats), p.stats_words / 2, (hipStream_t)stream);
     QV_CHECK_LAUNCH("qatvit_student_init");
     return 0;
 }

@@ -25,7 +25,7 @@ __global__ void k_ws_init(uint32_t* ws, int64_t channels) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_minmax_tensor(const float* __restrict__ x, int64_t n, uint32_t* ws) {
+__global__ __launch_bounds__(256) void k_minmax_tensor(const float* __restrict__ x, int64_t n, uint32_t* ws, int nslots) {
     float mn = INFINITY, mx = -INFINITY;
     const int64_t n4 = n >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -49,8 +49,7 @@ __global__ __launch_bounds__(256) void k_minmax_tensor(const float* __restrict__
     if (threadIdx.x == 0) {
         mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
         mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-        atomicMin(&ws[0], f2ord(mn));
-        atomicMax(&ws[1], f2ord(mx));
+        stat_atomic(ws, nslots, mn, mx);
     }
 }
 
@@ -138,19 +137,28 @@ __device__ inline float ema(float running, float cur, float c) {
 
 __global__ void k_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point,
                           const int64_t* observer_on, const int64_t* fake_quant_on, float c, int qmin, int qmax,
-                          int64_t channels, int symmetric, float* qp_out, int reset_ws) {
+                          int64_t channels, int symmetric, float* qp_out, int reset_ws, int nslots) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= channels) return;
     float mn = running_min[i], mx = running_max[i];
+    uint32_t omn = ws[2 * i], omx = ws[2 * i + 1];
+    if (nslots > 1) {  // per-tensor accumulator spread over nslots pairs (channels == 1)
+        for (int s = 1; s < nslots; ++s) {
+            omn = min(omn, ws[s * kStatStride]);
+            omx = max(omx, ws[s * kStatStride + 1]);
+        }
+    }
     if (*observer_on != 0) {
-        mn = ema(mn, ord2f(ws[2 * i]), c);
-        mx = ema(mx, ord2f(ws[2 * i + 1]), c);
+        mn = ema(mn, ord2f(omn), c);
+        mx = ema(mx, ord2f(omx), c);
         running_min[i] = mn;
         running_max[i] = mx;
     }
-    if (reset_ws) {  // the slot is an atomic min/max accumulator: re-arm it for the next step
-        ws[2 * i] = kOrdPosInf;
-        ws[2 * i + 1] = kOrdNegInf;
+    if (reset_ws) {  // the slots are atomic min/max accumulators: re-arm them for the next step
+        for (int s = 0; s < (nslots > 1 ? nslots : 1); ++s) {
+            ws[(nslots > 1 ? s * kStatStride : 2 * i)] = kOrdPosInf;
+            ws[(nslots > 1 ? s * kStatStride : 2 * i) + 1] = kOrdNegInf;
+        }
     }
     float s = scale[i];
     int32_t z = zero_point[i];
@@ -273,10 +281,10 @@ int launch_fq_forward(const float* x, float* y, uint8_t* mask_bits, float* runni
         k_minmax_rows<<<cdiv(channels, 4), 256, 0, st>>>(x, channels, inner, ws);
     } else {
         k_ws_init<<<1, 64, 0, st>>>(ws, 1);
-        k_minmax_tensor<<<stream_grid(n >> 2), 256, 0, st>>>(x, n, ws);
+        k_minmax_tensor<<<stream_grid(n >> 2), 256, 0, st>>>(x, n, ws, 1);
     }
     k_qparams<<<cdiv(channels, 64), 64, 0, st>>>(ws, running_min, running_max, scale, zero_point, observer_on, fake_quant_on, c, qmin,
-                                                  qmax, channels, symmetric ? 1 : 0, qp, 0);
+                                                  qmax, channels, symmetric ? 1 : 0, qp, 0, 1);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
     if (aligned && (channels == 1 || (inner & 7) == 0)) {
         dim3 grid(stream_grid(inner >> 3), (unsigned)channels);
@@ -289,9 +297,12 @@ int launch_fq_forward(const float* x, float* y, uint8_t* mask_bits, float* runni
 }
 
 // engine entry points: observer statistics and qparams as separate launches
-int launch_minmax(const float* x, int64_t channels, int64_t inner, int per_channel, uint32_t* ws, hipStream_t st) {
+int launch_minmax(const float* x, int64_t channels, int64_t inner, int per_channel, uint32_t* ws, int nslots, hipStream_t st) {
     if (per_channel) k_minmax_rows<<<cdiv(channels, 4), 256, 0, st>>>(x, channels, inner, ws);
-    else k_minmax_tensor<<<stream_grid((channels * inner) >> 2), 256, 0, st>>>(x, channels * inner, ws);
+    else {
+        int grid = stream_grid((channels * inner) >> 4);  // >= 16 elements per thread: few blocks, few atomics
+        k_minmax_tensor<<<grid, 256, 0, st>>>(x, channels * inner, ws, nslots);
+    }
     return 0;
 }
 int launch_ws_init(uint32_t* ws, int64_t slots, hipStream_t st) {
@@ -300,9 +311,9 @@ int launch_ws_init(uint32_t* ws, int64_t slots, hipStream_t st) {
 }
 int launch_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point, const int64_t* observer_on,
                    const int64_t* fake_quant_on, float c, int qmin, int qmax, int64_t channels, int symmetric, float* qp_out, int reset_ws,
-                   hipStream_t st) {
+                   int nslots, hipStream_t st) {
     k_qparams<<<cdiv(channels, 64), 64, 0, st>>>(ws, running_min, running_max, scale, zero_point, observer_on, fake_quant_on, c, qmin, qmax,
-                                                  channels, symmetric, qp_out, reset_ws);
+                                                  channels, symmetric, qp_out, reset_ws, nslots);
     return 0;
 }
 

@@ -37,6 +37,10 @@ __device__ inline int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// Timing-only ablation switches (tools/bench_gemm.py); 0 in every product build path.
+__device__ int g_dbg = 0;
+int set_gemm_debug(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int)); }
+
 // ============================================================================ NT
 // LDS image of a [rows][64 bf16] tile: 128-B rows, 16-B chunk index XOR (row & 7).
 __device__ inline int nt_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -50,7 +54,8 @@ struct NTArgs {
     const float* s2;
     const float* col_scale;  // optional [N] (per-channel weight scale), multiplies alpha
     const float* bias;       // optional [N]
-    uint32_t* stats;         // optional {ordered-min, ordered-max} of the stored values
+    uint32_t* stats;         // optional {ordered-min, ordered-max} accumulator of the stored values
+    int stat_slots;          // number of 128-B-spaced accumulator pairs (power of two; 1 = a single pair)
     const float* a_colscale; // optional [K]: fp32 A is multiplied by this per column before the split (per-channel dgrad)
 };
 
@@ -133,11 +138,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
     };
 
     const int nk = p.K / BK;
+    const int dbg = g_dbg;
     gload(0);
     lstore();
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (kt + 1 < nk && !(dbg & 4)) gload((kt + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 bfrag[TN];
@@ -152,8 +158,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
 #pragma unroll
                 for (int t = 0; t < TA; ++t) {
                     const bf16x8 af = *reinterpret_cast<const bf16x8*>(sA + t * BM * 128 + nt_off(row, 4 * kk + g));
+                    if (!(dbg & 2))
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[j], acc[i][j], 0, 0, 0);
+                    else asm volatile("" ::"v"(af));
                 }
             }
         }
@@ -163,43 +171,70 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
             __syncthreads();
         }
     }
+    if (dbg & 1) {  // timing only: keep the accumulators alive, store nothing
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
 
-    // ---- epilogue: C = acc * alpha[col] + bias[col]; min/max of what is stored
+    // ---- epilogue: C = acc * alpha[col] + bias[col]; min/max of what is stored.
+    // The accumulator layout (16 consecutive columns per 16 lanes, rows on registers) would give 64-B store
+    // segments; stage 64-row halves of the tile through LDS instead and store whole 16-B-per-lane row runs
+    // (BN*4 contiguous bytes per row).  The k-loop's last barrier has passed: the tile buffers are dead.
     float alpha = 1.f;
     if (p.s1) alpha *= *p.s1;
     if (p.s2) alpha *= *p.s2;
     float mn = INFINITY, mx = -INFINITY;
+    constexpr int LDC = BN + 4;                 // fp32 words per staged row (pad: conflict-free b32 writes)
+    float* sC = reinterpret_cast<float*>(smem); // [64][LDC]
+    constexpr int ROWS_PER_WAVE = BM / WM;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / WN) + 16 * j + r;
-        const float a = p.col_scale ? alpha * p.col_scale[col] : alpha;
-        const float b = p.bias ? p.bias[col] : 0.f;
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+        if ((wm * ROWS_PER_WAVE) / 64 == h) {
+            const int rbase = wm * ROWS_PER_WAVE - 64 * h;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int j = 0; j < TN; ++j) {
+                const int cl = wn * (BN / WN) + 16 * j + r;
+                const float a = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
+                const float b = p.bias ? p.bias[n0 + cl] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m0 + wm * (BM / WM) + 16 * i + 4 * g + e;
-                if (row < p.M) {
-                    const float v = acc[i][j][e] * a + b;
-                    p.C[(int64_t)row * p.ldc + col] = v;
-                    mn = fminf(mn, v);
-                    mx = fmaxf(mx, v);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int rl = rbase + 16 * i + 4 * g + e;
+                        const float v = acc[i][j][e] * a + b;
+                        sC[rl * LDC + cl] = v;
+                        if (m0 + 64 * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+                    }
             }
+        }
+        __syncthreads();
+        constexpr int C4 = BN / 4;              // float4 per row
+        constexpr int RPP = 256 / C4;           // rows per pass
+        const int c4 = tid % C4, r0 = tid / C4;
+#pragma unroll
+        for (int it = 0; it < 64 / RPP; ++it) {
+            const int rl = r0 + RPP * it;
+            const int row = m0 + 64 * h + rl;
+            if (row < p.M)
+                *reinterpret_cast<float4*>(p.C + (int64_t)row * p.ldc + n0 + 4 * c4) = *reinterpret_cast<const float4*>(sC + rl * LDC + 4 * c4);
         }
     }
     if (p.stats) {
         mn = wave_min(mn);
         mx = wave_max(mx);
-        float* smn = reinterpret_cast<float*>(smem);  // the tile buffers are dead after the k-loop's last barrier
+        __syncthreads();
+        float* smn = reinterpret_cast<float*>(smem);
         float* smx = smn + 4;
         if (lane == 0) { smn[wave] = mn; smx[wave] = mx; }
         __syncthreads();
         if (tid == 0) {
             mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
             mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-            atomicMin(&p.stats[0], f2ord(mn));
-            atomicMax(&p.stats[1], f2ord(mx));
+            stat_atomic(p.stats, p.stat_slots, mn, mx);
         }
     }
 }
@@ -213,23 +248,25 @@ template <int TA>
 static int launch_nt_t(const NTArgs& a, hipStream_t st) {
     if (a.N % 128 == 0) {
         const int nwg = cdiv(a.M, 128) * (a.N / 128);
-        const size_t lds = (size_t)(TA * 128 + 128) * 128;
+        size_t lds = (size_t)(TA * 128 + 128) * 128;
+        if (lds < 64 * (128 + 4) * 4) lds = 64 * (128 + 4) * 4;
         k_gemm_nt<TA, 128, 2, 2><<<nwg, 256, lds, st>>>(a);
     } else {
         const int nwg = cdiv(a.M, 128) * (a.N / 64);
-        const size_t lds = (size_t)(TA * 128 + 64) * 128;
+        size_t lds = (size_t)(TA * 128 + 64) * 128;
+        if (lds < 64 * (64 + 4) * 4) lds = 64 * (64 + 4) * 4;
         k_gemm_nt<TA, 64, 4, 1><<<nwg, 256, lds, st>>>(a);
     }
     return 0;
 }
 
 int launch_gemm_nt(int a_is_f32, const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, const float* a_colscale, hipStream_t st) {
-    if (M < 1 || N % 64 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) {
+                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, const float* a_colscale, hipStream_t st) {
+    if (M < 1 || N % 64 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) {
         set_error("gemm_nt: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d (need N%%64==0, K%%64==0, ld%%8==0)", M, N, K, lda, ldb);
         return 1;
     }
-    NTArgs a{A, reinterpret_cast<const __bf16*>(B), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, a_is_f32 ? a_colscale : nullptr};
+    NTArgs a{A, reinterpret_cast<const __bf16*>(B), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, a_is_f32 ? a_colscale : nullptr};
     return a_is_f32 ? launch_nt_t<2>(a, st) : launch_nt_t<1>(a, st);
 }
 

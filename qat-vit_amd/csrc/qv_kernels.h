@@ -19,24 +19,26 @@ int launch_kd_ce_loss(const float* student, const float* teacher, const int64_t*
                       float kd_alpha, float label_smoothing, float* out3, float* dlogits, hipStream_t st);
 
 // ---- fq.hip (engine pieces)
-int launch_minmax(const float* x, int64_t channels, int64_t inner, int per_channel, uint32_t* ws, hipStream_t st);
+int launch_minmax(const float* x, int64_t channels, int64_t inner, int per_channel, uint32_t* ws, int nslots, hipStream_t st);
 int launch_ws_init(uint32_t* ws, int64_t slots, hipStream_t st);
 int launch_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point, const int64_t* observer_on,
                    const int64_t* fake_quant_on, float c, int qmin, int qmax, int64_t channels, int symmetric, float* qp_out, int reset_ws,
-                   hipStream_t st);
+                   int nslots, hipStream_t st);
 
 // ---- gemm.hip
 int launch_gemm_nt(int a_is_f32, const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, const float* a_colscale, hipStream_t st);
+                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, const float* a_colscale, hipStream_t st);
 int launch_gemm_tn(int q_is_f32, const float* P, const void* Q, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s1,
                    const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
                    hipStream_t st);
 
+int set_gemm_debug(int v);
+
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st);
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
-                            float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int64_t M,
-                            int D, int T, hipStream_t st);
+                            float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
+                            int64_t M, int D, int T, hipStream_t st);
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
                           int qmax, void* out_bf16, int64_t M, int D, hipStream_t st);
 int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, float* G, int64_t n, hipStream_t st);
@@ -46,7 +48,7 @@ int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean
                      int cls_only, hipStream_t st);
 int launch_head_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp_norm, int qmin,
                     int qmax, const void* wq, const float* w_scale, int w_per_channel, const float* bias, float* hq, float* logits_pre,
-                    uint32_t* stats, int B, int D, int T, int C, hipStream_t st);
+                    uint32_t* stats, int stat_slots, int B, int D, int T, int C, hipStream_t st);
 int launch_logits_fq(const float* pre, const float* qp, int qmin, int qmax, float* out, int n, hipStream_t st);
 int launch_head_bwd(const float* dlogits, const float* logits_pre, const float* qp_logits, int qmin, int qmax, const float* hq, const float* qp_norm,
                     const void* wq, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dW,

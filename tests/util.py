@@ -29,3 +29,36 @@ def fq_modules(prepared):
     from torch.ao.quantization.fake_quantize import FusedMovingAvgObsFakeQuantize as FQ
 
     return {n: m for n, m in prepared.named_modules() if isinstance(m, FQ)}
+
+
+def ws_tensor(eng, name, blk, shape, dtype=None):
+    """A named intermediate tensor of the native engine's last step (view into its workspace)."""
+    import ctypes
+
+    dtype = dtype or torch.float32
+    off = eng.lib.qatvit_student_tensor_offset(ctypes.byref(eng.cfg), name.encode(), blk)
+    assert off >= 0, name
+    n = 1
+    for s in shape:
+        n *= s
+    return eng.workspace[off:off + n * (4 if dtype == torch.float32 else 2)].view(dtype).view(*shape)
+
+
+def capture_fq_io(prepared):
+    """Forward hooks on every activation fake-quant module: name -> (pre-FQ input, output)."""
+    caps = {}
+    for n, m in fq_modules(prepared).items():
+        if "weight_fake_quant" in n:
+            continue
+
+        def hook(mod, inp, out, n=n):
+            caps[n] = (inp[0].detach(), out.detach())
+
+        m.register_forward_hook(hook)
+    return caps
+
+
+def cosine(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
