@@ -89,37 +89,39 @@ int qatvit_kd_ce_loss(const float* student, const float* teacher, const int64_t*
  * All matrices row-major; "bf16" = IEEE bfloat16 bit patterns (uint16).
  */
 
-/* C[M,N] = (A[M,K] . B[N,K]^T) * (*s1) * (*s2) * col_scale[n] + bias[n]   (fp32 out)
+/* Operand convention of the GEMMs: every operand is a row-major bf16 matrix.  A tensor that sits on a
+ * fake-quant grid is passed as the integers (q - zero_point) (exact in bf16, `_lo` = NULL); a float tensor
+ * is passed as the pair hi = bf16(x), lo = bf16(x - hi) written by its producer kernel (2^-17 relative).
+ *
+ * C[M,N] = ((A_hi + A_lo)[M,K] . B[N,K]^T) * (*s1) * (*s2) * col_scale[n] + bias[n]   (fp32 out)
  * Replaces: F.linear inside nnqat.Linear.forward (torch/ao/nn/qat/modules/linear.py:49-50) and its dgrad.
- *  a_is_f32 = 0: A is bf16 (exact grid integers); 1: A is fp32 and is split hi/lo bf16 in the loader
- *  (optionally multiplied by a_colscale[k] first).  B is bf16.  s1,s2,col_scale,bias,stats,a_colscale may be NULL.
- *  stats: 2 x uint32 order-preserving min/max accumulator of the stored values (see qatvit_fq_workspace_bytes).
- *  Shapes: N % 64 == 0, K % 64 == 0. */
-int qatvit_gemm_nt(int32_t a_is_f32, const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K,
+ *  s1, s2, col_scale, bias, stats may be NULL.  stats: 2 x uint32 order-preserving {min,max} accumulator
+ *  of the stored values (initialise to {0xFF800000, 0x007FFFFF}).  Shapes: N % 128 == 0, K % 64 == 0. */
+int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int32_t M, int32_t N, int32_t K,
                    int32_t lda, int32_t ldb, int32_t ldc, const float* s1, const float* s2, const float* col_scale,
-                   const float* bias, uint32_t* stats, const float* a_colscale, void* stream);
+                   const float* bias, uint32_t* stats, void* stream);
 
-/* C[N,Kw] += sum_m P[m,N] * Q[m,Kw] * (*s1), masked by the weight fake-quant STE mask of W; dbias[N] += sum_m P[m,N].
+/* C[N,Kw] += sum_m (P_hi + P_lo)[m,N] * (Q_hi + Q_lo)[m,Kw] * (*s1) / row_div[n], masked by the weight fake-quant STE
+ * mask of W; dbias[N] += sum_m P[m,N] / row_div[n].
  * Replaces: the weight/bias gradient of nnqat.Linear / nnqat.Conv2d (autograd of linear.py:49-50, conv.py:54-55,
- * followed by the weight_fake_quant backward).  P fp32; Q bf16 (q_is_f32=0) or fp32 (1).  C, dbias are accumulated
- * with atomics (caller zeroes).  W (fp32 [N,Kw]) + w_scale/w_zp ([1] or [N]) may be NULL = no mask. */
-int qatvit_gemm_tn(int32_t q_is_f32, const float* P, const void* Q, float* C, int32_t M, int32_t N, int32_t Kw,
-                   int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale,
-                   const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias, void* stream);
-
-/* timing-only ablation of the GEMM kernels (tools/bench_gemm.py): bit0 no stores, bit1 no MFMA, bit2 no k-loop loads.
- * Results are invalid while nonzero; never set by the product path. */
-int qatvit_debug_gemm_ablate(int32_t flags);
+ * followed by the weight_fake_quant backward).  C, dbias are accumulated with atomics (caller zeroes).
+ * Q_lo, s1, W (fp32 [N,Kw], with w_scale/w_zp [1] or [N]), dbias, row_div may be NULL.  N % 128 == 0, Kw % 128 == 0. */
+int qatvit_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int32_t M, int32_t N,
+                   int32_t Kw, int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale,
+                   const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias,
+                   const float* row_div, void* stream);
 
 /* Attention core between attn.qkv and attn.proj (timm Attention; no fake-quant inside).
  *  qkv: PRE-fake-quant fp32 [B*T, 3*D]; qp: {scale, 1/scale, zero_point, enabled} of the qkv activation FQ
- *  (quantize-on-load).  O fp32 [B*T, D]; lse fp32 [B*H, qatvit_attn_padded_tokens(T)].
- *  backward writes dqkv = d/d(pre-FQ qkv), i.e. including the FQ STE mask; delta is scratch like lse. */
+ *  (quantize-on-load).  O = O_hi + O_lo, bf16 [B*T, D] each; lse fp32 [B*H, qatvit_attn_padded_tokens(T)].
+ *  backward writes dqkv (hi/lo bf16 [B*T, 3*D]) = d/d(pre-FQ qkv), i.e. including the FQ STE mask, times
+ *  col_scale[3*D] if given; delta is scratch like lse; dO is fp32 [B*T, D]. */
 int32_t qatvit_attn_padded_tokens(int32_t T);
 int qatvit_attn_forward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
-                        int32_t D, float* O, float* lse, void* stream);
+                        int32_t D, void* O_hi, void* O_lo, float* lse, void* stream);
 int qatvit_attn_backward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
-                         int32_t D, const float* O, const float* lse, float* delta, const float* dO, float* dqkv, void* stream);
+                         int32_t D, const void* O_hi, const void* O_lo, const float* lse, float* delta, const float* dO,
+                         void* dqkv_hi, void* dqkv_lo, const float* col_scale, void* stream);
 
 /* ===========================================================================
  * The whole student step.

@@ -94,7 +94,7 @@ def gen_fq():
     for cn, (qmin, qmax, sym, pc) in cfgs.items():
         for gn, g in gens.items():
             for (obs, fq) in [(1, 1), (1, 0), (2, 1)]:  # 2 = observer on for step 0 only
-                shape = (12, 5, 4, 4) if pc else (37, 21)
+                shape = (12, 5, 4, 4) if pc else (23, 11)
                 mn = torch.tensor([]) if pc else torch.tensor(float("inf"))
                 mx = torch.tensor([]) if pc else torch.tensor(float("-inf"))
                 sc, zp = torch.ones(1), torch.zeros(1, dtype=torch.int32)
@@ -170,7 +170,7 @@ def _run_steps(reg, backend, kw, B, img, seed, nsteps, teacher, full_grads):
         for n, p in prepared.named_parameters():
             gr = p.grad.detach()
             out[f"s{s}/gnorm/{n}"] = np.float64(gr.double().norm().item())
-            if full_grads:
+            if full_grads and s == 0:
                 out[f"s{s}/grad/{n}"] = gr.numpy().copy()
             else:
                 out[f"s{s}/gslice/{n}"] = gr.flatten()[:: max(1, gr.numel() // 64)][:64].numpy().copy()

@@ -25,7 +25,7 @@ VIT_CONFIGS = {
     "vit_small_patch16_224": (384, 12, 6),
     "vit_base_patch16_224": (768, 12, 12),
     # reduced shapes for fast fixtures (not a reference model name)
-    "vit_tiny_test": (64, 2, 2),
+    "vit_tiny_test": (128, 2, 2),
 }
 
 

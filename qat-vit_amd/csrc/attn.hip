@@ -17,6 +17,7 @@
 namespace qv {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -82,11 +83,14 @@ struct AttnArgs {
     int qmin, qmax;
     int B, T, H, D;     // D = H*HD
     float softmax_scale;
-    float* O;           // fwd out / bwd in: [B*T, D]
+    __bf16* O_hi;       // fwd out / bwd in: O = hi + lo, bf16 [B*T, D] each (the split-bf16 A operand of attn.proj)
+    __bf16* O_lo;
     float* lse;         // [B*H, TP]  (TP = padded tokens)
     float* delta;       // [B*H, TP]
-    const float* dO;    // [B*T, D]
-    float* dqkv;        // [B*T, 3*D]  d(loss)/d(pre-FQ qkv), i.e. already multiplied by the FQ mask
+    const float* dO;    // fp32 [B*T, D]
+    __bf16* dqkv_hi;    // [B*T, 3*D] hi/lo of d(loss)/d(pre-FQ qkv): already multiplied by the FQ mask (and by col_scale)
+    __bf16* dqkv_lo;
+    const float* col_scale;  // optional [3*D]: per-channel weight scale of attn.qkv folded into dqkv (see k_mask_bwd)
 };
 
 // stage one [T][HD] slice (q, k or v of head h) into an LDS image; `which`: 0 q, 1 k, 2 v
@@ -196,7 +200,13 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int qq = qt * 16 + 4 * g + e;
-                if (qq < T) p.O[((int64_t)b * T + qq) * D + h * HD + 16 * jd + r] = o[jd][e] * q.s;
+                if (qq < T) {
+                    const float v = o[jd][e] * q.s;
+                    const __bf16 hi = (__bf16)v;
+                    const int64_t off = ((int64_t)b * T + qq) * D + h * HD + 16 * jd + r;
+                    p.O_hi[off] = hi;
+                    p.O_lo[off] = (__bf16)(v - (float)hi);
+                }
             }
     }
 }
@@ -229,11 +239,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnArgs p) {
         for (int kk = 0; kk < HD / 32; ++kk) {
             qf[kk] = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
             const float* pd = p.dO + ((int64_t)b * T + qrow) * D + h * HD + 32 * kk + 8 * g;
-            const float* po = p.O + ((int64_t)b * T + qrow) * D + h * HD + 32 * kk + 8 * g;
+            const int64_t ooff = ((int64_t)b * T + qrow) * D + h * HD + 32 * kk + 8 * g;
             load_split8(pd, dh[kk], dl[kk]);
             const float4 d0 = reinterpret_cast<const float4*>(pd)[0], d1 = reinterpret_cast<const float4*>(pd)[1];
-            const float4 o0 = reinterpret_cast<const float4*>(po)[0], o1 = reinterpret_cast<const float4*>(po)[1];
-            dpart += (d0.x * o0.x + d0.y * o0.y) + (d0.z * o0.z + d0.w * o0.w) + (d1.x * o1.x + d1.y * o1.y) + (d1.z * o1.z + d1.w * o1.w);
+            const bf16x8 oh = *reinterpret_cast<const bf16x8*>(p.O_hi + ooff), ol = *reinterpret_cast<const bf16x8*>(p.O_lo + ooff);
+            const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dpart += dv[j] * ((float)oh[j] + (float)ol[j]);
         }
         dpart += __shfl_xor(dpart, 16, 64);
         dpart += __shfl_xor(dpart, 32, 64);
@@ -282,7 +294,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnArgs p) {
                 const int qq = qt * 16 + 4 * g + e;
                 if (qq < T) {
                     const int64_t off = ((int64_t)b * T + qq) * ld + h * HD + 16 * jd + r;
-                    p.dqkv[off] = qin(p.qkv[off], q) ? dq[jd][e] * a : 0.f;
+                    float v = qin(p.qkv[off], q) ? dq[jd][e] * a : 0.f;
+                    if (p.col_scale) v *= p.col_scale[h * HD + 16 * jd + r];
+                    const __bf16 hi = (__bf16)v;
+                    p.dqkv_hi[off] = hi;
+                    p.dqkv_lo[off] = (__bf16)(v - (float)hi);
                 }
             }
     }
@@ -372,12 +388,25 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnArgs p) {
                 const int64_t offk = ((int64_t)b * T + 16 * j + r) * ld + D + h * HD + 16 * id + 4 * g;
                 const int64_t offv = offk + D;
                 const float4 xk = *reinterpret_cast<const float4*>(p.qkv + offk), xv = *reinterpret_cast<const float4*>(p.qkv + offv);
-                *reinterpret_cast<float4*>(p.dqkv + offk) =
-                    make_float4(qin(xk.x, q) ? dk[id][0] * a : 0.f, qin(xk.y, q) ? dk[id][1] * a : 0.f, qin(xk.z, q) ? dk[id][2] * a : 0.f,
-                                qin(xk.w, q) ? dk[id][3] * a : 0.f);
-                *reinterpret_cast<float4*>(p.dqkv + offv) =
-                    make_float4(qin(xv.x, q) ? dv[id][0] : 0.f, qin(xv.y, q) ? dv[id][1] : 0.f, qin(xv.z, q) ? dv[id][2] : 0.f,
-                                qin(xv.w, q) ? dv[id][3] : 0.f);
+                float4 ck = make_float4(1.f, 1.f, 1.f, 1.f), cv = ck;
+                if (p.col_scale) {
+                    ck = *reinterpret_cast<const float4*>(p.col_scale + D + h * HD + 16 * id + 4 * g);
+                    cv = *reinterpret_cast<const float4*>(p.col_scale + 2 * D + h * HD + 16 * id + 4 * g);
+                }
+                const float vk[4] = {qin(xk.x, q) ? dk[id][0] * a * ck.x : 0.f, qin(xk.y, q) ? dk[id][1] * a * ck.y : 0.f,
+                                     qin(xk.z, q) ? dk[id][2] * a * ck.z : 0.f, qin(xk.w, q) ? dk[id][3] * a * ck.w : 0.f};
+                const float vv[4] = {qin(xv.x, q) ? dv[id][0] * cv.x : 0.f, qin(xv.y, q) ? dv[id][1] * cv.y : 0.f,
+                                     qin(xv.z, q) ? dv[id][2] * cv.z : 0.f, qin(xv.w, q) ? dv[id][3] * cv.w : 0.f};
+                bf16x4 kh, kl, vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kh[e] = (__bf16)vk[e]; kl[e] = (__bf16)(vk[e] - (float)kh[e]);
+                    vh[e] = (__bf16)vv[e]; vl[e] = (__bf16)(vv[e] - (float)vh[e]);
+                }
+                *reinterpret_cast<bf16x4*>(p.dqkv_hi + offk) = kh;
+                *reinterpret_cast<bf16x4*>(p.dqkv_lo + offk) = kl;
+                *reinterpret_cast<bf16x4*>(p.dqkv_hi + offv) = vh;
+                *reinterpret_cast<bf16x4*>(p.dqkv_lo + offv) = vl;
             }
         }
     }
@@ -419,14 +448,18 @@ static int dispatch(int which, const AttnArgs& a, hipStream_t st) {
 
 int attn_padded_tokens(int T) { return T <= 32 ? 32 : 224; }
 
-int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, float* O, float* lse, hipStream_t st) {
-    AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), O, lse, nullptr, nullptr, nullptr};
+int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, void* O_hi, void* O_lo, float* lse,
+                    hipStream_t st) {
+    AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), reinterpret_cast<__bf16*>(O_hi), reinterpret_cast<__bf16*>(O_lo), lse,
+               nullptr, nullptr, nullptr, nullptr, nullptr};
     return dispatch(0, a, st);
 }
 
-int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const float* O, const float* lse,
-                    float* delta, const float* dO, float* dqkv, hipStream_t st) {
-    AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), const_cast<float*>(O), const_cast<float*>(lse), delta, dO, dqkv};
+int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const void* O_hi, const void* O_lo,
+                    const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st) {
+    AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), reinterpret_cast<__bf16*>(const_cast<void*>(O_hi)),
+               reinterpret_cast<__bf16*>(const_cast<void*>(O_lo)), const_cast<float*>(lse), delta, dO, reinterpret_cast<__bf16*>(dqkv_hi),
+               reinterpret_cast<__bf16*>(dqkv_lo), col_scale};
     if (dispatch(1, a, st)) return 1;
     return dispatch(2, a, st);
 }

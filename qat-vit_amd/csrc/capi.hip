@@ -83,44 +83,42 @@ int qatvit_kd_ce_loss(const float* student, const float* teacher, const int64_t*
     return 0;
 }
 
-int qatvit_gemm_nt(int32_t a_is_f32, const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
-                   int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats,
-                   const float* a_colscale, void* stream) {
-    QV_CHECK_ARG(A && B && C, "qatvit_gemm_nt: null pointer argument");
-    if (launch_gemm_nt(a_is_f32, A, B, C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, 1, a_colscale, (hipStream_t)stream)) return 1;
+int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                   int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream) {
+    QV_CHECK_ARG(A_hi && B && C, "qatvit_gemm_nt: null pointer argument");
+    if (launch_gemm_nt(A_hi, A_lo, B, C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream)) return 1;
     QV_CHECK_LAUNCH("qatvit_gemm_nt");
     return 0;
 }
 
-int qatvit_gemm_tn(int32_t q_is_f32, const float* P, const void* Q, float* C, int32_t M, int32_t N, int32_t Kw, int32_t ldp, int32_t ldq,
-                   int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel,
-                   int32_t w_qmin, int32_t w_qmax, float* dbias, void* stream) {
-    QV_CHECK_ARG(P && Q && C, "qatvit_gemm_tn: null pointer argument");
+int qatvit_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int32_t M, int32_t N, int32_t Kw, int32_t ldp,
+                   int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel,
+                   int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, void* stream) {
+    QV_CHECK_ARG(P_hi && P_lo && Q_hi && C, "qatvit_gemm_tn: null pointer argument");
     QV_CHECK_ARG(!W || (w_scale && w_zp), "qatvit_gemm_tn: weight mask needs w_scale and w_zp");
-    if (launch_gemm_tn(q_is_f32, P, Q, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias,
+    if (launch_gemm_tn(P_hi, P_lo, Q_hi, Q_lo, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div,
                        (hipStream_t)stream))
         return 1;
     QV_CHECK_LAUNCH("qatvit_gemm_tn");
     return 0;
 }
 
-int qatvit_debug_gemm_ablate(int32_t flags) { return set_gemm_debug(flags); }
-
 int32_t qatvit_attn_padded_tokens(int32_t T) { return attn_padded_tokens(T); }
 
-int qatvit_attn_forward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H, int32_t D, float* O,
-                        float* lse, void* stream) {
-    QV_CHECK_ARG(qkv && qp && O && lse, "qatvit_attn_forward: null pointer argument");
+int qatvit_attn_forward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H, int32_t D, void* O_hi,
+                        void* O_lo, float* lse, void* stream) {
+    QV_CHECK_ARG(qkv && qp && O_hi && O_lo && lse, "qatvit_attn_forward: null pointer argument");
     QV_CHECK_ARG(B >= 1 && T >= 1 && H >= 1, "qatvit_attn_forward: empty shape");
-    if (launch_attn_fwd(qkv, qp, qmin, qmax, B, T, H, D, O, lse, (hipStream_t)stream)) return 1;
+    if (launch_attn_fwd(qkv, qp, qmin, qmax, B, T, H, D, O_hi, O_lo, lse, (hipStream_t)stream)) return 1;
     QV_CHECK_LAUNCH("qatvit_attn_forward");
     return 0;
 }
 
 int qatvit_attn_backward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H, int32_t D,
-                         const float* O, const float* lse, float* delta, const float* dO, float* dqkv, void* stream) {
-    QV_CHECK_ARG(qkv && qp && O && lse && delta && dO && dqkv, "qatvit_attn_backward: null pointer argument");
-    if (launch_attn_bwd(qkv, qp, qmin, qmax, B, T, H, D, O, lse, delta, dO, dqkv, (hipStream_t)stream)) return 1;
+                         const void* O_hi, const void* O_lo, const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo,
+                         const float* col_scale, void* stream) {
+    QV_CHECK_ARG(qkv && qp && O_hi && O_lo && lse && delta && dO && dqkv_hi && dqkv_lo, "qatvit_attn_backward: null pointer argument");
+    if (launch_attn_bwd(qkv, qp, qmin, qmax, B, T, H, D, O_hi, O_lo, lse, delta, dO, dqkv_hi, dqkv_lo, col_scale, (hipStream_t)stream)) return 1;
     QV_CHECK_LAUNCH("qatvit_attn_backward");
     return 0;
 }

@@ -30,6 +30,15 @@ __device__ inline float fqi(float x, const QP& q, float fqmin, float fqmax) {
     return fminf(fmaxf(rintf(x * q.inv) + q.zp, fqmin), fqmax) - q.zp;
 }
 
+// float operand of a later GEMM -> (hi, lo) bf16 pair, 4 elements
+__device__ inline void store_split4(__bf16* hi, __bf16* lo, int64_t off, float a, float b, float c, float d) {
+    bf16x4 h, l;
+    h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+    l[0] = (__bf16)(a - (float)h[0]); l[1] = (__bf16)(b - (float)h[1]); l[2] = (__bf16)(c - (float)h[2]); l[3] = (__bf16)(d - (float)h[3]);
+    *reinterpret_cast<bf16x4*>(hi + off) = h;
+    *reinterpret_cast<bf16x4*>(lo + off) = l;
+}
+
 static inline int rows_grid(int64_t rows) {
     int64_t b = (rows + 3) / 4;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -170,33 +179,41 @@ __device__ inline float dgelu(float x) {
 }
 
 __global__ __launch_bounds__(256) void k_fq_gelu(const float* __restrict__ Y, const float* __restrict__ qp, int qmin, int qmax,
-                                                 float* __restrict__ G, int64_t n4) {
+                                                 __bf16* __restrict__ G_hi, __bf16* __restrict__ G_lo, int64_t n4) {
     const QP q = load_qp(qp);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(Y)[i];
         bool in;
-        reinterpret_cast<float4*>(G)[i] = make_float4(gelu(fqv(v.x, q, qmin, qmax, in)), gelu(fqv(v.y, q, qmin, qmax, in)),
-                                                      gelu(fqv(v.z, q, qmin, qmax, in)), gelu(fqv(v.w, q, qmin, qmax, in)));
+        store_split4(G_hi, G_lo, i * 4, gelu(fqv(v.x, q, qmin, qmax, in)), gelu(fqv(v.y, q, qmin, qmax, in)), gelu(fqv(v.z, q, qmin, qmax, in)),
+                     gelu(fqv(v.w, q, qmin, qmax, in)));
     }
 }
 
-// GELU_BWD=0: dst = d * mask(Y);  GELU_BWD=1: dst = d * gelu'(fq(Y)) * mask(Y)
+// GELU_BWD=0: dY = d * mask(Y);  GELU_BWD=1: dY = d * gelu'(fq(Y)) * mask(Y); optionally * col_scale[col]
+// (per-channel weight scale of the consuming layer, folded here because dgrad's reduction runs over that axis).
+// Output: the (hi, lo) bf16 pair both the dgrad and the wgrad GEMM read.
 template <int GELU_BWD>
 __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ d, const float* __restrict__ Y, const float* __restrict__ qp,
-                                                  int qmin, int qmax, float* __restrict__ dst, int64_t n4) {
+                                                  int qmin, int qmax, const float* __restrict__ col_scale, int ncols4,
+                                                  __bf16* __restrict__ dst_hi, __bf16* __restrict__ dst_lo, int64_t n4) {
     const QP q = load_qp(qp);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(Y)[i];
         const float4 g = reinterpret_cast<const float4*>(d)[i];
         const float in4[4] = {v.x, v.y, v.z, v.w}, g4[4] = {g.x, g.y, g.z, g.w};
+        float cs[4] = {1.f, 1.f, 1.f, 1.f};
+        if (col_scale) {
+            const float4 c = reinterpret_cast<const float4*>(col_scale)[i % ncols4];
+            cs[0] = c.x; cs[1] = c.y; cs[2] = c.z; cs[3] = c.w;
+        }
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             bool in;
             const float f = fqv(in4[e], q, qmin, qmax, in);
-            o[e] = in ? (GELU_BWD ? g4[e] * dgelu(f) : g4[e]) : 0.f;
+            o[e] = in ? (GELU_BWD ? g4[e] * dgelu(f) : g4[e]) * cs[e] : 0.f;
         }
-        reinterpret_cast<float4*>(dst)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        store_split4(dst_hi, dst_lo, i * 4, o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dlog
 // dx0 [B,T,D] -> dpos[t,:] = sum_b dx0[b,t,:]; dcls = sum_b dx0[b,0,:]; dY0[b*np+p,:] = dx0[b,1+p,:] * mask(Y0)
 __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dx0, const float* __restrict__ Y0, const float* __restrict__ qp,
                                                    int qmin, int qmax, float* __restrict__ dpos, float* __restrict__ dcls,
-                                                   float* __restrict__ dY0, int B, int T, int D) {
+                                                   __bf16* __restrict__ dY0_hi, __bf16* __restrict__ dY0_lo, int B, int T, int D) {
     const QP q = load_qp(qp);
     const int d4 = D / 4;
     const int64_t n4 = (int64_t)T * d4;
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dx0
                 const float4 y = *reinterpret_cast<const float4*>(Y0 + yo);
                 bool i0, i1, i2, i3;
                 fqv(y.x, q, qmin, qmax, i0); fqv(y.y, q, qmin, qmax, i1); fqv(y.z, q, qmin, qmax, i2); fqv(y.w, q, qmin, qmax, i3);
-                *reinterpret_cast<float4*>(dY0 + yo) = make_float4(i0 ? g.x : 0.f, i1 ? g.y : 0.f, i2 ? g.z : 0.f, i3 ? g.w : 0.f);
+                store_split4(dY0_hi, dY0_lo, yo, i0 ? g.x : 0.f, i1 ? g.y : 0.f, i2 ? g.z : 0.f, i3 ? g.w : 0.f);
             }
         }
         *reinterpret_cast<float4*>(dpos + (int64_t)t * D + c) = acc;
@@ -452,14 +469,17 @@ int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, 
     return 0;
 }
 
-int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, float* G, int64_t n, hipStream_t st) {
-    k_fq_gelu<<<flat_grid(n / 4), 256, 0, st>>>(Y, qp, qmin, qmax, G, n / 4);
+int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, void* G_hi, void* G_lo, int64_t n, hipStream_t st) {
+    k_fq_gelu<<<flat_grid(n / 4), 256, 0, st>>>(Y, qp, qmin, qmax, reinterpret_cast<__bf16*>(G_hi), reinterpret_cast<__bf16*>(G_lo), n / 4);
     return 0;
 }
 
-int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, float* dst, int64_t n, hipStream_t st) {
-    if (gelu_bwd) k_mask_bwd<1><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, dst, n / 4);
-    else k_mask_bwd<0><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, dst, n / 4);
+int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, const float* col_scale, int ncols,
+                    void* dst_hi, void* dst_lo, int64_t n, hipStream_t st) {
+    __bf16* h = reinterpret_cast<__bf16*>(dst_hi);
+    __bf16* l = reinterpret_cast<__bf16*>(dst_lo);
+    if (gelu_bwd) k_mask_bwd<1><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, col_scale, ncols / 4, h, l, n / 4);
+    else k_mask_bwd<0><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, col_scale, ncols / 4, h, l, n / 4);
     return 0;
 }
 
@@ -496,9 +516,10 @@ int launch_head_bwd(const float* dlogits, const float* logits_pre, const float* 
     return 0;
 }
 
-int launch_embed_bwd(const float* dx0, const float* Y0, const float* qp, int qmin, int qmax, float* dpos, float* dcls, float* dY0, int B, int T, int D,
-                     hipStream_t st) {
-    k_embed_bwd<<<flat_grid((int64_t)T * (D / 4)), 256, 0, st>>>(dx0, Y0, qp, qmin, qmax, dpos, dcls, dY0, B, T, D);
+int launch_embed_bwd(const float* dx0, const float* Y0, const float* qp, int qmin, int qmax, float* dpos, float* dcls, void* dY0_hi, void* dY0_lo,
+                     int B, int T, int D, hipStream_t st) {
+    k_embed_bwd<<<flat_grid((int64_t)T * (D / 4)), 256, 0, st>>>(dx0, Y0, qp, qmin, qmax, dpos, dcls, reinterpret_cast<__bf16*>(dY0_hi),
+                                                                  reinterpret_cast<__bf16*>(dY0_lo), B, T, D);
     return 0;
 }
 

@@ -60,11 +60,11 @@ static int wparam(const Dims& d, int wi) {  // index of the weight tensor in par
 struct Plan {
     // byte offsets into the workspace
     int64_t stats, qp_act, qp_w, imgq, Y0, meanF, rstdF, hq, logits_pre;
-    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O, lse, Yproj, h2q, Y1, G, Y2;  // per-block base, stride blk
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2;  // per-block base, stride blk
     int64_t blk_stride;
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
-    int64_t dxA, dxB, dYs, dG, dY1, dH, dO, dqkv, delta, dh, dY0;
+    int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo;
     int64_t total, stats_words;
     int TP;
 };
@@ -103,12 +103,12 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->mean1 = take(M * 4); p->rstd1 = take(M * 4); p->mean2 = take(M * 4); p->rstd2 = take(M * 4);
     p->h1q = take(M * D * 2);
     p->qkv = take(M * 3 * D * 4);
-    p->O = take(M * D * 4);
+    p->O_hi = take(M * D * 2); p->O_lo = take(M * D * 2);
     p->lse = take((int64_t)d.B * d.H * p->TP * 4);
     p->Yproj = take(M * D * 4);
     p->h2q = take(M * D * 2);
     p->Y1 = take(M * Hd * 4);
-    p->G = take(M * Hd * 4);
+    p->G_hi = take(M * Hd * 2); p->G_lo = take(M * Hd * 2);
     p->Y2 = take(M * D * 4);
     p->blk_stride = o - b0;
     o = b0 + p->blk_stride * d.depth;
@@ -121,20 +121,21 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
         p->wT_off[wi] = take((int64_t)N * K * 2);
     }
     p->dxA = take(M * D * 4); p->dxB = take(M * D * 4);
-    p->dYs = take(M * D * 4);
-    p->dG = take(M * Hd * 4); p->dY1 = take(M * Hd * 4);
+    p->dYs_hi = take(M * D * 2); p->dYs_lo = take(M * D * 2);
+    p->dG = take(M * Hd * 4);
+    p->dY1_hi = take(M * Hd * 2); p->dY1_lo = take(M * Hd * 2);
     p->dH = take(M * D * 4); p->dO = take(M * D * 4);
-    p->dqkv = take(M * 3 * D * 4);
+    p->dqkv_hi = take(M * 3 * D * 2); p->dqkv_lo = take(M * 3 * D * 2);
     p->delta = take((int64_t)d.B * d.H * p->TP * 4);
     p->dh = take((int64_t)d.B * D * 4);
-    p->dY0 = take((int64_t)d.B * d.np * D * 4);
+    p->dY0_hi = take((int64_t)d.B * d.np * D * 2); p->dY0_lo = take((int64_t)d.B * d.np * D * 2);
     p->total = o;
     return 0;
 }
 
 static int check_cfg(const qatvit_cfg& c) {
-    if (c.batch < 1 || c.depth < 1 || c.embed_dim % 64 != 0 || c.mlp_hidden % 64 != 0 || c.embed_dim % c.num_heads != 0 ||
-        c.img_size % c.patch_size != 0 || (c.in_chans * c.patch_size * c.patch_size) % 64 != 0 || c.embed_dim > 768) {
+    if (c.batch < 1 || c.depth < 1 || c.embed_dim % 128 != 0 || c.mlp_hidden % 128 != 0 || c.embed_dim % c.num_heads != 0 ||
+        c.img_size % c.patch_size != 0 || (c.in_chans * c.patch_size * c.patch_size) % 128 != 0 || c.embed_dim > 768) {
         set_error("engine: unsupported config (batch %d depth %d dim %d hidden %d heads %d img %d patch %d)", c.batch, c.depth, c.embed_dim,
                   c.mlp_hidden, c.num_heads, c.img_size, c.patch_size);
         return 1;
@@ -168,25 +169,29 @@ struct Ctx {
                        c.act_qmin, c.act_qmax, 1, 0, act_qp(ai), 1, kStatSlots, st);
     }
     // forward GEMM against fake-quantized weight wi: C = (A . wq^T) * s_act * s_w + bias, stats -> act FQ `ai_out`
-    int linear_fwd(int a_is_f32, const void* A, int M, int wi, const float* s_act, const float* bias, float* C, int ai_out) const {
+    // (A_lo == nullptr: A holds grid integers; else A = A_hi + A_lo is a float operand)
+    int linear_fwd(const void* A_hi, const void* A_lo, int M, int wi, const float* s_act, const float* bias, float* C, int ai_out) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        return launch_gemm_nt(a_is_f32, A, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
-                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, nullptr, st);
+        return launch_gemm_nt(A_hi, A_lo, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
+                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st);
     }
-    // dgrad: dX[M,K] = dY[M,N] . W_fq[N,K]
-    int linear_dgrad(const float* dY, int M, int wi, float* dX) const {
+    // the per-channel weight scale of layer wi, which its dY producer folds in (nullptr for per-tensor)
+    const float* dy_colscale(int wi) const { return c.w_per_channel ? wfq[wi].scale : nullptr; }
+    // dgrad: dX[M,K] = dY[M,N] . W_fq[N,K]   (per-channel: dY already carries s_w[n])
+    int linear_dgrad(const void* dY_hi, const void* dY_lo, int M, int wi, float* dX) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        return launch_gemm_nt(1, dY, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr, nullptr,
-                              nullptr, 1, c.w_per_channel ? f.scale : nullptr, st);
+        return launch_gemm_nt(dY_hi, dY_lo, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr,
+                              nullptr, nullptr, 1, st);
     }
     // wgrad: dW[N,K] += sum_m dY[m,N] X[m,K] * s_x, masked by the weight FQ; db[N] += sum_m dY
-    int linear_wgrad(const float* dY, int M, int wi, int x_is_f32, const void* X, const float* s_x, float* dW, float* db) const {
+    int linear_wgrad(const void* dY_hi, const void* dY_lo, int M, int wi, const void* X_hi, const void* X_lo, const float* s_x, float* dW, float* db,
+                     bool dy_scaled = true) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        return launch_gemm_tn(x_is_f32, dY, X, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel, c.w_qmin,
-                              c.w_qmax, db, st);
+        return launch_gemm_tn(dY_hi, dY_lo, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
+                              c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st);
     }
 };
 
@@ -211,7 +216,7 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
     launch_minmax(images, 1, (int64_t)d.B * d.chans * d.img * d.img, 0, x.act_stats(A_IN), kStatSlots, st);
     x.qparams_act(A_IN);
     if (launch_img_patches(images, x.at<void>(p.imgq), x.act_qp(A_IN), qa, qb, d.B, d.chans, d.img, d.img, d.patch, st)) return 1;
-    if (x.linear_fwd(0, x.at<void>(p.imgq), d.B * d.np, 0, x.act_qp(A_IN), x.prm(P_PE_B), x.at<float>(p.Y0), A_PE)) return 1;
+    if (x.linear_fwd(x.at<void>(p.imgq), nullptr, d.B * d.np, 0, x.act_qp(A_IN), x.prm(P_PE_B), x.at<float>(p.Y0), A_PE)) return 1;
     x.qparams_act(A_PE);
     if (launch_resid_fq_lnstats(0, nullptr, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, x.prm(P_CLS), x.prm(P_POS), x.blk<float>(p.x_in, 0),
                                 x.blk<float>(p.mean1, 0), x.blk<float>(p.rstd1, 0), x.bprm(0, B_N1W), x.bprm(0, B_N1B), c.ln_eps,
@@ -225,14 +230,15 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         x.qparams_act(x.aidx(i, AB_N1));
         launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
                               qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st);
-        if (x.linear_fwd(0, x.blk<void>(p.h1q, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), x.blk<float>(p.qkv, i),
+        if (x.linear_fwd(x.blk<void>(p.h1q, i), nullptr, M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), x.blk<float>(p.qkv, i),
                          x.aidx(i, AB_QKV)))
             return 1;
         x.qparams_act(x.aidx(i, AB_QKV));
-        if (launch_attn_fwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<float>(p.O, i),
-                            x.blk<float>(p.lse, i), st))
+        if (launch_attn_fwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
+                            x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), st))
             return 1;
-        if (x.linear_fwd(1, x.blk<void>(p.O, i), M, x.widx(i, WB_PROJ), nullptr, x.bprm(i, B_PROJB), x.blk<float>(p.Yproj, i), x.aidx(i, AB_PROJ)))
+        if (x.linear_fwd(x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), M, x.widx(i, WB_PROJ), nullptr, x.bprm(i, B_PROJB),
+                         x.blk<float>(p.Yproj, i), x.aidx(i, AB_PROJ)))
             return 1;
         x.qparams_act(x.aidx(i, AB_PROJ));
         launch_resid_fq_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, nullptr, nullptr, xmid,
@@ -242,12 +248,13 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         x.qparams_act(x.aidx(i, AB_N2));
         launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
                               x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st);
-        if (x.linear_fwd(0, x.blk<void>(p.h2q, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), x.blk<float>(p.Y1, i),
+        if (x.linear_fwd(x.blk<void>(p.h2q, i), nullptr, M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), x.blk<float>(p.Y1, i),
                          x.aidx(i, AB_FC1)))
             return 1;
         x.qparams_act(x.aidx(i, AB_FC1));
-        launch_fq_gelu(x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.blk<float>(p.G, i), d.M * d.Hd, st);
-        if (x.linear_fwd(1, x.blk<void>(p.G, i), M, x.widx(i, WB_FC2), nullptr, x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i), x.aidx(i, AB_FC2)))
+        launch_fq_gelu(x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), d.M * d.Hd, st);
+        if (x.linear_fwd(x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), M, x.widx(i, WB_FC2), nullptr, x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i),
+                         x.aidx(i, AB_FC2)))
             return 1;
         x.qparams_act(x.aidx(i, AB_FC2));
         // residual + statistics of the NEXT LayerNorm (block i+1's norm1, or the final norm)
@@ -297,38 +304,46 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 return 1;
         } else if (s <= d.depth) {
             const int i = d.depth - s;
-            float* dYs = x.at<float>(p.dYs);
+            void* dYh = x.at<void>(p.dYs_hi);
+            void* dYl = x.at<void>(p.dYs_lo);
+            const int w_fc2 = x.widx(i, WB_FC2), w_fc1 = x.widx(i, WB_FC1), w_proj = x.widx(i, WB_PROJ), w_qkv = x.widx(i, WB_QKV);
             // ---- MLP branch
-            launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, dYs, d.M * d.D, st);
-            if (x.linear_wgrad(dYs, M, x.widx(i, WB_FC2), 1, x.blk<void>(p.G, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
-            if (x.linear_dgrad(dYs, M, x.widx(i, WB_FC2), x.at<float>(p.dG))) return 1;
-            launch_mask_bwd(1, x.at<float>(p.dG), x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.at<float>(p.dY1), d.M * d.Hd, st);
-            if (x.linear_wgrad(x.at<float>(p.dY1), M, x.widx(i, WB_FC1), 0, x.blk<void>(p.h2q, i), x.act_qp(x.aidx(i, AB_N2)), BG(i, B_FC1W),
-                               BG(i, B_FC1B)))
+            launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
+            if (x.linear_wgrad(dYh, dYl, M, w_fc2, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
+            if (x.linear_dgrad(dYh, dYl, M, w_fc2, x.at<float>(p.dG))) return 1;
+            launch_mask_bwd(1, x.at<float>(p.dG), x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), d.Hd,
+                            x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), d.M * d.Hd, st);
+            if (x.linear_wgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.blk<void>(p.h2q, i), nullptr, x.act_qp(x.aidx(i, AB_N2)),
+                               BG(i, B_FC1W), BG(i, B_FC1B)))
                 return 1;
-            if (x.linear_dgrad(x.at<float>(p.dY1), M, x.widx(i, WB_FC1), x.at<float>(p.dH))) return 1;
+            if (x.linear_dgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.at<float>(p.dH))) return 1;
             if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_mid, i), x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i),
                                  x.bprm(i, B_N2W), x.bprm(i, B_N2B), x.act_qp(x.aidx(i, AB_N2)), qa, qb, dxA, dxB, BG(i, B_N2W), BG(i, B_N2B), d.M,
                                  d.D, d.T, 0, st))
                 return 1;
             // ---- attention branch (dxB = gradient w.r.t. x_mid)
-            launch_mask_bwd(0, dxB, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, dYs, d.M * d.D, st);
-            if (x.linear_wgrad(dYs, M, x.widx(i, WB_PROJ), 1, x.blk<void>(p.O, i), nullptr, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
-            if (x.linear_dgrad(dYs, M, x.widx(i, WB_PROJ), x.at<float>(p.dO))) return 1;
-            if (launch_attn_bwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<float>(p.O, i),
-                                x.blk<float>(p.lse, i), x.at<float>(p.delta), x.at<float>(p.dO), x.at<float>(p.dqkv), st))
+            launch_mask_bwd(0, dxB, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, x.dy_colscale(w_proj), d.D, dYh, dYl, d.M * d.D, st);
+            if (x.linear_wgrad(dYh, dYl, M, w_proj, x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), nullptr, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
+            if (x.linear_dgrad(dYh, dYl, M, w_proj, x.at<float>(p.dO))) return 1;
+            if (launch_attn_bwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
+                                x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), x.at<float>(p.delta), x.at<float>(p.dO), x.at<void>(p.dqkv_hi),
+                                x.at<void>(p.dqkv_lo), x.dy_colscale(w_qkv), st))
                 return 1;
-            if (x.linear_wgrad(x.at<float>(p.dqkv), M, x.widx(i, WB_QKV), 0, x.blk<void>(p.h1q, i), x.act_qp(x.aidx(i, AB_N1)), BG(i, B_QKVW),
-                               BG(i, B_QKVB)))
+            if (x.linear_wgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.blk<void>(p.h1q, i), nullptr, x.act_qp(x.aidx(i, AB_N1)),
+                               BG(i, B_QKVW), BG(i, B_QKVB)))
                 return 1;
-            if (x.linear_dgrad(x.at<float>(p.dqkv), M, x.widx(i, WB_QKV), x.at<float>(p.dH))) return 1;
+            if (x.linear_dgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.at<float>(p.dH))) return 1;
             if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_in, i), x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i),
                                  x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)), qa, qb, dxB, dxA, BG(i, B_N1W), BG(i, B_N1B), d.M,
                                  d.D, d.T, 0, st))
                 return 1;
         } else {
-            launch_embed_bwd(dxA, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, G(P_POS), G(P_CLS), x.at<float>(p.dY0), d.B, d.T, d.D, st);
-            if (x.linear_wgrad(x.at<float>(p.dY0), d.B * d.np, 0, 0, x.at<void>(p.imgq), x.act_qp(A_IN), G(P_PE_W), G(P_PE_B))) return 1;
+            launch_embed_bwd(dxA, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, G(P_POS), G(P_CLS), x.at<void>(p.dY0_hi), x.at<void>(p.dY0_lo), d.B,
+                             d.T, d.D, st);
+            // (no dgrad into the image, so dY0 is not pre-scaled by the per-channel weight scale)
+            if (x.linear_wgrad(x.at<void>(p.dY0_hi), x.at<void>(p.dY0_lo), d.B * d.np, 0, x.at<void>(p.imgq), nullptr, x.act_qp(A_IN), G(P_PE_W),
+                               G(P_PE_B), false))
+                return 1;
         }
     }
     return 0;
@@ -392,8 +407,9 @@ int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, in
     if (make_plan(*cfg, &p)) return -1;
     struct { const char* n; int64_t off; bool per_block; } tab[] = {
         {"Y0", p.Y0, false}, {"imgq", p.imgq, false}, {"hq", p.hq, false}, {"logits_pre", p.logits_pre, false}, {"x_in", p.x_in, true},
-        {"x_mid", p.x_mid, true}, {"h1q", p.h1q, true}, {"qkv", p.qkv, true}, {"O", p.O, true}, {"Yproj", p.Yproj, true}, {"h2q", p.h2q, true},
-        {"Y1", p.Y1, true}, {"G", p.G, true}, {"Y2", p.Y2, true}, {"dxA", p.dxA, false}, {"dqkv", p.dqkv, false}, {"dO", p.dO, false},
+        {"x_mid", p.x_mid, true}, {"h1q", p.h1q, true}, {"qkv", p.qkv, true}, {"O_hi", p.O_hi, true}, {"O_lo", p.O_lo, true}, {"Yproj", p.Yproj, true}, {"h2q", p.h2q, true},
+        {"Y1", p.Y1, true}, {"G_hi", p.G_hi, true}, {"G_lo", p.G_lo, true}, {"Y2", p.Y2, true}, {"dxA", p.dxA, false}, {"dqkv_hi", p.dqkv_hi, false},
+        {"dqkv_lo", p.dqkv_lo, false}, {"dO", p.dO, false},
         {"dH", p.dH, false}, {"lse", p.lse, true},
     };
     for (auto& t : tab)

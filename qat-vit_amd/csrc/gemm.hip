@@ -5,30 +5,27 @@
 // gfx950 has no xf32 MFMA and fp32 MFMA runs at 1/16 of the bf16 rate, so the operands are mapped
 // onto bf16 MFMA *without losing the reference's precision*:
 //   * an operand that sits on a fake-quant grid (integer q - zp, |.| <= 255) is EXACT in bf16;
-//   * a float operand is split in the loader into hi = bf16(x), lo = bf16(x - hi) (16 significant
-//     bits, 2^-17 relative) and costs one extra MFMA pass per split operand;
+//   * a float operand arrives pre-split by its producer kernel as two bf16 matrices hi = bf16(x),
+//     lo = bf16(x - hi) (16 significant bits, 2^-17 relative) and costs one extra MFMA pass;
 //   * accumulation is fp32 in the MFMA accumulators; scales / bias are applied in the epilogue.
 // Two layouts:
 //   NT  C[M,N]  = sum_k  A[M,K] * B[N,K]      (forward, and dgrad with B = Wq^T)   row reads
 //   TN  C[N,Kw] += sum_m P[m,N] * Q[m,Kw]     (wgrad; reduction over tokens)       ds_read_b64_tr_b16
-// Tiles: 128 x {128,64} outputs per 256-thread workgroup, BK = 64, register-staged global->LDS
-// with the next tile's loads in flight during the MFMAs; LDS images XOR-swizzled so that the
-// fragment reads (ds_read_b128 / ds_read_b64_tr_b16) are bank-conflict free.
+// Both: 128x128 output tile per 256-thread workgroup, BK = 64, operands streamed HBM/L2 -> LDS by
+// LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, out-of-range rows read as zero) through a
+// 2- or 3-stage ring with counted s_waitcnt vmcnt and ONE raw s_barrier per k-step; the LDS images are
+// XOR-swizzled on the DMA *source* address (the DMA destination is lane-linear) and on the fragment
+// read, so ds_read_b128 / ds_read_b64_tr_b16 are bank-conflict free.
 #include "qv_common.h"
 #include "qv_kernels.h"
 
 namespace qv {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ inline void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
-    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
-}
+typedef __attribute__((address_space(3))) void lds_void;
 
 // XCD-aware, bijective block-id remap: blocks b and b+8 share an XCD (and its L2), so give each
 // XCD a contiguous run of tiles (neighbouring tiles share an A row panel).
@@ -37,17 +34,28 @@ __device__ inline int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-// Timing-only ablation switches (tools/bench_gemm.py); 0 in every product build path.
-__device__ int g_dbg = 0;
-int set_gemm_debug(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int)); }
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t bytes) {
+    // wave-uniform descriptor: raw buffer, out-of-range (>= bytes) lanes load 0
+    const uint32_t n = bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+
+template <int N> __device__ inline void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "add the immediate");
+}
 
 // ============================================================================ NT
-// LDS image of a [rows][64 bf16] tile: 128-B rows, 16-B chunk index XOR (row & 7).
+// LDS image of a [128 rows][64 bf16] tile: 128-B rows, 16-B chunk index XOR (row & 7).
 __device__ inline int nt_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 struct NTArgs {
-    const void* A;        // TA==1: bf16 [M,lda]; TA==2: fp32 [M,lda] (split in the loader)
-    const __bf16* B;      // bf16 [N,ldb]
+    const __bf16* A0;     // [M,lda] hi part (or the only part)
+    const __bf16* A1;     // [M,lda] lo part (TA == 2)
+    const __bf16* B;      // [N,ldb]
     float* C;             // fp32 [M,ldc]
     int M, N, K, lda, ldb, ldc;
     const float* s1;      // optional device scalars, alpha = (*s1) * (*s2)
@@ -56,155 +64,108 @@ struct NTArgs {
     const float* bias;       // optional [N]
     uint32_t* stats;         // optional {ordered-min, ordered-max} accumulator of the stored values
     int stat_slots;          // number of 128-B-spaced accumulator pairs (power of two; 1 = a single pair)
-    const float* a_colscale; // optional [K]: fp32 A is multiplied by this per column before the split (per-channel dgrad)
 };
 
-template <int TA, int BN, int WM, int WN>
+template <int TA, int NSTAGE>
 __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
-    constexpr int BM = 128, BK = 64;
-    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;  // 16x16 tiles per wave
+    constexpr int BM = 128, BN = 128, BK = 64;
+    constexpr int IMG = 128 * 128;                  // bytes of one [128][64] bf16 image
+    constexpr int STAGE = (TA + 1) * IMG;
+    constexpr int NDMA = (TA + 1) * 4;              // LDS-DMA instructions per wave per k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                        // TA images of BM x 128 B
-    char* sB = smem + TA * BM * 128;        // BN x 128 B
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave >> 1, wn = wave & 1;
     const int tilesN = p.N / BN;
-    const int nwg = gridDim.x;
-    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
 
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(p.A0, (int64_t)p.M * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(TA == 2 ? p.A1 : p.A0, (int64_t)p.M * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, (int64_t)p.N * p.ldb * 2);
+    // this lane's place inside a 1-KiB DMA piece (8 rows x 128 B): row lr, swizzled source chunk
+    const int lr = lane >> 3;
+    const int src_chunk = (lane & 7) ^ lr;
 
-    // staging registers
-    float4 ra_f[TA == 2 ? 8 : 1];
-    uint4 ra_h[TA == 1 ? 4 : 1];
-    uint4 rb[BN / 32];
-
-    auto gload = [&](int k0) {
-        if constexpr (TA == 2) {
-            const float* A = reinterpret_cast<const float*>(p.A);
-            const int c4 = tid & 15, r0 = tid >> 4;
+    auto issue = [&](int kt) {
+        char* st = smem + (kt % NSTAGE) * STAGE;
+        const int k0 = kt * BK;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = min(m0 + r0 + 16 * i, p.M - 1);
-                ra_f[i] = *reinterpret_cast<const float4*>(A + (int64_t)row * p.lda + k0 + c4 * 4);
-            }
-            if (p.a_colscale) {
-                const float4 cs = *reinterpret_cast<const float4*>(p.a_colscale + k0 + c4 * 4);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { ra_f[i].x *= cs.x; ra_f[i].y *= cs.y; ra_f[i].z *= cs.z; ra_f[i].w *= cs.w; }
-            }
-        } else {
-            const __bf16* A = reinterpret_cast<const __bf16*>(p.A);
-            const int ch = tid & 7, r0 = tid >> 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = min(m0 + r0 + 32 * i, p.M - 1);
-                ra_h[i] = *reinterpret_cast<const uint4*>(A + (int64_t)row * p.lda + k0 + ch * 8);
-            }
-        }
-        const int ch = tid & 7, r0 = tid >> 3;
-#pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-            const int row = n0 + r0 + 32 * i;
-            rb[i] = *reinterpret_cast<const uint4*>(p.B + (int64_t)row * p.ldb + k0 + ch * 8);
+        for (int c = 0; c < 4; ++c) {
+            const int piece = wave * 4 + c;              // 16 pieces per image
+            const int row = piece * 8 + lr;
+            const uint32_t offA = (uint32_t)(((int64_t)(m0 + row) * p.lda + k0 + src_chunk * 8) * 2);
+            const uint32_t offB = (uint32_t)(((int64_t)(n0 + row) * p.ldb + k0 + src_chunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lds_void*)(st + piece * 1024), 16, offA, 0, 0, 0);
+            if constexpr (TA == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (lds_void*)(st + IMG + piece * 1024), 16, offA, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(st + TA * IMG + piece * 1024), 16, offB, 0, 0, 0);
         }
     };
-    auto lstore = [&]() {
-        if constexpr (TA == 2) {
-            const int c4 = tid & 15, r0 = tid >> 4;
+
+    f32x4 acc[4][4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = r0 + 16 * i;
-                bf16x4 hi, lo;
-                split4(ra_f[i], hi, lo);
-                const int off = nt_off(row, c4 >> 1) + (c4 & 1) * 8;
-                *reinterpret_cast<bf16x4*>(sA + off) = hi;
-                *reinterpret_cast<bf16x4*>(sA + BM * 128 + off) = lo;
-            }
-        } else {
-            const int ch = tid & 7, r0 = tid >> 3;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sA + nt_off(r0 + 32 * i, ch)) = ra_h[i];
-        }
-        const int ch = tid & 7, r0 = tid >> 3;
-#pragma unroll
-        for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<uint4*>(sB + nt_off(r0 + 32 * i, ch)) = rb[i];
-    };
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    const int dbg = g_dbg;
-    gload(0);
-    lstore();
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) issue(s);
+
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk && !(dbg & 4)) gload((kt + 1) * BK);
+        // tile kt has landed once at most the (NSTAGE-2) younger tiles' DMAs are still outstanding
+        if (NSTAGE == 3 && kt + 1 < nk) wait_vmcnt<NDMA>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone left buffer (kt-1)%NSTAGE
+        asm volatile("" ::: "memory");
+        if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
+        const char* st = smem + (kt % NSTAGE) * STAGE;
+        const char* sB = st + TA * IMG;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 bfrag[TN];
+            bf16x8 bfrag[4], afrag[TA][4];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn * (BN / WN) + 16 * j + r;
-                bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off(row, 4 * kk + g));
-            }
+            for (int j = 0; j < 4; ++j) bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off(wn * 64 + 16 * j + r, 4 * kk + g));
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * (BM / WM) + 16 * i + r;
+            for (int t = 0; t < TA; ++t)
 #pragma unroll
-                for (int t = 0; t < TA; ++t) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(sA + t * BM * 128 + nt_off(row, 4 * kk + g));
-                    if (!(dbg & 2))
+                for (int i = 0; i < 4; ++i) afrag[t][i] = *reinterpret_cast<const bf16x8*>(st + t * IMG + nt_off(wm * 64 + 16 * i + r, 4 * kk + g));
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[j], acc[i][j], 0, 0, 0);
-                    else asm volatile("" ::"v"(af));
-                }
-            }
-        }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            lstore();
-            __syncthreads();
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t][i], bfrag[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (dbg & 1) {  // timing only: keep the accumulators alive, store nothing
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
+    __syncthreads();  // all fragment reads done: the ring is free for the epilogue
 
     // ---- epilogue: C = acc * alpha[col] + bias[col]; min/max of what is stored.
     // The accumulator layout (16 consecutive columns per 16 lanes, rows on registers) would give 64-B store
     // segments; stage 64-row halves of the tile through LDS instead and store whole 16-B-per-lane row runs
-    // (BN*4 contiguous bytes per row).  The k-loop's last barrier has passed: the tile buffers are dead.
+    // (512 contiguous bytes per row).
     float alpha = 1.f;
     if (p.s1) alpha *= *p.s1;
     if (p.s2) alpha *= *p.s2;
     float mn = INFINITY, mx = -INFINITY;
     constexpr int LDC = BN + 4;                 // fp32 words per staged row (pad: conflict-free b32 writes)
     float* sC = reinterpret_cast<float*>(smem); // [64][LDC]
-    constexpr int ROWS_PER_WAVE = BM / WM;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h) __syncthreads();
-        if ((wm * ROWS_PER_WAVE) / 64 == h) {
-            const int rbase = wm * ROWS_PER_WAVE - 64 * h;
+        if (wm == h) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int cl = wn * (BN / WN) + 16 * j + r;
+            for (int j = 0; j < 4; ++j) {
+                const int cl = wn * 64 + 16 * j + r;
                 const float a = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
                 const float b = p.bias ? p.bias[n0 + cl] : 0.f;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int rl = rbase + 16 * i + 4 * g + e;
+                        const int rl = 16 * i + 4 * g + e;
                         const float v = acc[i][j][e] * a + b;
                         sC[rl * LDC + cl] = v;
                         if (m0 + 64 * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
@@ -212,12 +173,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
             }
         }
         __syncthreads();
-        constexpr int C4 = BN / 4;              // float4 per row
-        constexpr int RPP = 256 / C4;           // rows per pass
-        const int c4 = tid % C4, r0 = tid / C4;
+        const int c4 = tid & 31, r0 = tid >> 5;
 #pragma unroll
-        for (int it = 0; it < 64 / RPP; ++it) {
-            const int rl = r0 + RPP * it;
+        for (int it = 0; it < 8; ++it) {
+            const int rl = r0 + 8 * it;
             const int row = m0 + 64 * h + rl;
             if (row < p.M)
                 *reinterpret_cast<float4*>(p.C + (int64_t)row * p.ldc + n0 + 4 * c4) = *reinterpret_cast<const float4*>(sC + rl * LDC + 4 * c4);
@@ -244,30 +203,28 @@ static void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int TA>
-static int launch_nt_t(const NTArgs& a, hipStream_t st) {
-    if (a.N % 128 == 0) {
-        const int nwg = cdiv(a.M, 128) * (a.N / 128);
-        size_t lds = (size_t)(TA * 128 + 128) * 128;
-        if (lds < 64 * (128 + 4) * 4) lds = 64 * (128 + 4) * 4;
-        k_gemm_nt<TA, 128, 2, 2><<<nwg, 256, lds, st>>>(a);
-    } else {
-        const int nwg = cdiv(a.M, 128) * (a.N / 64);
-        size_t lds = (size_t)(TA * 128 + 64) * 128;
-        if (lds < 64 * (64 + 4) * 4) lds = 64 * (64 + 4) * 4;
-        k_gemm_nt<TA, 64, 4, 1><<<nwg, 256, lds, st>>>(a);
-    }
-    return 0;
-}
-
-int launch_gemm_nt(int a_is_f32, const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, const float* a_colscale, hipStream_t st) {
-    if (M < 1 || N % 64 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) {
-        set_error("gemm_nt: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d (need N%%64==0, K%%64==0, ld%%8==0)", M, N, K, lda, ldb);
+int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
+                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st) {
+    if (M < 1 || N % 128 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) {
+        set_error("gemm_nt: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d ldc=%d (need N%%128==0, K%%64==0, lda/ldb%%8==0, ldc%%4==0)", M, N, K,
+                  lda, ldb, ldc);
         return 1;
     }
-    NTArgs a{A, reinterpret_cast<const __bf16*>(B), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, a_is_f32 ? a_colscale : nullptr};
-    return a_is_f32 ? launch_nt_t<2>(a, st) : launch_nt_t<1>(a, st);
+    NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B), C, M, N, K, lda, ldb,
+             ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots};
+    const int nwg = cdiv(M, 128) * (N / 128);
+    if (A_lo) {
+        constexpr size_t lds = 3 * 3 * 16384;  // 3 stages x (A_hi, A_lo, B)
+        static bool once = (allow_lds(k_gemm_nt<2, 3>, lds), true);
+        (void)once;
+        k_gemm_nt<2, 3><<<nwg, 256, lds, st>>>(a);
+    } else {
+        constexpr size_t lds = 2 * 2 * 16384;  // 2 stages x (A, B) = 64 KiB (the 64 x 132 fp32 epilogue tile fits): two workgroups per CU
+        static bool once = (allow_lds(k_gemm_nt<1, 2>, lds), true);
+        (void)once;
+        k_gemm_nt<1, 2><<<nwg, 256, lds, st>>>(a);
+    }
+    return 0;
 }
 
 // ============================================================================ TN (wgrad)
@@ -276,11 +233,13 @@ __device__ inline int tn_sw(int row) { return ((row & 3) << 1) | (((row >> 3) & 
 __device__ inline int tn_off(int row, int chunk) { return row * 256 + ((chunk ^ tn_sw(row)) << 4); }
 
 struct TNArgs {
-    const float* P;   // fp32 [M, ldp]  (dY), split in the loader
-    const void* Q;    // TQ==1: bf16 [M, ldq] (grid integers); TQ==2: fp32 [M, ldq] (split)
-    float* C;         // fp32 [N, ldc], accumulated with atomics (caller zeroes)
+    const __bf16* P0;   // [M, ldp] hi part of dY
+    const __bf16* P1;   // [M, ldp] lo part of dY
+    const __bf16* Q0;   // [M, ldq] grid integers, or hi part of a float operand
+    const __bf16* Q1;   // [M, ldq] lo part (TQ == 2)
+    float* C;           // fp32 [N, ldc], accumulated with atomics (caller zeroes)
     int M, N, Kw, ldp, ldq, ldc;
-    int steps_per_split;  // 64-row steps each z-slice reduces
+    int steps_per_split;  // 64-row steps each blockIdx.y slice reduces
     const float* s1;      // optional device scalar (activation scale)
     // weight fake-quant STE mask, recomputed from the fp32 weight and its qparams:
     const float* W;       // optional fp32 [N, ldc]
@@ -288,6 +247,7 @@ struct TNArgs {
     const int32_t* w_zp;  // [1] or [N]
     int w_per_channel, w_qmin, w_qmax;
     float* dbias;         // optional [N]: += sum_m P[m, n]  (bias gradient, ones-fragment MFMA)
+    const float* row_div; // optional [N]: results (and dbias) are divided by row_div[n] (P was pre-multiplied by the per-channel weight scale)
 };
 
 __device__ inline bf16x8 tr_frag(const char* img, int row0, int col0, int lane) {
@@ -300,148 +260,96 @@ __device__ inline bf16x8 tr_frag(const char* img, int row0, int col0, int lane) 
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tn_off(row, chunk) + (pp & 1) * 8));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tn_off(row + 4, chunk) + (pp & 1) * 8));
     // whole-vector bit cast: per-element short->__bf16 inserts are miscompiled by hipcc 7.2 (every element becomes lo[0])
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TQ, int BKW, int WM, int WN>  // output tile 128 (N) x BKW (Kw)
+template <int TQ, int NSTAGE>
 __global__ __launch_bounds__(256) void k_gemm_tn(const TNArgs p) {
-    constexpr int BN = 128, BK = 64;
-    constexpr int TM = BN / WM / 16, TNn = BKW / WN / 16;
-    constexpr int QROWB = BKW * 2;  // bytes per LDS row of a Q image (always stored in 256-B rows)
+    constexpr int BN = 128, BKW = 128, BK = 64;
+    constexpr int IMG = BK * 256;                   // bytes of one [64][128] bf16 image
+    constexpr int STAGE = (2 + TQ) * IMG;
+    constexpr int NDMA = (2 + TQ) * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sP = smem;                 // 2 images (hi, lo) of 64 x 256 B
-    char* sQ = smem + 2 * BK * 256;  // TQ images of 64 x 256 B
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     const int tilesK = p.Kw / BKW;
     const int n0 = (blockIdx.x / tilesK) * BN, k0 = (blockIdx.x % tilesK) * BKW;
     const int total_steps = (p.M + BK - 1) / BK;
     const int s_begin = blockIdx.y * p.steps_per_split;
     const int s_end = min(total_steps, s_begin + p.steps_per_split);
-    (void)QROWB;
+    const int nsteps = s_end - s_begin;
 
-    f32x4 acc[TM][TNn];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TNn; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rP0 = make_rsrc(p.P0, (int64_t)p.M * p.ldp * 2);
+    const __amdgpu_buffer_rsrc_t rP1 = make_rsrc(p.P1, (int64_t)p.M * p.ldp * 2);
+    const __amdgpu_buffer_rsrc_t rQ0 = make_rsrc(p.Q0, (int64_t)p.M * p.ldq * 2);
+    const __amdgpu_buffer_rsrc_t rQ1 = make_rsrc(TQ == 2 ? p.Q1 : p.Q0, (int64_t)p.M * p.ldq * 2);
+    // this lane's place inside a 1-KiB DMA piece (4 rows x 256 B)
+    const int lr = lane >> 4;
 
+    auto issue = [&](int s) {
+        char* st = smem + (s % NSTAGE) * STAGE;
+        const int mrow0 = (s_begin + s) * BK;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int piece = wave * 4 + c;                    // 16 pieces per image
+            const int row = piece * 4 + lr;                    // 0..63
+            const int src_chunk = (lane & 15) ^ tn_sw(row);
+            const uint32_t offP = (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + src_chunk * 8) * 2);
+            const uint32_t offQ = (uint32_t)(((int64_t)(mrow0 + row) * p.ldq + k0 + src_chunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rP0, (lds_void*)(st + piece * 1024), 16, offP, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rP1, (lds_void*)(st + IMG + piece * 1024), 16, offP, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ0, (lds_void*)(st + 2 * IMG + piece * 1024), 16, offQ, 0, 0, 0);
+            if constexpr (TQ == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ1, (lds_void*)(st + 3 * IMG + piece * 1024), 16, offQ, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.dbias != nullptr && (blockIdx.x % tilesK) == 0 && wn == 0;  // wave-uniform
-    f32x4 accb[TM];
+    f32x4 accb[4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    float4 rp[8];
-    float4 rq_f[TQ == 2 ? BKW / 16 : 1];
-    uint4 rq_h[TQ == 1 ? BKW / 32 : 1];
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nsteps) issue(s);
 
-    auto gload = [&](int step) {
-        const int mrow0 = step * BK;
-        {
-            const int c4 = tid & 31, r0 = tid >> 5;
+    for (int s = 0; s < nsteps; ++s) {
+        if (NSTAGE == 3 && s + 1 < nsteps) wait_vmcnt<NDMA>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NSTAGE - 1 < nsteps) issue(s + NSTAGE - 1);
+        const char* st = smem + (s % NSTAGE) * STAGE;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = mrow0 + r0 + 8 * i;
-                const bool ok = m < p.M && n0 + c4 * 4 < p.N;
-                const float4 v = *reinterpret_cast<const float4*>(p.P + (int64_t)min(m, p.M - 1) * p.ldp + min(n0 + c4 * 4, p.N - 4));
-                rp[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        if constexpr (TQ == 2) {
-            constexpr int C4 = BKW / 4;          // float4 per row
-            constexpr int RPT = 256 / C4;        // rows per pass
-            const float* Q = reinterpret_cast<const float*>(p.Q);
-            const int c4 = tid % C4, r0 = tid / C4;
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 qf[TQ][4];
 #pragma unroll
-            for (int i = 0; i < BK / RPT; ++i) {
-                const int m = mrow0 + r0 + RPT * i;
-                const float4 v = *reinterpret_cast<const float4*>(Q + (int64_t)min(m, p.M - 1) * p.ldq + k0 + c4 * 4);
-                rq_f[i] = m < p.M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        } else {
-            constexpr int CH = BKW / 8;          // 16-B chunks per row
-            constexpr int RPT = 256 / CH;
-            const __bf16* Q = reinterpret_cast<const __bf16*>(p.Q);
-            const int ch = tid % CH, r0 = tid / CH;
+            for (int t = 0; t < TQ; ++t)
 #pragma unroll
-            for (int i = 0; i < BK / RPT; ++i) {
-                const int m = mrow0 + r0 + RPT * i;
-                const uint4 v = *reinterpret_cast<const uint4*>(Q + (int64_t)min(m, p.M - 1) * p.ldq + k0 + ch * 8);
-                rq_h[i] = m < p.M ? v : make_uint4(0, 0, 0, 0);
-            }
-        }
-    };
-    auto lstore = [&]() {
-        {
-            const int c4 = tid & 31, r0 = tid >> 5;
+                for (int j = 0; j < 4; ++j) qf[t][j] = tr_frag(st + (2 + t) * IMG, 32 * kk, wn * 64 + 16 * j, lane);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = r0 + 8 * i;
-                bf16x4 hi, lo;
-                split4(rp[i], hi, lo);
-                const int off = tn_off(row, c4 >> 1) + (c4 & 1) * 8;
-                *reinterpret_cast<bf16x4*>(sP + off) = hi;
-                *reinterpret_cast<bf16x4*>(sP + BK * 256 + off) = lo;
-            }
-        }
-        if constexpr (TQ == 2) {
-            constexpr int C4 = BKW / 4, RPT = 256 / C4;
-            const int c4 = tid % C4, r0 = tid / C4;
-#pragma unroll
-            for (int i = 0; i < BK / RPT; ++i) {
-                const int row = r0 + RPT * i;
-                bf16x4 hi, lo;
-                split4(rq_f[i], hi, lo);
-                const int off = tn_off(row, c4 >> 1) + (c4 & 1) * 8;
-                *reinterpret_cast<bf16x4*>(sQ + off) = hi;
-                *reinterpret_cast<bf16x4*>(sQ + BK * 256 + off) = lo;
-            }
-        } else {
-            constexpr int CH = BKW / 8, RPT = 256 / CH;
-            const int ch = tid % CH, r0 = tid / CH;
-#pragma unroll
-            for (int i = 0; i < BK / RPT; ++i) *reinterpret_cast<uint4*>(sQ + tn_off(r0 + RPT * i, ch)) = rq_h[i];
-        }
-    };
-
-    if (s_begin < s_end) {
-        gload(s_begin);
-        lstore();
-        __syncthreads();
-        for (int s = s_begin; s < s_end; ++s) {
-            if (s + 1 < s_end) gload(s + 1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 qf[TQ][TNn];
-#pragma unroll
-                for (int t = 0; t < TQ; ++t)
-#pragma unroll
-                    for (int j = 0; j < TNn; ++j) qf[t][j] = tr_frag(sQ + t * BK * 256, 32 * kk, wn * (BKW / WN) + 16 * j, lane);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const bf16x8 ph = tr_frag(sP, 32 * kk, wm * (BN / WM) + 16 * i, lane);
-                    const bf16x8 pl = tr_frag(sP + BK * 256, 32 * kk, wm * (BN / WM) + 16 * i, lane);
-                    if (do_bias) {
-                        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ones, accb[i], 0, 0, 0);
-                        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, ones, accb[i], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < TNn; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, qf[0][j], acc[i][j], 0, 0, 0);
-                        if constexpr (TQ == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[1][j], acc[i][j], 0, 0, 0);
-                    }
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 ph = tr_frag(st, 32 * kk, wm * 64 + 16 * i, lane);
+                const bf16x8 pl = tr_frag(st + IMG, 32 * kk, wm * 64 + 16 * i, lane);
+                if (do_bias) {
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ones, accb[i], 0, 0, 0);
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, ones, accb[i], 0, 0, 0);
                 }
-            }
-            __syncthreads();
-            if (s + 1 < s_end) {
-                lstore();
-                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, qf[0][j], acc[i][j], 0, 0, 0);
+                    if constexpr (TQ == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[1][j], acc[i][j], 0, 0, 0);
+                }
             }
         }
     }
@@ -450,12 +358,13 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TNArgs p) {
     const float alpha = p.s1 ? *p.s1 : 1.f;
     const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int n = n0 + wm * (BN / WM) + 16 * i + 4 * g + e;
+            const int n = n0 + wm * 64 + 16 * i + 4 * g + e;
             if (n >= p.N) continue;
-            if (do_bias && r == 0) atomicAdd(&p.dbias[n], accb[i][e]);
+            const float rdiv = p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f;
+            if (do_bias && r == 0) atomicAdd(&p.dbias[n], accb[i][e] * rdiv);
             float inv = 0.f, fzp = 0.f;
             if (p.W) {
                 const int ci = p.w_per_channel ? n : 0;
@@ -463,9 +372,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TNArgs p) {
                 fzp = (float)p.w_zp[ci];
             }
 #pragma unroll
-            for (int j = 0; j < TNn; ++j) {
-                const int kw = k0 + wn * (BKW / WN) + 16 * j + r;
-                float v = acc[i][j][e] * alpha;
+            for (int j = 0; j < 4; ++j) {
+                const int kw = k0 + wn * 64 + 16 * j + r;
+                float v = acc[i][j][e] * (alpha * rdiv);
                 if (p.W) {
                     const float q = rintf(p.W[(int64_t)n * p.ldc + kw] * inv) + fzp;
                     if (!(q >= (float)p.w_qmin && q <= (float)p.w_qmax)) v = 0.f;
@@ -476,36 +385,35 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TNArgs p) {
     }
 }
 
-int launch_gemm_tn(int q_is_f32, const float* P, const void* Q, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s1,
-                   const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
-                   hipStream_t st) {
-    if (M < 1 || N % 64 != 0 || Kw % 64 != 0 || ldp % 4 != 0 || ldq % 8 != 0) {
-        set_error("gemm_tn: unsupported shape M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%64==0, Kw%%64==0)", M, N, Kw, ldp, ldq);
+int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                   const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
+                   float* dbias, const float* row_div, hipStream_t st) {
+    if (M < 1 || N % 128 != 0 || Kw % 128 != 0 || ldp % 8 != 0 || ldq % 8 != 0) {
+        set_error("gemm_tn: unsupported shape M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%128==0, ld%%8==0)", M, N, Kw, ldp, ldq);
         return 1;
     }
-    TNArgs a{P, Q, C, M, N, Kw, ldp, ldq, ldc, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias};
+    TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), reinterpret_cast<const __bf16*>(Q_hi),
+             reinterpret_cast<const __bf16*>(Q_lo), C, M, N, Kw, ldp, ldq, ldc, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div};
     const int steps = (M + 63) / 64;
-    const bool wide = (Kw % 128 == 0);
-    const int tiles = cdiv(N, 128) * (Kw / (wide ? 128 : 64));
-    // split the token reduction so that ~2 workgroups per CU exist; each split >= 4 steps
-    int splits = (512 + tiles - 1) / tiles;
+    const int tiles = (N / 128) * (Kw / 128);
+    // One workgroup per CU is resident (96-144 KiB of LDS): split the token reduction so that the grid is as close
+    // to (but not above) a whole number of 256-CU rounds as possible - 513 workgroups would cost a third round.
+    int splits = 512 / tiles;
     if (splits > steps / 4) splits = steps / 4 > 0 ? steps / 4 : 1;
     if (splits < 1) splits = 1;
     a.steps_per_split = (steps + splits - 1) / splits;
     splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
     dim3 grid(tiles, splits);
-    if (wide) {
-        const size_t lds = (size_t)(2 + (q_is_f32 ? 2 : 1)) * 64 * 256;
-        static bool once = (allow_lds(k_gemm_tn<2, 128, 2, 2>, 65536), allow_lds(k_gemm_tn<1, 128, 2, 2>, 65536), true);
+    if (Q_lo) {
+        constexpr size_t lds = 2 * 4 * 16384;  // 2 stages x (P_hi, P_lo, Q_hi, Q_lo)
+        static bool once = (allow_lds(k_gemm_tn<2, 2>, lds), true);
         (void)once;
-        if (q_is_f32) k_gemm_tn<2, 128, 2, 2><<<grid, 256, lds, st>>>(a);
-        else k_gemm_tn<1, 128, 2, 2><<<grid, 256, lds, st>>>(a);
+        k_gemm_tn<2, 2><<<grid, 256, lds, st>>>(a);
     } else {
-        const size_t lds = (size_t)(2 + (q_is_f32 ? 2 : 1)) * 64 * 256;
-        static bool once2 = (allow_lds(k_gemm_tn<2, 64, 4, 1>, 65536), allow_lds(k_gemm_tn<1, 64, 4, 1>, 65536), true);
-        (void)once2;
-        if (q_is_f32) k_gemm_tn<2, 64, 4, 1><<<grid, 256, lds, st>>>(a);
-        else k_gemm_tn<1, 64, 4, 1><<<grid, 256, lds, st>>>(a);
+        constexpr size_t lds = 3 * 3 * 16384;  // 3 stages x (P_hi, P_lo, Q)
+        static bool once = (allow_lds(k_gemm_tn<1, 3>, lds), true);
+        (void)once;
+        k_gemm_tn<1, 3><<<grid, 256, lds, st>>>(a);
     }
     return 0;
 }

@@ -25,15 +25,12 @@ int launch_qparams(uint32_t* ws, float* running_min, float* running_max, float* 
                    const int64_t* fake_quant_on, float c, int qmin, int qmax, int64_t channels, int symmetric, float* qp_out, int reset_ws,
                    int nslots, hipStream_t st);
 
-// ---- gemm.hip
-int launch_gemm_nt(int a_is_f32, const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, const float* a_colscale, hipStream_t st);
-int launch_gemm_tn(int q_is_f32, const float* P, const void* Q, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s1,
-                   const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
-                   hipStream_t st);
-
-int set_gemm_debug(int v);
-
+// ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)
+int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
+                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st);
+int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                   const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
+                   float* dbias, const float* row_div, hipStream_t st);
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st);
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
@@ -41,8 +38,9 @@ int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const
                             int64_t M, int D, int T, hipStream_t st);
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
                           int qmax, void* out_bf16, int64_t M, int D, hipStream_t st);
-int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, float* G, int64_t n, hipStream_t st);
-int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, float* dst, int64_t n, hipStream_t st);
+int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, void* G_hi, void* G_lo, int64_t n, hipStream_t st);
+int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, const float* col_scale, int ncols,
+                    void* dst_hi, void* dst_lo, int64_t n, hipStream_t st);
 int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                      const float* qp, int qmin, int qmax, const float* dx_in, float* dx_out, float* dgamma, float* dbeta, int64_t M, int D, int T,
                      int cls_only, hipStream_t st);
@@ -53,14 +51,15 @@ int launch_logits_fq(const float* pre, const float* qp, int qmin, int qmax, floa
 int launch_head_bwd(const float* dlogits, const float* logits_pre, const float* qp_logits, int qmin, int qmax, const float* hq, const float* qp_norm,
                     const void* wq, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dW,
                     float* dbias, float* dh, int B, int D, int C, hipStream_t st);
-int launch_embed_bwd(const float* dx0, const float* Y0, const float* qp, int qmin, int qmax, float* dpos, float* dcls, float* dY0, int B, int T, int D,
-                     hipStream_t st);
+int launch_embed_bwd(const float* dx0, const float* Y0, const float* qp, int qmin, int qmax, float* dpos, float* dcls, void* dY0_hi, void* dY0_lo,
+                     int B, int T, int D, hipStream_t st);
 int launch_wquant(const float* W, const float* qp, int per_channel, int qmin, int qmax, void* wq, void* wqT, int N, int K, hipStream_t st);
 
 // ---- attn.hip
 int attn_padded_tokens(int T);
-int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, float* O, float* lse, hipStream_t st);
-int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const float* O, const float* lse,
-                    float* delta, const float* dO, float* dqkv, hipStream_t st);
+int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, void* O_hi, void* O_lo, float* lse,
+                    hipStream_t st);
+int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const void* O_hi, const void* O_lo,
+                    const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st);
 
 }  // namespace qv

@@ -242,8 +242,17 @@ class _StudentStep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
-        grads = ctx.engine.backward(dlogits)
-        return (None, None, *grads)
+        # The native backward writes every parameter gradient into one flat buffer; hand the views to the parameters
+        # directly (what `zero_grad(set_to_none=True)` + autograd would end up with) instead of returning them, so
+        # autograd's AccumulateGrad does not clone 152 tensors per step.
+        eng = ctx.engine
+        grads = eng.backward(dlogits)
+        for p, g in zip(eng.params, grads):
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        return (None, None) + (None,) * len(grads)
 
 
 def student_forward(wrapper, images: torch.Tensor) -> torch.Tensor:

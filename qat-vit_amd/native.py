@@ -27,12 +27,11 @@ SIGNATURES = {
     "qatvit_ln_forward": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_float, c_void_p]),
     "qatvit_ln_backward": (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_void_p]),
     "qatvit_kd_ce_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
-    "qatvit_gemm_nt": (c_int, [c_int32, c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 7),
-    "qatvit_gemm_tn": (c_int, [c_int32, c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p, c_void_p]),
-    "qatvit_debug_gemm_ablate": (c_int, [c_int32]),
+    "qatvit_gemm_nt": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
+    "qatvit_gemm_tn": (c_int, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3),
     "qatvit_attn_padded_tokens": (c_int32, [c_int32]),
-    "qatvit_attn_forward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 3),
-    "qatvit_attn_backward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 6),
+    "qatvit_attn_forward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 4),
+    "qatvit_attn_backward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 9),
     "qatvit_student_num_params": (c_int32, [c_void_p]),
     "qatvit_student_num_act_fq": (c_int32, [c_void_p]),
     "qatvit_student_num_weight_fq": (c_int32, [c_void_p]),

@@ -102,7 +102,7 @@ def run(name, backend, B, img, kw, teacher):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    tiny = dict(embed_dim=64, depth=2, num_heads=2, img_size=32)
+    tiny = dict(embed_dim=128, depth=2, num_heads=2, img_size=32)
     if which in ("all", "tiny"):
         run("tiny", "qnnpack", 4, 32, tiny, True)
         run("tiny", "x86", 4, 32, tiny, True)

@@ -53,11 +53,11 @@ def test_registry_api_and_errors(tmp_path):
 
 
 def test_checkpoint_roundtrip_with_prefixes(tmp_path):
-    s = qat_vit_amd.create_student("vit", qat_wrapper=True, embed_dim=64, depth=1, num_heads=2, img_size=32)
+    s = qat_vit_amd.create_student("vit", qat_wrapper=True, embed_dim=128, depth=1, num_heads=2, img_size=32)
     sd = {"module." + k: v for k, v in s.state_dict().items()}  # DDP-saved wrapper state
     torch.save({"state_dict": sd}, tmp_path / "c.pth")
     s2 = qat_vit_amd.create_model("vit_small_patch16_224_student", pretrained=False, checkpoint_path=tmp_path / "c.pth",
-                                  embed_dim=64, depth=1, num_heads=2, img_size=32)
+                                  embed_dim=128, depth=1, num_heads=2, img_size=32)
     # keys carry a "model." prefix the student loader does not strip (same as the reference, strict=False)
     assert isinstance(s2, torch.nn.Module)
 

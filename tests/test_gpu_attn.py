@@ -1,6 +1,6 @@
 """Fused attention kernels (quantize-on-load from the pre-FQ qkv tensor) against an fp64 torch
 reference that fake-quantizes qkv the same way.  P, dO, dS are split hi/lo bf16 (2^-17), the
-integer Q.K^T is exact -> 3e-5 relative L2 asserted."""
+integer Q.K^T is exact, outputs are written as hi/lo bf16 pairs -> 3e-5 relative L2 asserted."""
 import pytest
 import torch
 
@@ -23,8 +23,9 @@ def _ref(qkv_pre, scale, zp, qmin, qmax, B, T, H, D, dO):
     return o.detach(), fq.grad * mask
 
 
-@pytest.mark.parametrize("B,T,H,D", [(3, 197, 6, 384), (2, 5, 2, 64), (2, 197, 12, 768), (1, 17, 2, 128)])
-def test_attention_fwd_bwd(native_lib, B, T, H, D):
+@pytest.mark.parametrize("B,T,H,D", [(3, 197, 6, 384), (2, 5, 2, 128), (2, 197, 12, 768), (1, 17, 4, 128)])
+@pytest.mark.parametrize("with_colscale", [False, True])
+def test_attention_fwd_bwd(native_lib, B, T, H, D, with_colscale):
     torch.manual_seed(B * T + D)
     dev = "cuda"
     qkv = torch.randn(B * T, 3 * D, device=dev) * 1.5
@@ -33,17 +34,25 @@ def test_attention_fwd_bwd(native_lib, B, T, H, D):
     qp = torch.tensor([scale, 1.0, float(zp), 1.0], device=dev)
     qp[1] = torch.ones(1, device=dev)[0] / qp[0]
     TP = native_lib.qatvit_attn_padded_tokens(T)
-    O = torch.full((B * T, D), float("nan"), device=dev)
+    Oh = torch.zeros(B * T, D, device=dev, dtype=torch.bfloat16)
+    Ol = torch.zeros_like(Oh)
     lse = torch.zeros(B * H, TP, device=dev)
     delta = torch.zeros(B * H, TP, device=dev)
     dO = torch.randn(B * T, D, device=dev)
-    dqkv = torch.full((B * T, 3 * D), float("nan"), device=dev)
+    gh = torch.full((B * T, 3 * D), float("nan"), device=dev, dtype=torch.bfloat16)
+    gl = torch.full_like(gh, float("nan"))
+    cs = (torch.rand(3 * D, device=dev) + 0.5) if with_colscale else None
     st = torch.cuda.current_stream().cuda_stream
-    assert native_lib.qatvit_attn_forward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, O.data_ptr(), lse.data_ptr(), st) == 0, native_lib.qatvit_last_error()
-    assert native_lib.qatvit_attn_backward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, O.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                           dO.data_ptr(), dqkv.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+    assert native_lib.qatvit_attn_forward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+    assert native_lib.qatvit_attn_backward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
+                                           delta.data_ptr(), dO.data_ptr(), gh.data_ptr(), gl.data_ptr(), None if cs is None else cs.data_ptr(),
+                                           st) == 0, native_lib.qatvit_last_error()
     ro, rg = _ref(qkv, qp[0], zp, qmin, qmax, B, T, H, D, dO)
-    assert not torch.isnan(O).any() and not torch.isnan(dqkv).any()
+    if cs is not None:
+        rg = rg * cs.double()[None, :]
+    O = Oh.float() + Ol.float()
+    dqkv = gh.float() + gl.float()
+    assert not torch.isnan(dqkv).any()
     assert rel_l2(O.cpu(), ro.cpu()) < 3e-5
     assert rel_l2(dqkv[:, :D].cpu(), rg[:, :D].cpu()) < 3e-5           # dQ
     assert rel_l2(dqkv[:, D:2 * D].cpu(), rg[:, D:2 * D].cpu()) < 3e-5  # dK
@@ -53,5 +62,5 @@ def test_attention_fwd_bwd(native_lib, B, T, H, D):
 
 def test_attention_rejects_unsupported(native_lib):
     x = torch.zeros(8, device="cuda")
-    assert native_lib.qatvit_attn_forward(x.data_ptr(), x.data_ptr(), 0, 255, 1, 300, 1, 64, x.data_ptr(), x.data_ptr(), None) != 0
+    assert native_lib.qatvit_attn_forward(x.data_ptr(), x.data_ptr(), 0, 255, 1, 300, 1, 64, x.data_ptr(), x.data_ptr(), x.data_ptr(), None) != 0
     assert b"unsupported" in native_lib.qatvit_last_error()

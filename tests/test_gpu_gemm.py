@@ -1,8 +1,8 @@
 """MFMA GEMM kernels through the C ABI against fp64 torch references on the same inputs.
 
-Tolerances: a grid (integer) operand is exact in bf16 and a float operand is split hi+lo
-(2^-17 relative per element), accumulation is fp32 -> 2e-5 relative L2 is asserted (observed ~1e-6);
-integer x integer products must be exact."""
+Operands are bf16: a grid (integer) operand is exact, a float operand is passed as the (hi, lo) pair its
+producer kernel would write (2^-17 relative per element); accumulation is fp32 -> 2e-5 relative L2 is
+asserted (observed ~1e-6); integer x integer products must be exact."""
 import numpy as np
 import pytest
 import torch
@@ -16,42 +16,52 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
-@pytest.mark.parametrize("M,N,K", [(1576, 1152, 384), (300, 384, 1536), (128, 64, 64), (50, 192, 256), (1000, 384, 768)])
+def split(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+@pytest.mark.parametrize("M,N,K", [(1576, 1152, 384), (300, 384, 1536), (128, 128, 64), (50, 256, 256), (1000, 384, 768), (20, 128, 128)])
 @pytest.mark.parametrize("a_f32", [0, 1])
 def test_gemm_nt(native_lib, M, N, K, a_f32):
     torch.manual_seed(M + N + K + a_f32)
     dev = "cuda"
     B = torch.randint(-128, 128, (N, K), device=dev).float()
+    Bh = B.to(torch.bfloat16)
     if a_f32:
         A = torch.randn(M, K, device=dev) * 3
-        Aarg = A
+        Ah, Al = split(A)
     else:
         A = torch.randint(-255, 256, (M, K), device=dev).float()
-        Aarg = A.to(torch.bfloat16)
+        Ah, Al = A.to(torch.bfloat16), None
     s1 = torch.tensor([0.0123], device=dev)
     s2 = torch.tensor([0.0045], device=dev)
     cs = torch.rand(N, device=dev) + 0.5
     bias = torch.randn(N, device=dev)
-    stats = torch.tensor([0xFF800000, 0x007FFFFF], dtype=torch.int64, device=dev).to(torch.int32)  # ord(+inf), ord(-inf) bit patterns
-    stats = torch.tensor([-8388608, 8388607], dtype=torch.int32, device=dev)  # same bit patterns as int32
+    stats = torch.tensor([-8388608, 8388607], dtype=torch.int32, device=dev)  # bit patterns of ord(+inf), ord(-inf)
     C = torch.full((M, N), float("nan"), device=dev)
-    Bh = B.to(torch.bfloat16)  # keep alive: a temporary's memory would be recycled by the caching allocator
-    st = native_lib.qatvit_gemm_nt(a_f32, Aarg.data_ptr(), Bh.data_ptr(), C.data_ptr(), M, N, K, K, K, N, s1.data_ptr(),
-                                   s2.data_ptr(), cs.data_ptr(), bias.data_ptr(), stats.data_ptr(), None, _st())
+    st = native_lib.qatvit_gemm_nt(Ah.data_ptr(), _ptr(Al), Bh.data_ptr(), C.data_ptr(), M, N, K, K, K, N, s1.data_ptr(), s2.data_ptr(),
+                                   cs.data_ptr(), bias.data_ptr(), stats.data_ptr(), _st())
     assert st == 0, native_lib.qatvit_last_error()
     ref = (A.double() @ B.double().t()) * (s1.double() * s2.double()) * cs.double() + bias.double()
     assert not torch.isnan(C).any()
     assert rel_l2(C.cpu(), ref.cpu()) < 2e-5
-    # stats = min/max of what was stored (order-preserving uint32 map)
     u = stats.cpu().numpy().view(np.uint32)
+
     def ord2f(k):
         k = np.uint32(k)
         v = (k & np.uint32(0x7FFFFFFF)) if (k & np.uint32(0x80000000)) else ~k
         return np.array([v], np.uint32).view(np.float32)[0]
+
     assert ord2f(u[0]) == C.min().item() and ord2f(u[1]) == C.max().item()
 
 
-def test_gemm_nt_integer_exact_and_colscale(native_lib):
+def test_gemm_nt_integer_exact(native_lib):
     dev = "cuda"
     torch.manual_seed(0)
     M, N, K = 256, 128, 384
@@ -59,45 +69,41 @@ def test_gemm_nt_integer_exact_and_colscale(native_lib):
     B = torch.randint(-128, 128, (N, K), device=dev).float()
     C = torch.empty(M, N, device=dev)
     Ah, Bh = A.to(torch.bfloat16), B.to(torch.bfloat16)
-    st = native_lib.qatvit_gemm_nt(0, Ah.data_ptr(), Bh.data_ptr(), C.data_ptr(), M, N, K, K, K, N,
-                                   None, None, None, None, None, None, _st())
+    st = native_lib.qatvit_gemm_nt(Ah.data_ptr(), None, Bh.data_ptr(), C.data_ptr(), M, N, K, K, K, N, None, None, None, None, None, _st())
     assert st == 0
     assert torch.equal(C.double(), A.double() @ B.double().t())  # integers < 2^24: exact
-    # per-column pre-scale of a float A (per-channel dgrad form)
-    Af = torch.randn(M, K, device=dev)
-    cs = torch.rand(K, device=dev) + 0.5
-    st = native_lib.qatvit_gemm_nt(1, Af.data_ptr(), Bh.data_ptr(), C.data_ptr(), M, N, K, K, K, N, None, None, None, None,
-                                   None, cs.data_ptr(), _st())
-    assert st == 0
-    assert rel_l2(C.cpu(), ((Af.double() * cs.double()) @ B.double().t()).cpu()) < 2e-5
 
 
-def test_gemm_nt_rejects_bad_shapes(native_lib):
-    x = torch.zeros(64, 64, device="cuda")
-    assert native_lib.qatvit_gemm_nt(1, x.data_ptr(), x.data_ptr(), x.data_ptr(), 64, 60, 64, 64, 64, 60, None, None, None, None, None, None, None) != 0
+def test_gemm_rejects_bad_shapes(native_lib):
+    x = torch.zeros(128, 128, device="cuda")
+    assert native_lib.qatvit_gemm_nt(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), 64, 64, 64, 64, 64, 64, None, None, None, None, None, None) != 0
+    assert b"unsupported shape" in native_lib.qatvit_last_error()
+    assert native_lib.qatvit_gemm_tn(x.data_ptr(), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 128, 64, 128, 128, None, None, None,
+                                     None, 0, -128, 127, None, None, None) != 0
     assert b"unsupported shape" in native_lib.qatvit_last_error()
 
 
-@pytest.mark.parametrize("M,N,Kw", [(1576, 1152, 384), (1576, 384, 1536), (70, 64, 64), (1000, 192, 64), (5000, 384, 768)])
+@pytest.mark.parametrize("M,N,Kw", [(1576, 1152, 384), (1576, 384, 1536), (70, 128, 128), (1000, 256, 128), (5000, 384, 768)])
 @pytest.mark.parametrize("q_f32", [0, 1])
 def test_gemm_tn(native_lib, M, N, Kw, q_f32):
     torch.manual_seed(M + N + Kw + q_f32)
     dev = "cuda"
     P = torch.randn(M, N, device=dev) * 1e-3
+    Ph, Pl = split(P)
     if q_f32:
         Q = torch.randn(M, Kw, device=dev)
-        Qarg = Q
+        Qh, Ql = split(Q)
     else:
         Q = torch.randint(-255, 256, (M, Kw), device=dev).float()
-        Qarg = Q.to(torch.bfloat16)
+        Qh, Ql = Q.to(torch.bfloat16), None
     s1 = torch.tensor([0.031], device=dev)
     W = torch.randn(N, Kw, device=dev)
     w_scale = torch.tensor([2.0 / 127], device=dev)  # clips |W| > 2
     w_zp = torch.zeros(1, dtype=torch.int32, device=dev)
     C = torch.zeros(N, Kw, device=dev)
     db = torch.zeros(N, device=dev)
-    st = native_lib.qatvit_gemm_tn(q_f32, P.data_ptr(), Qarg.data_ptr(), C.data_ptr(), M, N, Kw, N, Kw, Kw, s1.data_ptr(), W.data_ptr(),
-                                   w_scale.data_ptr(), w_zp.data_ptr(), 0, -128, 127, db.data_ptr(), _st())
+    st = native_lib.qatvit_gemm_tn(Ph.data_ptr(), Pl.data_ptr(), Qh.data_ptr(), _ptr(Ql), C.data_ptr(), M, N, Kw, N, Kw, Kw, s1.data_ptr(),
+                                   W.data_ptr(), w_scale.data_ptr(), w_zp.data_ptr(), 0, -128, 127, db.data_ptr(), None, _st())
     assert st == 0, native_lib.qatvit_last_error()
     inv = (torch.ones(1, device=dev) / w_scale)
     qv = torch.round(W * inv)
@@ -108,7 +114,7 @@ def test_gemm_tn(native_lib, M, N, Kw, q_f32):
     assert rel_l2(db.cpu(), P.double().sum(0).cpu()) < 2e-5
 
 
-def test_gemm_tn_per_channel_mask_no_bias(native_lib):
+def test_gemm_tn_per_channel_mask_and_row_div(native_lib):
     dev = "cuda"
     torch.manual_seed(5)
     M, N, Kw = 900, 128, 128
@@ -118,10 +124,13 @@ def test_gemm_tn_per_channel_mask_no_bias(native_lib):
     w_scale = (torch.rand(N, device=dev) + 0.5) * 2.0 / 127
     w_zp = torch.zeros(N, dtype=torch.int32, device=dev)
     C = torch.zeros(N, Kw, device=dev)
+    db = torch.zeros(N, device=dev)
+    Ph, Pl = split(P * w_scale[None, :])  # the producer folds the per-channel scale in ...
     Qh = Q.to(torch.bfloat16)
-    st = native_lib.qatvit_gemm_tn(0, P.data_ptr(), Qh.data_ptr(), C.data_ptr(), M, N, Kw, N, Kw, Kw, None, W.data_ptr(),
-                                   w_scale.data_ptr(), w_zp.data_ptr(), 1, -128, 127, None, _st())
+    st = native_lib.qatvit_gemm_tn(Ph.data_ptr(), Pl.data_ptr(), Qh.data_ptr(), None, C.data_ptr(), M, N, Kw, N, Kw, Kw, None, W.data_ptr(),
+                                   w_scale.data_ptr(), w_zp.data_ptr(), 1, -128, 127, db.data_ptr(), w_scale.data_ptr(), _st())  # ... row_div takes it out
     assert st == 0, native_lib.qatvit_last_error()
     qv = torch.round(W * (1.0 / w_scale)[:, None])
     mask = ((qv >= -128) & (qv <= 127)).double()
     assert rel_l2(C.cpu(), ((P.double().t() @ Q.double()) * mask).cpu()) < 2e-5
+    assert rel_l2(db.cpu(), P.double().sum(0).cpu()) < 2e-5

@@ -17,25 +17,34 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3  # us
 
+def split(x):
+    hi = x.to(torch.bfloat16)
+    return hi, (x - hi.float()).to(torch.bfloat16)
+
 def nt(a_f32, N, K, stats=False, flags=0):
-    A = torch.randn(M, K, device=dev) if a_f32 else torch.randint(-255, 256, (M, K), device=dev).to(torch.bfloat16)
+    if a_f32:
+        Ah, Al = split(torch.randn(M, K, device=dev))
+    else:
+        Ah, Al = torch.randint(-255, 256, (M, K), device=dev).to(torch.bfloat16), None
     B = torch.randint(-128, 128, (N, K), device=dev).to(torch.bfloat16)
     C = torch.empty(M, N, device=dev)
     bias = torch.randn(N, device=dev)
     s1 = torch.tensor([0.01], device=dev)
     sw = torch.zeros(32 * 32, dtype=torch.int32, device=dev)
-    L.qatvit_debug_gemm_ablate(flags)
-    t = timeit(lambda: L.qatvit_gemm_nt(a_f32, A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, K, K, N, s1.data_ptr(), None, None, bias.data_ptr(),
-                                        sw.data_ptr() if stats else None, None, st))
-    L.qatvit_debug_gemm_ablate(0)
+    t = timeit(lambda: L.qatvit_gemm_nt(Ah.data_ptr(), None if Al is None else Al.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, K, K, N,
+                                        s1.data_ptr(), None, None, bias.data_ptr(), sw.data_ptr() if stats else None, st))
     passes = 2 if a_f32 else 1
     return t, 2.0 * M * N * K / t / 1e6, 2.0 * M * N * K * passes / t / 1e6
 
 def tn(q_f32, N, Kw):
-    P = torch.randn(M, N, device=dev)
-    Q = torch.randn(M, Kw, device=dev) if q_f32 else torch.randint(-255, 256, (M, Kw), device=dev).to(torch.bfloat16)
+    Ph, Pl = split(torch.randn(M, N, device=dev))
+    if q_f32:
+        Qh, Ql = split(torch.randn(M, Kw, device=dev))
+    else:
+        Qh, Ql = torch.randint(-255, 256, (M, Kw), device=dev).to(torch.bfloat16), None
     C = torch.zeros(N, Kw, device=dev)
-    t = timeit(lambda: L.qatvit_gemm_tn(q_f32, P.data_ptr(), Q.data_ptr(), C.data_ptr(), M, N, Kw, N, Kw, Kw, None, None, None, None, 0, -128, 127, None, st))
+    t = timeit(lambda: L.qatvit_gemm_tn(Ph.data_ptr(), Pl.data_ptr(), Qh.data_ptr(), None if Ql is None else Ql.data_ptr(), C.data_ptr(), M, N, Kw,
+                                        N, Kw, Kw, None, None, None, None, 0, -128, 127, None, None, st))
     passes = 3 if q_f32 else 2
     return t, 2.0 * M * N * Kw / t / 1e6, 2.0 * M * N * Kw * passes / t / 1e6
 
@@ -43,9 +52,6 @@ print("NT shapes (us, algorithmic TF/s, issued-MFMA TF/s)")
 for name, a, N, K in [("qkv fwd", 0, 1152, 384), ("fc1 fwd", 0, 1536, 384), ("proj fwd", 1, 384, 384), ("fc2 fwd", 1, 384, 1536),
                       ("qkv dgrad", 1, 384, 1152), ("fc1 dgrad", 1, 384, 1536), ("fc2 dgrad", 1, 1536, 384)]:
     print(f"  {name:10s} a_f32={a} N={N:5d} K={K:5d}: " + "  ".join(f"{v:9.1f}" for v in nt(a, N, K)))
-print("NT qkv fwd ablations: flags -> us")
-for fl, what in [(0, "full"), (1, "no stores"), (2, "no mfma"), (4, "no k-loop loads"), (3, "no mfma no stores"), (5, "no loads no stores"), (7, "none")]:
-    print(f"  {what:22s} {nt(0, 1152, 384, flags=fl)[0]:9.1f}   fc2fwd(a_f32,K=1536): {nt(1, 384, 1536, flags=fl)[0]:9.1f}")
 print("TN shapes")
 for name, q, N, Kw in [("qkv wgrad", 0, 1152, 384), ("fc1 wgrad", 0, 1536, 384), ("proj wgrad", 1, 384, 384), ("fc2 wgrad", 1, 384, 1536)]:
     print(f"  {name:10s} q_f32={q} N={N:5d} Kw={Kw:5d}: " + "  ".join(f"{v:9.1f}" for v in tn(q, N, Kw)))
