@@ -5,12 +5,15 @@ Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1: launched by
 ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``); rank 0 prints
 ONE JSON line.  Workload at N=1 is BASELINE.json configs[1]: ViT-S student + QATWrapper,
 batch 256, qnnpack qconfig (per-tensor fake-quant), no teacher; synthetic 224x224x3 images.
-A "step" = student forward + label-smoothed CE + backward (+ gradient all-reduce when N>1);
-optimizer/clip are outside the metric.
+A "step" = student forward + label-smoothed CE + backward (+ bucketed RCCL gradient all-reduce
+overlapped with backward and the rank-0 fake-quant-state broadcast when N>1); optimizer/clip are
+outside the metric.  `--backend x86 --teacher` gives config C3/C4
+(per-channel weights, [0,127] activations, KD against a frozen ViT-B teacher run by torch).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -24,7 +27,8 @@ warnings.filterwarnings("ignore")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 
 
 def prepare(wrapper, backend):
@@ -37,13 +41,26 @@ def prepare(wrapper, backend):
     return p
 
 
-def roofline_fq(batch, iters=20):
-    """Dominant HBM-bound kernel of the student step: the activation fake-quant quantize pass
-    on the largest activation (fc1 output [B*197,1536] fp32).  Algorithmic bytes = 8 B/element
-    (SURVEY.md section 8(d)); time = HIP events on the launch stream around `iters` launches."""
+def hbm_kernel_rates(batch, iters=20):
+    """Achieved HBM GB/s of the stand-alone fake-quant and LayerNorm kernels at the step's largest shapes
+    (algorithmic bytes: FQ 8 B/elt, LN fwd 8 B/elt, LN bwd 12 B/elt - SURVEY.md section 8(d))."""
     from qat_vit_amd import native
 
     L = native.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
     n = batch * 197 * 1536
     x = torch.randn(n, device="cuda")
     y = torch.empty_like(x)
@@ -52,27 +69,23 @@ def roofline_fq(batch, iters=20):
     sc, zp = torch.ones(1, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
     on = torch.ones(1, dtype=torch.int64, device="cuda")
     ws = torch.empty(1 << 12, dtype=torch.uint8, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
-
-    def call():
-        native.check(L.qatvit_fq_forward(x.data_ptr(), y.data_ptr(), mask.data_ptr(), mn.data_ptr(), mx.data_ptr(), sc.data_ptr(),
-                                         zp.data_ptr(), on.data_ptr(), on.data_ptr(), 0.01, 0, 255, 1, n, 0, 0, ws.data_ptr(), st), "fq")
-
-    for _ in range(3):
-        call()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        call()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    # one call = min/max pass (reads 4 B/elt) + quantize pass (reads 4, writes 4 B/elt): the
-    # algorithmic credit is 8 B/elt for the whole fused op
-    achieved = 8.0 * n / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "qatvit_fq_forward (k_minmax_tensor + k_qparams + k_quantize)", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "elements": n, "ms_per_launch": round(ms, 4)}
+    ms = timed(lambda: native.check(L.qatvit_fq_forward(x.data_ptr(), y.data_ptr(), mask.data_ptr(), mn.data_ptr(), mx.data_ptr(), sc.data_ptr(),
+                                                        zp.data_ptr(), on.data_ptr(), on.data_ptr(), 0.01, 0, 255, 1, n, 0, 0, ws.data_ptr(), st), "fq"))
+    out["fake_quant_fwd_GBps"] = round(8.0 * n / (ms * 1e-3) / 1e9, 1)
+    ms = timed(lambda: native.check(L.qatvit_fq_backward(x.data_ptr(), mask.data_ptr(), y.data_ptr(), n, st), "fqb"))
+    out["fake_quant_bwd_GBps"] = round(8.0 * n / (ms * 1e-3) / 1e9, 1)
+    rows, D = batch * 197, 384
+    xx = torch.randn(rows, D, device="cuda")
+    g, b = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
+    yy, mean, rstd = torch.empty_like(xx), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    ms = timed(lambda: native.check(L.qatvit_ln_forward(xx.data_ptr(), g.data_ptr(), b.data_ptr(), yy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, 1e-6, st), "ln"))
+    out["layernorm_fwd_GBps"] = round(8.0 * rows * D / (ms * 1e-3) / 1e9, 1)
+    ms = timed(lambda: native.check(L.qatvit_ln_backward(yy.data_ptr(), xx.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), yy.data_ptr(),
+                                                         dg.data_ptr(), db.data_ptr(), rows, D, st), "lnb"))
+    out["layernorm_bwd_GBps"] = round(12.0 * rows * D / (ms * 1e-3) / 1e9, 1)
+    out["hbm_peak_GBps"] = HBM_PEAK_GBS
+    return out
 
 
 def cpu_baseline(seconds=15.0):
@@ -103,15 +116,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
     ap.add_argument("--backend", default="qnnpack")
+    ap.add_argument("--teacher", action="store_true", help="KD against a frozen ViT-B teacher (configs C3/C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-rates", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -121,35 +135,45 @@ def main():
     import qat_vit_amd
     from qat_vit_amd import functional as F
     from qat_vit_amd import native
-    from qat_vit_amd.dp import FQStateSync, GradReducer
 
-    native.lib()  # fail loudly before any timing if the HIP library is missing
+    L = native.lib()  # fail loudly before any timing if the HIP library is missing
     torch.manual_seed(0)
     student = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True).to(dev)
     model = prepare(student, args.backend).to(dev)
-    reducer = sync = None
-    if world > 1:
-        for p in model.parameters():
-            dist.broadcast(p.data, src=0)
-        reducer, sync = GradReducer(model), FQStateSync(model)
+    teacher = None
+    if args.teacher:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            teacher = qat_vit_amd.create_teacher("vit", num_classes=10).to(dev).eval()
+        for p in teacher.parameters():
+            p.requires_grad = False
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, 224, 224, device=dev, generator=g)
     y = torch.randint(0, 10, (args.batch,), device=dev, generator=g)
 
+    with torch.no_grad():
+        model(x)  # builds the native engine (workspace, FQ arenas)
+    eng = model.__dict__["_qatvit_engine"]
+    if world > 1:
+        eng.enable_data_parallel()
+
     def step():
-        for p in model.parameters():
+        for p in eng.params:
             p.grad = None
-        if sync is not None:
-            sync.broadcast()
+        t_out = None
+        if teacher is not None:
+            with torch.no_grad():
+                t_out = teacher(x)
         out = model(x)
-        loss, _ = F.kd_ce_loss(out, None, y, 4.0, 0.5, 0.1)
+        loss, _ = F.kd_ce_loss(out, t_out, y, 4.0, 0.5, 0.1)
         loss.backward()
-        if reducer is not None:
-            reducer.wait()
 
     for _ in range(args.warmup):
         step()
+    n_nt2 = 6 * eng.cfg.depth  # proj fwd, fc2 fwd + 4 dgrads per block
+    if rank == 0:
+        native.check(L.qatvit_profile_start(1, n_nt2 * args.steps + 8), "profile_start")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -166,17 +190,29 @@ def main():
         dt = t.item()
 
     if rank == 0:
+        ms, cnt, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        native.check(L.qatvit_profile_stop(ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl)), "profile_stop")
         imgs = args.batch * world * args.steps
         res = {
             "metric": "images/sec QAT student step (fwd+bwd+allreduce)",
             "value": round(imgs / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"vit_small_patch16_224 student + QATWrapper, {args.backend} qconfig (per-tensor fake-quant), no teacher, "
-                                   f"batch {args.batch}/GPU, 224x224x3 (BASELINE configs[1])",
+            "dtype": "f32 semantics (bf16 MFMA on exact grid / hi+lo split operands, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"vit_small_patch16_224 student + QATWrapper, {args.backend} qconfig, "
+                                   f"{'vit_base teacher KD (teacher forward by torch)' if args.teacher else 'no teacher'}, "
+                                   f"batch {args.batch}/GPU, 224x224x3 (BASELINE configs[{2 if args.teacher else 1}])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         }
-        res["roofline"] = roofline_fq(args.batch)
+        tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        res["roofline"] = {
+            "bound": "mfma", "kernel": "qv::k_gemm_nt<2,3> (split-bf16 A: proj/fc2 forward + all dgrads; the largest single kernel of the step)",
+            "achieved": round(tflops, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": cnt.value, "avg_us_per_launch": round(1e3 * ms.value / max(1, cnt.value), 1),
+            "note": "algorithmic FLOPs 2*M*N*K per launch / HIP-event time of that launch inside the timed steps; every launch issues two "
+                    "bf16 MFMA passes (hi and lo), so issued MFMA work is 2x this figure",
+        }
+        if not args.no_kernel_rates:
+            res["hbm_kernels"] = hbm_kernel_rates(args.batch)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -167,6 +167,12 @@ int qatvit_student_forward(const qatvit_cfg* cfg, void* const* params, const qat
 int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
                             const float* dlogits, void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to,
                             void* stream);
+/* Measurement hooks (bench.py): bracket every launch of one GEMM class inside the step with HIP events on the
+ * launch stream.  kind: 1 = NT with split (hi+lo) A operand, 2 = NT with grid A operand, 3 = TN (wgrad).
+ * stop() synchronises on the recorded events and returns the summed kernel time, launch count and the summed
+ * algorithmic FLOPs (2*M*N*K per launch, one pass). */
+int qatvit_profile_start(int32_t kind, int32_t max_launches);
+int qatvit_profile_stop(double* total_ms, int64_t* launches, double* flops);
 /* byte offset of a named intermediate tensor inside the workspace (tests); -1 if unknown */
 int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, int32_t block);
 

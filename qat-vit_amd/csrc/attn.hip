@@ -21,6 +21,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kAW = 8;  // waves per attention workgroup (two per SIMD)
+
 struct AQP { float s, inv, zp; float fqmin, fqmax; };
 __device__ inline float qint(float x, const AQP& q) { return fminf(fmaxf(rintf(x * q.inv) + q.zp, q.fqmin), q.fqmax) - q.zp; }
 __device__ inline bool qin(float x, const AQP& q) {
@@ -97,7 +99,7 @@ struct AttnArgs {
 template <int HD, bool TR, int NKT>
 __device__ inline void stage_tokens(char* img, const float* base, int T, int ld, const AQP& q) {
     constexpr int CH = HD / 8;  // 16-B chunks per token row
-    for (int i = threadIdx.x; i < NKT * 16 * CH; i += 256) {
+    for (int i = threadIdx.x; i < NKT * 16 * CH; i += kAW * 64) {
         const int tok = i / CH, ch = i % CH;
         bf16x8 f;
         if (tok < T) f = load_q8(base + (int64_t)tok * ld + ch * 8, q);
@@ -110,7 +112,7 @@ __device__ inline void stage_tokens(char* img, const float* base, int T, int ld,
 template <int HD, int NKT>
 __device__ inline void stage_split_tr(char* img_hi, char* img_lo, const float* base, int T, int ld) {
     constexpr int CH = HD / 8;
-    for (int i = threadIdx.x; i < NKT * 16 * CH; i += 256) {
+    for (int i = threadIdx.x; i < NKT * 16 * CH; i += kAW * 64) {
         const int tok = i / CH, ch = i % CH;
         bf16x8 hi, lo;
         if (tok < T) load_split8(base + (int64_t)tok * ld + ch * 8, hi, lo);
@@ -126,7 +128,7 @@ __device__ inline AQP make_aqp(const float* qp, int qmin, int qmax) { return AQP
 
 // ============================================================================ forward
 template <int HD, int NKT>
-__global__ __launch_bounds__(256) void k_attn_fwd(const AttnArgs p) {
+__global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
     constexpr int IMG = NKT * 16 * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;         // row image
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const float c = q.s * q.s * p.softmax_scale;
     const int nqt = (T + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += kAW) {
         const int qrow = min(qt * 16 + r, T - 1);
         bf16x8 qf[HD / 32];
 #pragma unroll
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const AttnArgs p) {
 
 // ============================================================================ backward, dQ (+ delta)
 template <int HD, int NKT>
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnArgs p) {
+__global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
     constexpr int IMG = NKT * 16 * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;             // row image (A operand of S^T)
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const float c = q.s * q.s * p.softmax_scale;
     const int nqt = (T + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += kAW) {
         const int qrow = min(qt * 16 + r, T - 1);
         const bool qvalid = qt * 16 + r < T;
         bf16x8 qf[HD / 32], dh[HD / 32], dl[HD / 32];
@@ -306,8 +308,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const AttnArgs p) {
 
 // ============================================================================ backward, dK and dV
 template <int HD, int NKT>
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnArgs p) {
+__global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dkv(const AttnArgs p) {
+    // Each wave owns up to two key tiles (j0 = wave, j1 = wave + kAW) and keeps their K/V fragments and the
+    // dK^T / dV^T accumulators in registers; it sweeps the query tiles in pairs ONCE, loading (and quantizing /
+    // splitting) each pair's Q and dO row fragments once for both owned key tiles.
     constexpr int IMG = NKT * 16 * HD * 2;
+    constexpr int KK = HD / 32, ND = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQt = smem;             // tr image of Q integers
     char* sDh = smem + IMG;       // tr images of dO hi / lo
@@ -320,94 +326,123 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnArgs p) {
     stage_tokens<HD, true, NKT>(sQt, base, T, ld, q);
     stage_split_tr<HD, NKT>(sDh, sDl, dObase, T, D);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float c = q.s * q.s * p.softmax_scale;
     const int nkt = (T + 15) / 16;
     const float* lse = p.lse + (int64_t)blockIdx.x * TP;
     const float* delta = p.delta + (int64_t)blockIdx.x * TP;
-    for (int j = wave; j < nkt; j += 4) {
-        const int krow = min(16 * j + r, T - 1);
-        bf16x8 kf[HD / 32], vf[HD / 32];
+    const int jt[2] = {wave, wave + kAW};
+    const bool has[2] = {jt[0] < nkt, jt[1] < nkt};
+    if (!has[0]) return;  // (after the only barrier)
+    bf16x8 kf[2][KK], vf[2][KK];
+    bool kvalid[2];
+    f32x4 dk[2][ND], dv[2][ND];
 #pragma unroll
-        for (int kk = 0; kk < HD / 32; ++kk) {
-            kf[kk] = load_q8(base + D + (int64_t)krow * ld + 32 * kk + 8 * g, q);
-            vf[kk] = load_q8(base + 2 * D + (int64_t)krow * ld + 32 * kk + 8 * g, q);
+    for (int u = 0; u < 2; ++u) {
+        const int krow = min(16 * jt[u] + r, T - 1);
+        kvalid[u] = has[u] && 16 * jt[u] + r < T;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            kf[u][kk] = load_q8(base + D + (int64_t)krow * ld + 32 * kk + 8 * g, q);
+            vf[u][kk] = load_q8(base + 2 * D + (int64_t)krow * ld + 32 * kk + 8 * g, q);
         }
-        const bool kvalid = 16 * j + r < T;
-        f32x4 dk[HD / 16], dv[HD / 16];
 #pragma unroll
-        for (int id = 0; id < HD / 16; ++id) dk[id] = dv[id] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int id = 0; id < ND; ++id) dk[u][id] = dv[u][id] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 1
-        for (int qs = 0; qs < NKT / 2; ++qs) {
+    for (int qs = 0; qs < NKT / 2; ++qs) {
+        // this pair's query-row fragments (A operands of S and dP), and per-row softmax constants
+        bf16x8 qa[2][KK], da[2][KK], db[2][KK];
+        float lse_r[2][4], dlt_r[2][4];
+        bool qval[2][4];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int qt = 2 * qs + v;
+            const int qrow = min(16 * qt + r, T - 1);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                qa[v][kk] = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
+                load_split8(dObase + (int64_t)qrow * D + 32 * kk + 8 * g, da[v][kk], db[v][kk]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qq = 16 * qt + 4 * g + e;
+                qval[v][e] = qq < T;
+                lse_r[v][e] = lse[min(qq, T - 1)];
+                dlt_r[v][e] = delta[min(qq, T - 1)];
+            }
+        }
+        bf16x8 dth[ND], dtl[ND], qtf[ND];
+#pragma unroll
+        for (int id = 0; id < ND; ++id) {
+            dth[id] = tr_frag2<HD>(sDh, 32 * qs, 32 * qs + 16, 16 * id, lane);
+            dtl[id] = tr_frag2<HD>(sDl, 32 * qs, 32 * qs + 16, 16 * id, lane);
+            qtf[id] = tr_frag2<HD>(sQt, 32 * qs, 32 * qs + 16, 16 * id, lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!has[u]) continue;  // wave-uniform
             f32x4 p2[2], ds2[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int qt = 2 * qs + u;
-                const int qrow = min(16 * qt + r, T - 1);
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < 2; ++v) {
+                f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < HD / 32; ++kk) {
-                    const bf16x8 qa = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
-                    bf16x8 da, db;
-                    load_split8(dObase + (int64_t)qrow * D + 32 * kk + 8 * g, da, db);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kk], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kk], dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db, vf[kk], dp, 0, 0, 0);
+                for (int kk = 0; kk < KK; ++kk) {
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[v][kk], kf[u][kk], sacc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[v][kk], vf[u][kk], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db[v][kk], vf[u][kk], dp, 0, 0, 0);
                 }
-                // S orientation: this lane's key = 16j + r, query = 16qt + 4g + e
+                // S orientation: this lane's key = 16*jt[u] + r, query = 16*(2qs+v) + 4g + e
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int qq = 16 * qt + 4 * g + e;
-                    const bool valid = qq < T && kvalid;
-                    const int qc = min(qq, T - 1);
-                    const float pr = valid ? expf(s[e] * c - lse[qc]) : 0.f;
-                    p2[u][e] = pr;
-                    ds2[u][e] = pr * (dp[e] * q.s - delta[qc]);
+                    const float pr = (qval[v][e] && kvalid[u]) ? expf(sacc[e] * c - lse_r[v][e]) : 0.f;
+                    p2[v][e] = pr;
+                    ds2[v][e] = pr * (dp[e] * q.s - dlt_r[v][e]);
                 }
             }
             bf16x8 ph, pl, sh, sl;
             split_acc2(p2[0], p2[1], ph, pl);
             split_acc2(ds2[0], ds2[1], sh, sl);
 #pragma unroll
-            for (int id = 0; id < HD / 16; ++id) {
-                const bf16x8 dth = tr_frag2<HD>(sDh, 32 * qs, 32 * qs + 16, 16 * id, lane);
-                const bf16x8 dtl = tr_frag2<HD>(sDl, 32 * qs, 32 * qs + 16, 16 * id, lane);
-                const bf16x8 qtf = tr_frag2<HD>(sQt, 32 * qs, 32 * qs + 16, 16 * id, lane);
-                dv[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth, ph, dv[id], 0, 0, 0);
-                dv[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth, pl, dv[id], 0, 0, 0);
-                dv[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtl, ph, dv[id], 0, 0, 0);
-                dk[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, sh, dk[id], 0, 0, 0);
-                dk[id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, sl, dk[id], 0, 0, 0);
+            for (int id = 0; id < ND; ++id) {
+                dv[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth[id], ph, dv[u][id], 0, 0, 0);
+                dv[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth[id], pl, dv[u][id], 0, 0, 0);
+                dv[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtl[id], ph, dv[u][id], 0, 0, 0);
+                dk[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[id], sh, dk[u][id], 0, 0, 0);
+                dk[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[id], sl, dk[u][id], 0, 0, 0);
             }
         }
-        // accumulators: row = feature 16id + 4g + e, col = key 16j + r  -> 16-B stores along d
-        if (kvalid) {
-            const float a = q.s * p.softmax_scale;
+    }
+    // accumulators: row = feature 16id + 4g + e, col = key 16j + r  -> 8-B (4 x bf16) stores along d
+    const float a = q.s * p.softmax_scale;
 #pragma unroll
-            for (int id = 0; id < HD / 16; ++id) {
-                const int64_t offk = ((int64_t)b * T + 16 * j + r) * ld + D + h * HD + 16 * id + 4 * g;
-                const int64_t offv = offk + D;
-                const float4 xk = *reinterpret_cast<const float4*>(p.qkv + offk), xv = *reinterpret_cast<const float4*>(p.qkv + offv);
-                float4 ck = make_float4(1.f, 1.f, 1.f, 1.f), cv = ck;
-                if (p.col_scale) {
-                    ck = *reinterpret_cast<const float4*>(p.col_scale + D + h * HD + 16 * id + 4 * g);
-                    cv = *reinterpret_cast<const float4*>(p.col_scale + 2 * D + h * HD + 16 * id + 4 * g);
-                }
-                const float vk[4] = {qin(xk.x, q) ? dk[id][0] * a * ck.x : 0.f, qin(xk.y, q) ? dk[id][1] * a * ck.y : 0.f,
-                                     qin(xk.z, q) ? dk[id][2] * a * ck.z : 0.f, qin(xk.w, q) ? dk[id][3] * a * ck.w : 0.f};
-                const float vv[4] = {qin(xv.x, q) ? dv[id][0] * cv.x : 0.f, qin(xv.y, q) ? dv[id][1] * cv.y : 0.f,
-                                     qin(xv.z, q) ? dv[id][2] * cv.z : 0.f, qin(xv.w, q) ? dv[id][3] * cv.w : 0.f};
-                bf16x4 kh, kl, vh, vl;
+    for (int u = 0; u < 2; ++u) {
+        if (!kvalid[u]) continue;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    kh[e] = (__bf16)vk[e]; kl[e] = (__bf16)(vk[e] - (float)kh[e]);
-                    vh[e] = (__bf16)vv[e]; vl[e] = (__bf16)(vv[e] - (float)vh[e]);
-                }
-                *reinterpret_cast<bf16x4*>(p.dqkv_hi + offk) = kh;
-                *reinterpret_cast<bf16x4*>(p.dqkv_lo + offk) = kl;
-                *reinterpret_cast<bf16x4*>(p.dqkv_hi + offv) = vh;
-                *reinterpret_cast<bf16x4*>(p.dqkv_lo + offv) = vl;
+        for (int id = 0; id < ND; ++id) {
+            const int64_t offk = ((int64_t)b * T + 16 * jt[u] + r) * ld + D + h * HD + 16 * id + 4 * g;
+            const int64_t offv = offk + D;
+            const float4 xk = *reinterpret_cast<const float4*>(p.qkv + offk), xv = *reinterpret_cast<const float4*>(p.qkv + offv);
+            float4 ck = make_float4(1.f, 1.f, 1.f, 1.f), cv = ck;
+            if (p.col_scale) {
+                ck = *reinterpret_cast<const float4*>(p.col_scale + D + h * HD + 16 * id + 4 * g);
+                cv = *reinterpret_cast<const float4*>(p.col_scale + 2 * D + h * HD + 16 * id + 4 * g);
             }
+            const float vk[4] = {qin(xk.x, q) ? dk[u][id][0] * a * ck.x : 0.f, qin(xk.y, q) ? dk[u][id][1] * a * ck.y : 0.f,
+                                 qin(xk.z, q) ? dk[u][id][2] * a * ck.z : 0.f, qin(xk.w, q) ? dk[u][id][3] * a * ck.w : 0.f};
+            const float vv[4] = {qin(xv.x, q) ? dv[u][id][0] * cv.x : 0.f, qin(xv.y, q) ? dv[u][id][1] * cv.y : 0.f,
+                                 qin(xv.z, q) ? dv[u][id][2] * cv.z : 0.f, qin(xv.w, q) ? dv[u][id][3] * cv.w : 0.f};
+            bf16x4 kh, kl, vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kh[e] = (__bf16)vk[e]; kl[e] = (__bf16)(vk[e] - (float)kh[e]);
+                vh[e] = (__bf16)vv[e]; vl[e] = (__bf16)(vv[e] - (float)vh[e]);
+            }
+            *reinterpret_cast<bf16x4*>(p.dqkv_hi + offk) = kh;
+            *reinterpret_cast<bf16x4*>(p.dqkv_lo + offk) = kl;
+            *reinterpret_cast<bf16x4*>(p.dqkv_hi + offv) = vh;
+            *reinterpret_cast<bf16x4*>(p.dqkv_lo + offv) = vl;
         }
     }
 }
@@ -430,9 +465,9 @@ static void launch3(int which, const AttnArgs& a, hipStream_t st) {
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)), true);
     (void)once;
-    if (which == 0) k_attn_fwd<HD, NKT><<<grid, 256, 2 * img, st>>>(a);
-    else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, 256, 3 * img, st>>>(a);
-    else k_attn_bwd_dkv<HD, NKT><<<grid, 256, 3 * img, st>>>(a);
+    if (which == 0) k_attn_fwd<HD, NKT><<<grid, kAW * 64, 2 * img, st>>>(a);
+    else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, kAW * 64, 3 * img, st>>>(a);
+    else k_attn_bwd_dkv<HD, NKT><<<grid, kAW * 64, 3 * img, st>>>(a);
 }
 
 static int dispatch(int which, const AttnArgs& a, hipStream_t st) {

@@ -8,6 +8,8 @@
 // device state (backward runs on autograd's worker thread).
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/qatvit.h"
 #include "qv_common.h"
 #include "qv_kernels.h"
@@ -143,6 +145,25 @@ static int check_cfg(const qatvit_cfg& c) {
     return 0;
 }
 
+// ---- optional in-situ timing of one GEMM class with HIP events on the launch stream (bench.py only)
+struct Prof {
+    int kind = 0;  // 0 off, 1 NT split-A (k_gemm_nt<2,3>), 2 NT grid-A (k_gemm_nt<1,2>), 3 TN
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    double flops = 0.0;
+};
+static Prof g_prof;
+struct ProfScope {
+    hipStream_t st;
+    bool on;
+    ProfScope(int kind, double flops, hipStream_t s) : st(s), on(g_prof.kind == kind && g_prof.used + 2 <= g_prof.ev.size()) {
+        if (on) { (void)hipEventRecord(g_prof.ev[g_prof.used], st); g_prof.flops += flops; }
+    }
+    ~ProfScope() {
+        if (on) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st); g_prof.used += 2; }
+    }
+};
+
 struct Ctx {
     const qatvit_cfg& c;
     Dims d;
@@ -173,6 +194,7 @@ struct Ctx {
     int linear_fwd(const void* A_hi, const void* A_lo, int M, int wi, const float* s_act, const float* bias, float* C, int ai_out) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
+        ProfScope ps(A_lo ? 1 : 2, 2.0 * M * N * K, st);
         return launch_gemm_nt(A_hi, A_lo, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
                               c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st);
     }
@@ -182,6 +204,7 @@ struct Ctx {
     int linear_dgrad(const void* dY_hi, const void* dY_lo, int M, int wi, float* dX) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
+        ProfScope ps(1, 2.0 * M * N * K, st);
         return launch_gemm_nt(dY_hi, dY_lo, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr,
                               nullptr, nullptr, 1, st);
     }
@@ -190,6 +213,7 @@ struct Ctx {
                      bool dy_scaled = true) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
+        ProfScope ps(3, 2.0 * M * N * K, st);
         return launch_gemm_tn(dY_hi, dY_lo, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
                               c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st);
     }
@@ -397,6 +421,38 @@ int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qa
     if (make_plan(*cfg, &x.p)) return 1;
     if (bwd(x, dlogits, grads, stage_from, stage_to)) return 1;
     QV_CHECK_LAUNCH("qatvit_student_backward");
+    return 0;
+}
+
+// bench.py: time every launch of one GEMM class with HIP events on the stream it is launched on
+int qatvit_profile_start(int32_t kind, int32_t max_launches) {
+    QV_CHECK_ARG(kind >= 1 && kind <= 3 && max_launches > 0, "qatvit_profile_start: bad arguments");
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.assign((size_t)max_launches * 2, nullptr);
+    for (auto& e : g_prof.ev)
+        if (hipEventCreate(&e) != hipSuccess) { set_error("qatvit_profile_start: hipEventCreate failed"); return 2; }
+    g_prof.used = 0;
+    g_prof.flops = 0.0;
+    g_prof.kind = kind;
+    return 0;
+}
+
+int qatvit_profile_stop(double* total_ms, int64_t* launches, double* flops) {
+    QV_CHECK_ARG(total_ms && launches && flops, "qatvit_profile_stop: null argument");
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        (void)hipEventSynchronize(g_prof.ev[i + 1]);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+        ms += t;
+    }
+    *total_ms = ms;
+    *launches = (int64_t)(g_prof.used / 2);
+    *flops = g_prof.flops;
+    g_prof.kind = 0;
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.used = 0;
     return 0;
 }
 
