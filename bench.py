@@ -205,7 +205,7 @@ def main():
         }
         tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         res["roofline"] = {
-            "bound": "mfma", "kernel": "qv::k_gemm_nt<2,3> (split-bf16 A: proj/fc2 forward + all dgrads; the largest single kernel of the step)",
+            "bound": "mfma", "kernel": "qv::k_gemm_nt<2,3,4,2> (split-bf16 A: proj/fc2 forward + all dgrads; the largest single kernel of the step)",
             "achieved": round(tflops, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / BF16_PEAK_TFLOPS, 4), "traffic": None,
             "launches": cnt.value, "avg_us_per_launch": round(1e3 * ms.value / max(1, cnt.value), 1),
             "note": "algorithmic FLOPs 2*M*N*K per launch / HIP-event time of that launch inside the timed steps; every launch issues two "

@@ -16,6 +16,8 @@
 // 2- or 3-stage ring with counted s_waitcnt vmcnt and ONE raw s_barrier per k-step; the LDS images are
 // XOR-swizzled on the DMA *source* address (the DMA destination is lane-linear) and on the fragment
 // read, so ds_read_b128 / ds_read_b64_tr_b16 are bank-conflict free.
+#include <stdlib.h>
+
 #include "qv_common.h"
 #include "qv_kernels.h"
 
@@ -41,11 +43,11 @@ __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t byt
 }
 
 template <int N> __device__ inline void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else static_assert(N == 0, "add the immediate");
+    static_assert(N >= 0 && N <= 20, "vmcnt immediate");
+#define QV_W(n) if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+    QV_W(0); QV_W(1); QV_W(2); QV_W(3); QV_W(4); QV_W(5); QV_W(6); QV_W(7); QV_W(8); QV_W(9); QV_W(10);
+    QV_W(11); QV_W(12); QV_W(13); QV_W(14); QV_W(15); QV_W(16); QV_W(17); QV_W(18); QV_W(19); QV_W(20);
+#undef QV_W
 }
 
 // ============================================================================ NT
@@ -66,17 +68,22 @@ struct NTArgs {
     int stat_slots;          // number of 128-B-spaced accumulator pairs (power of two; 1 = a single pair)
 };
 
-template <int TA, int NSTAGE>
-__global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
-    constexpr int BM = 128, BN = 128, BK = 64;
-    constexpr int IMG = 128 * 128;                  // bytes of one [128][64] bf16 image
-    constexpr int STAGE = (TA + 1) * IMG;
-    constexpr int NDMA = (TA + 1) * 4;              // LDS-DMA instructions per wave per k-tile
+template <int TA, int NSTAGE, int WM, int TM>
+__global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
+    // WM x 2 waves, each a (16*TM) x 64 output sub-tile: BM = 16*TM*WM rows x 128 columns per workgroup
+    constexpr int WR = 16 * TM;                     // rows per wave
+    constexpr int BM = WR * WM, BN = 128, BK = 64, NW = 2 * WM;
+    constexpr int IMGA = BM * 128;                  // bytes of one [BM][64] bf16 image
+    constexpr int IMGB = BN * 128;
+    constexpr int STAGE = TA * IMGA + IMGB;
+    constexpr int PA = (BM / 8) / NW;               // 1-KiB DMA pieces per wave per A image
+    constexpr int PB = (BN / 8) / NW;
+    constexpr int NDMA = TA * PA + PB;              // LDS-DMA instructions per wave per k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;   // wm in [0, WM)
     const int tilesN = p.N / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
@@ -92,20 +99,23 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
         char* st = smem + (kt % NSTAGE) * STAGE;
         const int k0 = kt * BK;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int piece = wave * 4 + c;              // 16 pieces per image
-            const int row = piece * 8 + lr;
-            const uint32_t offA = (uint32_t)(((int64_t)(m0 + row) * p.lda + k0 + src_chunk * 8) * 2);
-            const uint32_t offB = (uint32_t)(((int64_t)(n0 + row) * p.ldb + k0 + src_chunk * 8) * 2);
+        for (int c = 0; c < PA; ++c) {
+            const int piece = wave * PA + c;
+            const uint32_t offA = (uint32_t)(((int64_t)(m0 + piece * 8 + lr) * p.lda + k0 + src_chunk * 8) * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lds_void*)(st + piece * 1024), 16, offA, 0, 0, 0);
-            if constexpr (TA == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (lds_void*)(st + IMG + piece * 1024), 16, offA, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(st + TA * IMG + piece * 1024), 16, offB, 0, 0, 0);
+            if constexpr (TA == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (lds_void*)(st + IMGA + piece * 1024), 16, offA, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            const int piece = wave * PB + c;
+            const uint32_t offB = (uint32_t)(((int64_t)(n0 + piece * 8 + lr) * p.ldb + k0 + src_chunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(st + TA * IMGA + piece * 1024), 16, offB, 0, 0, 0);
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -122,18 +132,18 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
         asm volatile("" ::: "memory");
         if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
         const char* st = smem + (kt % NSTAGE) * STAGE;
-        const char* sB = st + TA * IMG;
+        const char* sB = st + TA * IMGA;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 bfrag[4], afrag[TA][4];
+            bf16x8 bfrag[4], afrag[TA][TM];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off(wn * 64 + 16 * j + r, 4 * kk + g));
 #pragma unroll
             for (int t = 0; t < TA; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) afrag[t][i] = *reinterpret_cast<const bf16x8*>(st + t * IMG + nt_off(wm * 64 + 16 * i + r, 4 * kk + g));
+                for (int i = 0; i < TM; ++i) afrag[t][i] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + nt_off(wm * WR + 16 * i + r, 4 * kk + g));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int t = 0; t < TA; ++t)
 #pragma unroll
@@ -153,19 +163,20 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
     constexpr int LDC = BN + 4;                 // fp32 words per staged row (pad: conflict-free b32 writes)
     float* sC = reinterpret_cast<float*>(smem); // [64][LDC]
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < BM / 64; ++h) {
         if (h) __syncthreads();
-        if (wm == h) {
+        if ((wm * WR) / 64 == h) {
+            const int rbase = wm * WR - 64 * h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int cl = wn * 64 + 16 * j + r;
                 const float a = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
                 const float b = p.bias ? p.bias[n0 + cl] : 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int rl = 16 * i + 4 * g + e;
+                        const int rl = rbase + 16 * i + 4 * g + e;
                         const float v = acc[i][j][e] * a + b;
                         sC[rl * LDC + cl] = v;
                         if (m0 + 64 * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
@@ -175,8 +186,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
         __syncthreads();
         const int c4 = tid & 31, r0 = tid >> 5;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rl = r0 + 8 * it;
+        for (int it = 0; it < 64 / (NW * 2); ++it) {
+            const int rl = r0 + (NW * 2) * it;
             const int row = m0 + 64 * h + rl;
             if (row < p.M)
                 *reinterpret_cast<float4*>(p.C + (int64_t)row * p.ldc + n0 + 4 * c4) = *reinterpret_cast<const float4*>(sC + rl * LDC + 4 * c4);
@@ -187,12 +198,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const NTArgs p) {
         mx = wave_max(mx);
         __syncthreads();
         float* smn = reinterpret_cast<float*>(smem);
-        float* smx = smn + 4;
+        float* smx = smn + NW;
         if (lane == 0) { smn[wave] = mn; smx[wave] = mx; }
         __syncthreads();
         if (tid == 0) {
-            mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
-            mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+#pragma unroll
+            for (int w = 1; w < NW; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); }
             stat_atomic(p.stats, p.stat_slots, mn, mx);
         }
     }
@@ -212,18 +223,29 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B), C, M, N, K, lda, ldb,
              ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots};
-    const int nwg = cdiv(M, 128) * (N / 128);
+    // Tile/wave configurations (tools/bench_gemm.py picks per operand class; QATVIT_NT1 / QATVIT_NT2 override for tuning):
+    //   a: 128 x 128, 4 waves x (64x64)     b: 256 x 128, 8 waves x (64x64)     c: 128 x 128, 8 waves x (32x64)
+    static const int cfg1 = getenv("QATVIT_NT1") ? atoi(getenv("QATVIT_NT1")) : 3;   // measured best at B=256 (profiles/round1_gemm_configs.txt)
+    static const int cfg2 = getenv("QATVIT_NT2") ? atoi(getenv("QATVIT_NT2")) : 2;
+#define QV_NT_LAUNCH(TA_, NS_, WM_, TM_)                                                            \
+    do {                                                                                            \
+        constexpr int bm = 16 * TM_ * WM_;                                                          \
+        constexpr size_t lds = (size_t)NS_ * (TA_ * bm * 128 + 16384);                              \
+        static bool once = (allow_lds(k_gemm_nt<TA_, NS_, WM_, TM_>, lds), true);                   \
+        (void)once;                                                                                 \
+        k_gemm_nt<TA_, NS_, WM_, TM_><<<cdiv(M, bm) * (N / 128), WM_ * 128, lds, st>>>(a);          \
+    } while (0)
     if (A_lo) {
-        constexpr size_t lds = 3 * 3 * 16384;  // 3 stages x (A_hi, A_lo, B)
-        static bool once = (allow_lds(k_gemm_nt<2, 3>, lds), true);
-        (void)once;
-        k_gemm_nt<2, 3><<<nwg, 256, lds, st>>>(a);
+        if (cfg2 == 1) QV_NT_LAUNCH(2, 3, 2, 4);        // a, 3 stages (144 KiB)
+        else if (cfg2 == 2) QV_NT_LAUNCH(2, 3, 4, 2);   // c, 3 stages (144 KiB)
+        else QV_NT_LAUNCH(2, 2, 4, 4);                  // (cfg 0) b, 2 stages (160 KiB: the whole LDS)
     } else {
-        constexpr size_t lds = 2 * 2 * 16384;  // 2 stages x (A, B) = 64 KiB (the 64 x 132 fp32 epilogue tile fits): two workgroups per CU
-        static bool once = (allow_lds(k_gemm_nt<1, 2>, lds), true);
-        (void)once;
-        k_gemm_nt<1, 2><<<nwg, 256, lds, st>>>(a);
+        if (cfg1 == 1) QV_NT_LAUNCH(1, 3, 4, 4);        // b, 3 stages (144 KiB)
+        else if (cfg1 == 2) QV_NT_LAUNCH(1, 3, 4, 2);   // c, 3 stages (96 KiB)
+        else if (cfg1 == 3) QV_NT_LAUNCH(1, 2, 4, 2);   // c, 2 stages (64 KiB, two workgroups per CU)
+        else QV_NT_LAUNCH(1, 2, 2, 4);                  // (cfg 0) a, 2 stages (64 KiB, two workgroups per CU)
     }
+#undef QV_NT_LAUNCH
     return 0;
 }
 
@@ -264,12 +286,15 @@ __device__ inline bf16x8 tr_frag(const char* img, int row0, int col0, int lane) 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TQ, int NSTAGE>
-__global__ __launch_bounds__(256) void k_gemm_tn(const TNArgs p) {
-    constexpr int BN = 128, BKW = 128, BK = 64;
+template <int TQ, int NSTAGE, int WM>
+__global__ __launch_bounds__(WM * 128) void k_gemm_tn(const TNArgs p) {
+    // WM x 2 waves over a 128 (N) x 128 (Kw) output tile: each wave (128/WM) x 64
+    constexpr int BN = 128, BKW = 128, BK = 64, NW = 2 * WM;
+    constexpr int TM = BN / WM / 16;                // 16-row fragments of P per wave
     constexpr int IMG = BK * 256;                   // bytes of one [64][128] bf16 image
     constexpr int STAGE = (2 + TQ) * IMG;
-    constexpr int NDMA = (2 + TQ) * 4;
+    constexpr int PP = 16 / NW;                     // 1-KiB DMA pieces per wave per image
+    constexpr int NDMA = (2 + TQ) * PP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,8 +317,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TNArgs p) {
         char* st = smem + (s % NSTAGE) * STAGE;
         const int mrow0 = (s_begin + s) * BK;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int piece = wave * 4 + c;                    // 16 pieces per image
+        for (int c = 0; c < PP; ++c) {
+            const int piece = wave * PP + c;                   // 16 pieces per image
             const int row = piece * 4 + lr;                    // 0..63
             const int src_chunk = (lane & 15) ^ tn_sw(row);
             const uint32_t offP = (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + src_chunk * 8) * 2);
@@ -305,15 +330,15 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TNArgs p) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.dbias != nullptr && (blockIdx.x % tilesK) == 0 && wn == 0;  // wave-uniform
-    f32x4 accb[4];
+    f32x4 accb[TM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TM; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
@@ -337,9 +362,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TNArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) qf[t][j] = tr_frag(st + (2 + t) * IMG, 32 * kk, wn * 64 + 16 * j, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x8 ph = tr_frag(st, 32 * kk, wm * 64 + 16 * i, lane);
-                const bf16x8 pl = tr_frag(st + IMG, 32 * kk, wm * 64 + 16 * i, lane);
+            for (int i = 0; i < TM; ++i) {
+                const bf16x8 ph = tr_frag(st, 32 * kk, wm * (16 * TM) + 16 * i, lane);
+                const bf16x8 pl = tr_frag(st + IMG, 32 * kk, wm * (16 * TM) + 16 * i, lane);
                 if (do_bias) {
                     accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ones, accb[i], 0, 0, 0);
                     accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, ones, accb[i], 0, 0, 0);
@@ -358,10 +383,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TNArgs p) {
     const float alpha = p.s1 ? *p.s1 : 1.f;
     const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int n = n0 + wm * 64 + 16 * i + 4 * g + e;
+            const int n = n0 + wm * (16 * TM) + 16 * i + 4 * g + e;
             if (n >= p.N) continue;
             const float rdiv = p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f;
             if (do_bias && r == 0) atomicAdd(&p.dbias[n], accb[i][e] * rdiv);
@@ -406,14 +431,14 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     dim3 grid(tiles, splits);
     if (Q_lo) {
         constexpr size_t lds = 2 * 4 * 16384;  // 2 stages x (P_hi, P_lo, Q_hi, Q_lo)
-        static bool once = (allow_lds(k_gemm_tn<2, 2>, lds), true);
+        static bool once = (allow_lds(k_gemm_tn<2, 2, 4>, lds), true);
         (void)once;
-        k_gemm_tn<2, 2><<<grid, 256, lds, st>>>(a);
+        k_gemm_tn<2, 2, 4><<<grid, 512, lds, st>>>(a);
     } else {
         constexpr size_t lds = 3 * 3 * 16384;  // 3 stages x (P_hi, P_lo, Q)
-        static bool once = (allow_lds(k_gemm_tn<1, 3>, lds), true);
+        static bool once = (allow_lds(k_gemm_tn<1, 3, 4>, lds), true);
         (void)once;
-        k_gemm_tn<1, 3><<<grid, 256, lds, st>>>(a);
+        k_gemm_tn<1, 3, 4><<<grid, 512, lds, st>>>(a);
     }
     return 0;
 }

@@ -48,10 +48,12 @@ def tn(q_f32, N, Kw):
     passes = 3 if q_f32 else 2
     return t, 2.0 * M * N * Kw / t / 1e6, 2.0 * M * N * Kw * passes / t / 1e6
 
+print("cfg NT1=%s NT2=%s" % (os.environ.get("QATVIT_NT1"), os.environ.get("QATVIT_NT2")))
 print("NT shapes (us, algorithmic TF/s, issued-MFMA TF/s)")
 for name, a, N, K in [("qkv fwd", 0, 1152, 384), ("fc1 fwd", 0, 1536, 384), ("proj fwd", 1, 384, 384), ("fc2 fwd", 1, 384, 1536),
                       ("qkv dgrad", 1, 384, 1152), ("fc1 dgrad", 1, 384, 1536), ("fc2 dgrad", 1, 1536, 384)]:
     print(f"  {name:10s} a_f32={a} N={N:5d} K={K:5d}: " + "  ".join(f"{v:9.1f}" for v in nt(a, N, K)))
+if os.environ.get("SKIP_TN"): sys.exit(0)
 print("TN shapes")
 for name, q, N, Kw in [("qkv wgrad", 0, 1152, 384), ("fc1 wgrad", 0, 1536, 384), ("proj wgrad", 1, 384, 384), ("fc2 wgrad", 1, 384, 1536)]:
     print(f"  {name:10s} q_f32={q} N={N:5d} Kw={Kw:5d}: " + "  ".join(f"{v:9.1f}" for v in tn(q, N, Kw)))
