@@ -8,7 +8,7 @@ batch 256, qnnpack qconfig (per-tensor fake-quant), no teacher; synthetic 224x22
 A "step" = student forward + label-smoothed CE + backward (+ bucketed RCCL gradient all-reduce
 overlapped with backward and the rank-0 fake-quant-state broadcast when N>1); optimizer/clip are
 outside the metric.  `--backend x86 --teacher` gives config C3/C4
-(per-channel weights, [0,127] activations, KD against a frozen ViT-B teacher run by torch).
+(per-channel weights, [0,127] activations, KD against a frozen ViT-B teacher: native 3-pass split-bf16 forward).
 """
 from __future__ import annotations
 
@@ -134,6 +134,7 @@ def main():
 
     import qat_vit_amd
     from qat_vit_amd import functional as F
+    from qat_vit_amd.engine import engine_of
     from qat_vit_amd import native
 
     L = native.lib()  # fail loudly before any timing if the HIP library is missing
@@ -154,7 +155,7 @@ def main():
 
     with torch.no_grad():
         model(x)  # builds the native engine (workspace, FQ arenas)
-    eng = model.__dict__["_qatvit_engine"]
+    eng = engine_of(model)
     if world > 1:
         eng.enable_data_parallel()
 
@@ -164,7 +165,7 @@ def main():
         t_out = None
         if teacher is not None:
             with torch.no_grad():
-                t_out = teacher(x)
+                t_out = teacher(x)   # eval + no_grad + CUDA -> qatvit_teacher_forward
         out = model(x)
         loss, _ = F.kd_ce_loss(out, t_out, y, 4.0, 0.5, 0.1)
         loss.backward()
@@ -199,7 +200,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 semantics (bf16 MFMA on exact grid / hi+lo split operands, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"vit_small_patch16_224 student + QATWrapper, {args.backend} qconfig, "
-                                   f"{'vit_base teacher KD (teacher forward by torch)' if args.teacher else 'no teacher'}, "
+                                   f"{'vit_base teacher KD (native teacher forward inside the timed step)' if args.teacher else 'no teacher'}, "
                                    f"batch {args.batch}/GPU, 224x224x3 (BASELINE configs[{2 if args.teacher else 1}])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         }

@@ -167,6 +167,17 @@ int qatvit_student_forward(const qatvit_cfg* cfg, void* const* params, const qat
 int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
                             const float* dlogits, void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to,
                             void* stream);
+/* ---------------------------------------------------------------------------
+ * Frozen KD teacher forward (no fake-quant, no gradient).
+ * Replaces: `with torch.no_grad(): teacher_out = teacher(images)` (qat_trainer.py:337-338).
+ *  cfg: same struct (the quantisation fields are ignored).  params: fp32 tensors in the student's order.
+ *  w_hi / w_lo: bf16 (hi, lo) pairs of the 2-D weights, in weight_fq order without the head
+ *  (patch_embed.proj, then per block qkv, proj, fc1, fc2), prepared once by the host since the weights are frozen.
+ *  Every product is float x float: three bf16 MFMA passes (hi.hi + lo.hi + hi.lo), fp32 accumulate. */
+int64_t qatvit_teacher_workspace_bytes(const qatvit_cfg* cfg);
+int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* const* w_hi, void* const* w_lo,
+                           const float* images, float* logits, void* workspace, void* stream);
+
 /* Measurement hooks (bench.py): bracket every launch of one GEMM class inside the step with HIP events on the
  * launch stream.  kind: 1 = NT with split (hi+lo) A operand, 2 = NT with grid A operand, 3 = TN (wgrad).
  * stop() synchronises on the recorded events and returns the summed kernel time, launch count and the summed

@@ -57,7 +57,8 @@ __device__ inline int nt_off(int row, int chunk) { return row * 128 + ((chunk ^ 
 struct NTArgs {
     const __bf16* A0;     // [M,lda] hi part (or the only part)
     const __bf16* A1;     // [M,lda] lo part (TA == 2)
-    const __bf16* B;      // [N,ldb]
+    const __bf16* B;      // [N,ldb] (hi part when TB == 2)
+    const __bf16* B1;     // [N,ldb] lo part (TB == 2: float weights of the frozen teacher)
     float* C;             // fp32 [M,ldc]
     int M, N, K, lda, ldb, ldc;
     const float* s1;      // optional device scalars, alpha = (*s1) * (*s2)
@@ -68,17 +69,17 @@ struct NTArgs {
     int stat_slots;          // number of 128-B-spaced accumulator pairs (power of two; 1 = a single pair)
 };
 
-template <int TA, int NSTAGE, int WM, int TM>
+template <int TA, int NSTAGE, int WM, int TM, int TB = 1>
 __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
     // WM x 2 waves, each a (16*TM) x 64 output sub-tile: BM = 16*TM*WM rows x 128 columns per workgroup
     constexpr int WR = 16 * TM;                     // rows per wave
     constexpr int BM = WR * WM, BN = 128, BK = 64, NW = 2 * WM;
     constexpr int IMGA = BM * 128;                  // bytes of one [BM][64] bf16 image
     constexpr int IMGB = BN * 128;
-    constexpr int STAGE = TA * IMGA + IMGB;
+    constexpr int STAGE = TA * IMGA + TB * IMGB;
     constexpr int PA = (BM / 8) / NW;               // 1-KiB DMA pieces per wave per A image
     constexpr int PB = (BN / 8) / NW;
-    constexpr int NDMA = TA * PA + PB;              // LDS-DMA instructions per wave per k-tile
+    constexpr int NDMA = TA * PA + TB * PB;         // LDS-DMA instructions per wave per k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
     const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(p.A0, (int64_t)p.M * p.lda * 2);
     const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(TA == 2 ? p.A1 : p.A0, (int64_t)p.M * p.lda * 2);
     const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, (int64_t)p.N * p.ldb * 2);
+    const __amdgpu_buffer_rsrc_t rB1 = make_rsrc(TB == 2 ? p.B1 : p.B, (int64_t)p.N * p.ldb * 2);
     // this lane's place inside a 1-KiB DMA piece (8 rows x 128 B): row lr, swizzled source chunk
     const int lr = lane >> 3;
     const int src_chunk = (lane & 7) ^ lr;
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
             const int piece = wave * PB + c;
             const uint32_t offB = (uint32_t)(((int64_t)(n0 + piece * 8 + lr) * p.ldb + k0 + src_chunk * 8) * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(st + TA * IMGA + piece * 1024), 16, offB, 0, 0, 0);
+            if constexpr (TB == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, (lds_void*)(st + TA * IMGA + IMGB + piece * 1024), 16, offB, 0, 0, 0);
         }
     };
 
@@ -135,9 +138,12 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
         const char* sB = st + TA * IMGA;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 bfrag[4], afrag[TA][TM];
+            bf16x8 bfrag[4], blo[TB == 2 ? 4 : 1], afrag[TA][TM];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off(wn * 64 + 16 * j + r, 4 * kk + g));
+            for (int j = 0; j < 4; ++j) {
+                bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off(wn * 64 + 16 * j + r, 4 * kk + g));
+                if constexpr (TB == 2) blo[j] = *reinterpret_cast<const bf16x8*>(sB + IMGB + nt_off(wn * 64 + 16 * j + r, 4 * kk + g));
+            }
 #pragma unroll
             for (int t = 0; t < TA; ++t)
 #pragma unroll
@@ -148,6 +154,12 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
                 for (int t = 0; t < TA; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t][i], bfrag[j], acc[i][j], 0, 0, 0);
+            if constexpr (TB == 2) {  // third pass of a float x float product: A_hi . B_lo
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][i], blo[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
     __syncthreads();  // all fragment reads done: the ring is free for the epilogue
@@ -215,14 +227,23 @@ static void allow_lds(K kernel, size_t bytes) {
 }
 
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st) {
+                   const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
+                   const void* B_lo) {
     if (M < 1 || N % 128 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) {
         set_error("gemm_nt: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d ldc=%d (need N%%128==0, K%%64==0, lda/ldb%%8==0, ldc%%4==0)", M, N, K,
                   lda, ldb, ldc);
         return 1;
     }
-    NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B), C, M, N, K, lda, ldb,
-             ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots};
+    NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
+             reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots};
+    if (B_lo) {  // float x float (teacher): A must be split too; 128 x 128 tile, 8 waves, 2 stages x 64 KiB
+        if (!A_lo) { set_error("gemm_nt: a split B operand needs a split A operand"); return 1; }
+        constexpr size_t lds = 2 * 4 * 16384;
+        static bool once = (allow_lds(k_gemm_nt<2, 2, 4, 2, 2>, lds), true);
+        (void)once;
+        k_gemm_nt<2, 2, 4, 2, 2><<<cdiv(M, 128) * (N / 128), 512, lds, st>>>(a);
+        return 0;
+    }
     // Tile/wave configurations (tools/bench_gemm.py picks per operand class; QATVIT_NT1 / QATVIT_NT2 override for tuning):
     //   a: 128 x 128, 4 waves x (64x64)     b: 256 x 128, 8 waves x (64x64)     c: 128 x 128, 8 waves x (32x64)
     static const int cfg1 = getenv("QATVIT_NT1") ? atoi(getenv("QATVIT_NT1")) : 3;   // measured best at B=256 (profiles/round1_gemm_configs.txt)

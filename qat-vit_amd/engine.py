@@ -14,6 +14,7 @@ fake-quant state (what DDP does for the reference, torch/nn/parallel/distributed
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import List, Optional
 
 import torch
@@ -255,12 +256,21 @@ class _StudentStep(torch.autograd.Function):
         return (None, None) + (None,) * len(grads)
 
 
+# engines live outside the module (a ctypes pointer table must not be deep-copied or pickled with it)
+_ENGINES = weakref.WeakKeyDictionary()
+
+
+def engine_of(wrapper) -> Optional["StudentEngine"]:
+    """The native engine bound to a prepared wrapper (None before its first CUDA forward)."""
+    return _ENGINES.get(wrapper)
+
+
 def student_forward(wrapper, images: torch.Tensor) -> torch.Tensor:
-    eng: Optional[StudentEngine] = wrapper.__dict__.get("_qatvit_engine")
+    eng: Optional[StudentEngine] = _ENGINES.get(wrapper)
     if eng is None or eng.cfg.batch != images.shape[0]:
         pg = eng.pg if eng is not None else None
         eng = StudentEngine(wrapper, images.shape[0])
         if pg is not None:
             eng.enable_data_parallel(pg)
-        wrapper.__dict__["_qatvit_engine"] = eng
+        _ENGINES[wrapper] = eng
     return _StudentStep.apply(images, eng, *eng.params)

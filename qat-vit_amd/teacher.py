@@ -1,0 +1,83 @@
+"""Host side of the native frozen-teacher forward (``qatvit_teacher_forward``, include/qatvit.h).
+
+The reference calls ``teacher(images)`` under ``torch.no_grad()`` with every parameter frozen
+(/root/reference/src/training/qat_trainer.py:257-260,337-338).  ``VisionTransformer.forward`` routes exactly that
+situation (CUDA input, grad mode off, eval) here; the weights' (hi, lo) bf16 pairs are built once and rebuilt only
+if a weight tensor is replaced or modified in place.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+
+import torch
+
+from . import native
+
+
+class TeacherEngine:
+    def __init__(self, model: torch.nn.Module, batch: int):
+        dev = model.cls_token.device
+        self.device = dev
+        self.lib = native.lib()
+        blocks = list(model.blocks)
+        pe = model.patch_embed.proj
+        ps = [pe.weight, pe.bias, model.cls_token, model.pos_embed]
+        for b in blocks:
+            ps += [b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.qkv.bias, b.attn.proj.weight, b.attn.proj.bias,
+                   b.norm2.weight, b.norm2.bias, b.mlp.fc1.weight, b.mlp.fc1.bias, b.mlp.fc2.weight, b.mlp.fc2.bias]
+        ps += [model.norm.weight, model.norm.bias, model.head.weight, model.head.bias]
+        for p in ps:
+            if p is None or p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                raise RuntimeError("teacher parameters must be contiguous fp32 tensors on one device")
+        self.params = ps
+        self.cfg = native.Cfg(
+            batch=batch, img_size=model.patch_embed.img_size, patch_size=model.patch_embed.patch_size, in_chans=pe.weight.shape[1],
+            embed_dim=model.embed_dim, depth=len(blocks), num_heads=blocks[0].attn.num_heads, mlp_hidden=blocks[0].mlp.fc1.weight.shape[0],
+            num_classes=model.head.weight.shape[0], act_qmin=0, act_qmax=255, w_qmin=-128, w_qmax=127, w_per_channel=0,
+            averaging_const=0.01, ln_eps=float(blocks[0].norm1.eps),
+        )
+        self.weights = [pe.weight] + [w for b in blocks for w in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight)]
+        self._split_weights()
+        nbytes = self.lib.qatvit_teacher_workspace_bytes(ctypes.byref(self.cfg))
+        if nbytes <= 0:
+            raise RuntimeError("qatvit_teacher_workspace_bytes: " + self.lib.qatvit_last_error().decode())
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._ptr_params = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+        self._key = tuple(p.data_ptr() for p in ps)
+
+    @torch.no_grad()
+    def _split_weights(self):
+        self.w_hi, self.w_lo = [], []
+        for w in self.weights:
+            w2 = w.detach().reshape(w.shape[0], -1)
+            hi = w2.to(torch.bfloat16)
+            self.w_hi.append(hi.contiguous())
+            self.w_lo.append((w2 - hi.float()).to(torch.bfloat16).contiguous())
+        self._versions = tuple((w.data_ptr(), w._version) for w in self.weights)
+        self._ptr_hi = (ctypes.c_void_p * len(self.w_hi))(*[t.data_ptr() for t in self.w_hi])
+        self._ptr_lo = (ctypes.c_void_p * len(self.w_lo))(*[t.data_ptr() for t in self.w_lo])
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        c = self.cfg
+        if images.shape != (c.batch, c.in_chans, c.img_size, c.img_size) or images.dtype != torch.float32:
+            raise RuntimeError(f"expected fp32 images {(c.batch, c.in_chans, c.img_size, c.img_size)}, got {tuple(images.shape)} {images.dtype}")
+        if tuple((w.data_ptr(), w._version) for w in self.weights) != self._versions:
+            self._split_weights()  # a checkpoint was loaded into the teacher after the first call
+        images = images.contiguous()
+        logits = torch.empty(c.batch, c.num_classes, dtype=torch.float32, device=self.device)
+        native.check(self.lib.qatvit_teacher_forward(ctypes.byref(c), self._ptr_params, self._ptr_hi, self._ptr_lo, images.data_ptr(),
+                                                     logits.data_ptr(), self.workspace.data_ptr(), native.stream_ptr()), "qatvit_teacher_forward")
+        return logits
+
+
+# engines live outside the module (a ctypes pointer table must not be deep-copied or pickled with it)
+_ENGINES = weakref.WeakKeyDictionary()
+
+
+def teacher_forward(model, images):
+    eng = _ENGINES.get(model)
+    if eng is None or eng.cfg.batch != images.shape[0] or eng.device != images.device or tuple(p.data_ptr() for p in eng.params) != eng._key:
+        eng = TeacherEngine(model, images.shape[0])
+        _ENGINES[model] = eng
+    return eng.forward(images)

@@ -118,8 +118,24 @@ class VisionTransformer(nn.Module):
         return self.norm(self.blocks(x))
 
     def forward(self, x):
+        if x.is_cuda and not torch.is_grad_enabled() and not self.training and _native_teacher_ok(self):
+            # the frozen-teacher situation of the reference loop (qat_trainer.py:257-260,337-338): native forward
+            from .teacher import teacher_forward
+
+            return teacher_forward(self, x)
         x = self.forward_features(x)
         return self.head(self.head_drop(self.fc_norm(x[:, 0])))
+
+
+def _native_teacher_ok(m: "VisionTransformer") -> bool:
+    """Shapes the native teacher covers, and an un-prepared (float) tree."""
+    return (m.embed_dim % 128 == 0 and m.embed_dim <= 768 and type(m.head) is nn.Linear and type(m.patch_embed.proj) is nn.Conv2d
+            and m.blocks[0].mlp.fc1.weight.shape[0] % 128 == 0 and m.blocks[0].attn.head_dim in (32, 64) and m.patch_embed.num_patches < 224
+            and x_dtype_ok(m))
+
+
+def x_dtype_ok(m) -> bool:
+    return m.cls_token.dtype == torch.float32
 
 
 def create_vit(name: str, pretrained: bool = False, num_classes: int = 10, **kwargs) -> VisionTransformer:

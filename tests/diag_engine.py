@@ -18,6 +18,7 @@ import qat_vit_amd
 from oracle import step_ref
 from oracle.vit_ref import RefVisionTransformer, randomize_
 from qat_vit_amd import functional as F
+from qat_vit_amd.engine import engine_of
 from qat_vit_amd import native
 from tests.util import prepare
 
@@ -67,7 +68,7 @@ def run(name, backend, B, img, kw, teacher):
         loss, _ = F.kd_ce_loss(out, t, y, 4.0, 0.5, 0.1)
         loss.backward()
         torch.cuda.synchronize()
-        eng = p.__dict__["_qatvit_engine"]
+        eng = engine_of(p)
         D, T, Hd, depth = eng.cfg.embed_dim, (img // 16) ** 2 + 1, eng.cfg.mlp_hidden, eng.cfg.depth
         M = B * T
         print(f"== {name} {backend} B={B} step {step}: logits rel {rel(out, ro):.3e}  loss {loss.item():.6f} vs {rl.item():.6f}")

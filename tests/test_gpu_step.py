@@ -27,7 +27,8 @@ pytestmark = pytest.mark.gpu
 import qat_vit_amd  # noqa: E402
 from oracle import step_ref  # noqa: E402
 from oracle.vit_ref import RefVisionTransformer, randomize_  # noqa: E402
-from qat_vit_amd import functional as F  # noqa: E402
+from qat_vit_amd import functional as F
+from qat_vit_amd.engine import engine_of  # noqa: E402
 from tests.util import capture_fq_io, cosine, fq_modules, prepare, rel_l2, ws_tensor  # noqa: E402
 
 TOL = 1e-3
@@ -70,7 +71,7 @@ def _tiny_case(golden_dir, backend):
     ro, rl, _, _ = step_ref.student_step(po, x, y, t)
     assert rel_l2(ro.numpy(), z["s0/logits"]) < 0.05               # live oracle vs fixture: another host CPU, flips possible
     out, parts = _step(p, x.cuda(), y.cuda(), t.cuda())
-    eng = p.__dict__["_qatvit_engine"]
+    eng = engine_of(p)
     B, T, D = 4, 5, 128
     M = B * T
     # weight fake-quant state is input-independent: exact parity class
@@ -126,7 +127,7 @@ def _full_size_case(backend, seed, teacher, fixture=None, golden_dir=None):
     ro, rloss, _, _ = step_ref.student_step(po, x, y, t)
     go, gloss, _, _ = step_ref.student_step(pg, x.cuda(), y.cuda(), None if t is None else t.cuda())
     out, parts = _step(p, x.cuda(), y.cuda(), None if t is None else t.cuda())
-    eng = p.__dict__["_qatvit_engine"]
+    eng = engine_of(p)
     if z is not None and ast.literal_eval(str(z["meta"]))["torch"] == torch.__version__:
         # The fixture was produced by the same torch build on ANOTHER host CPU (different core count / BLAS
         # blocking => different fp32 summation order): even CPU-vs-CPU the logits sit on the noise floor
@@ -230,7 +231,7 @@ def test_engine_data_parallel_path_single_rank(native_lib):
     try:
         with torch.no_grad():
             p2(x)
-        eng = p2.__dict__["_qatvit_engine"]
+        eng = engine_of(p2)
         eng.enable_data_parallel(bucket_bytes=64 << 10)
         with torch.no_grad():
             p1(x)
@@ -241,3 +242,33 @@ def test_engine_data_parallel_path_single_rank(native_lib):
             assert rel_l2(b.grad.cpu(), a.grad.cpu()) < 1e-6, n   # atomics order differs run to run
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("arch,B", [("vit_base_patch16_224_teacher", 4), ("vit_small_patch16_224_student", 3)])
+def test_native_teacher_forward_vs_fp64(native_lib, arch, B):
+    """Frozen-teacher forward (no fake-quant => no discontinuities): native 3-pass split-bf16 path vs the same tree in fp64
+    torch on the GPU.  2^-16 per product, fp32 accumulate, 12 blocks deep: 2e-4 relative L2 asserted (observed ~1e-5)."""
+    torch.manual_seed(0)
+    m = qat_vit_amd.create_model(arch, pretrained=False, num_classes=10).cuda().eval()
+    with torch.no_grad():
+        for p in m.parameters():          # timm init leaves biases at zero and the cls token at 1e-6: make the test vector non-degenerate
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+        m.cls_token.normal_(std=0.02)
+    x = torch.randn(B, 3, 224, 224, device="cuda")
+    with torch.no_grad():
+        out = m(x)                                    # native (eval + no_grad + CUDA)
+    from qat_vit_amd.teacher import _ENGINES as T_ENGINES
+
+    assert m in T_ENGINES
+    m64 = copy.deepcopy(m).double()
+    with torch.no_grad():
+        ref = m64.head(m64.forward_features(x.double())[:, 0])
+    assert rel_l2(out.cpu(), ref.cpu()) < 2e-4
+    # a weight update invalidates the cached (hi, lo) pairs
+    with torch.no_grad():
+        m.blocks[0].mlp.fc1.weight.mul_(1.5)
+        out2 = m(x)
+        m64.blocks[0].mlp.fc1.weight.mul_(1.5)
+        ref2 = m64.head(m64.forward_features(x.double())[:, 0])
+    assert rel_l2(out2.cpu(), ref2.cpu()) < 2e-4
