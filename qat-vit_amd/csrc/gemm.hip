@@ -69,11 +69,11 @@ struct NTArgs {
     int stat_slots;          // number of 128-B-spaced accumulator pairs (power of two; 1 = a single pair)
 };
 
-template <int TA, int NSTAGE, int WM, int TM, int TB = 1>
-__global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
-    // WM x 2 waves, each a (16*TM) x 64 output sub-tile: BM = 16*TM*WM rows x 128 columns per workgroup
-    constexpr int WR = 16 * TM;                     // rows per wave
-    constexpr int BM = WR * WM, BN = 128, BK = 64, NW = 2 * WM;
+template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4>  // ABL: timing-only ablation (1 = no LDS reads / MFMA)
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
+    // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
+    constexpr int WR = 16 * TM, WC = 16 * TNT;      // rows / columns per wave
+    constexpr int BM = WR * WM, BN = WC * WN, BK = 64, NW = WN * WM;
     constexpr int IMGA = BM * 128;                  // bytes of one [BM][64] bf16 image
     constexpr int IMGB = BN * 128;
     constexpr int STAGE = TA * IMGA + TB * IMGB;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;   // wm in [0, WM)
+    const int wm = wave / WN, wn = wave % WN;
     const int tilesN = p.N / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
@@ -116,11 +116,11 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
         }
     };
 
-    f32x4 acc[TM][4];
+    f32x4 acc[TM][TNT];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
 #pragma unroll
@@ -136,13 +136,14 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
         if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
         const char* st = smem + (kt % NSTAGE) * STAGE;
         const char* sB = st + TA * IMGA;
+        if constexpr (ABL == 1) continue;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 bfrag[4], blo[TB == 2 ? 4 : 1], afrag[TA][TM];
+            bf16x8 bfrag[TNT], blo[TB == 2 ? TNT : 1], afrag[TA][TM];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off(wn * 64 + 16 * j + r, 4 * kk + g));
-                if constexpr (TB == 2) blo[j] = *reinterpret_cast<const bf16x8*>(sB + IMGB + nt_off(wn * 64 + 16 * j + r, 4 * kk + g));
+            for (int j = 0; j < TNT; ++j) {
+                bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off(wn * WC + 16 * j + r, 4 * kk + g));
+                if constexpr (TB == 2) blo[j] = *reinterpret_cast<const bf16x8*>(sB + IMGB + nt_off(wn * WC + 16 * j + r, 4 * kk + g));
             }
 #pragma unroll
             for (int t = 0; t < TA; ++t)
@@ -153,12 +154,12 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
 #pragma unroll
                 for (int t = 0; t < TA; ++t)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t][i], bfrag[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t][i], bfrag[j], acc[i][j], 0, 0, 0);
             if constexpr (TB == 2) {  // third pass of a float x float product: A_hi . B_lo
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][i], blo[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][i], blo[j], acc[i][j], 0, 0, 0);
             }
         }
     }
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
         if ((wm * WR) / 64 == h) {
             const int rbase = wm * WR - 64 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int cl = wn * 64 + 16 * j + r;
+            for (int j = 0; j < TNT; ++j) {
+                const int cl = wn * WC + 16 * j + r;
                 const float a = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
                 const float b = p.bias ? p.bias[n0 + cl] : 0.f;
 #pragma unroll
@@ -196,10 +197,9 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_nt(const NTArgs p) {
             }
         }
         __syncthreads();
-        const int c4 = tid & 31, r0 = tid >> 5;
-#pragma unroll
-        for (int it = 0; it < 64 / (NW * 2); ++it) {
-            const int rl = r0 + (NW * 2) * it;
+        constexpr int C4 = BN / 4;              // float4 per staged row
+        for (int idx = tid; idx < 64 * C4; idx += NW * 64) {
+            const int rl = idx / C4, c4 = idx % C4;
             const int row = m0 + 64 * h + rl;
             if (row < p.M)
                 *reinterpret_cast<float4*>(p.C + (int64_t)row * p.ldc + n0 + 4 * c4) = *reinterpret_cast<const float4*>(sC + rl * LDC + 4 * c4);
@@ -256,6 +256,33 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         (void)once;                                                                                 \
         k_gemm_nt<TA_, NS_, WM_, TM_><<<cdiv(M, bm) * (N / 128), WM_ * 128, lds, st>>>(a);          \
     } while (0)
+    // N-panel-wide tiles: 128 x 384, 2 x 4 waves each 64 x 96.  Every N of ViT-S/B (384, 1152, 1536, 768, 2304, 3072) is a
+    // multiple of 384, so for N = 384 the A operand is streamed into LDS exactly once (the kernels are bound by the
+    // fabric -> LDS-DMA rate, ~7 TB/s chip-wide, not by MFMA: profiles/round1_gemm_ablation.txt).
+    static const int wide = getenv("QATVIT_NT_WIDE") ? atoi(getenv("QATVIT_NT_WIDE")) : 1;
+    if (((wide == 1 && A_lo) || wide == 2) && N % 384 == 0) {   // grid-A GEMMs (K = 384, store-bound) measured equal or better on 128^2 tiles
+        const int nwg = cdiv(M, 128) * (N / 384);
+        if (A_lo) {
+            constexpr size_t lds = 2 * (2 * 16384 + 49152);   // 2 stages x (A_hi, A_lo [128x64], B [384x64]) = 160 KiB
+            static bool once = (allow_lds(k_gemm_nt<2, 2, 2, 4, 1, 0, 4, 6>, lds), true);
+            (void)once;
+            k_gemm_nt<2, 2, 2, 4, 1, 0, 4, 6><<<nwg, 512, lds, st>>>(a);
+        } else {
+            constexpr size_t lds = 2 * (16384 + 49152);       // 2 stages x (A, B) = 128 KiB
+            static bool once = (allow_lds(k_gemm_nt<1, 2, 2, 4, 1, 0, 4, 6>, lds), true);
+            (void)once;
+            k_gemm_nt<1, 2, 2, 4, 1, 0, 4, 6><<<nwg, 512, lds, st>>>(a);
+        }
+        return 0;
+    }
+    static const int abl = getenv("QATVIT_NT_ABL") ? atoi(getenv("QATVIT_NT_ABL")) : 0;
+    if (abl == 1 && A_lo) {  // timing-only: DMA ring + barriers + epilogue, no math (tools/bench_gemm.py)
+        constexpr size_t lds = 3 * (2 * 16384 + 16384);
+        static bool once = (allow_lds(k_gemm_nt<2, 3, 4, 2, 1, 1>, lds), true);
+        (void)once;
+        k_gemm_nt<2, 3, 4, 2, 1, 1><<<cdiv(M, 128) * (N / 128), 512, lds, st>>>(a);
+        return 0;
+    }
     if (A_lo) {
         if (cfg2 == 1) QV_NT_LAUNCH(2, 3, 2, 4);        // a, 3 stages (144 KiB)
         else if (cfg2 == 2) QV_NT_LAUNCH(2, 3, 4, 2);   // c, 3 stages (144 KiB)
@@ -293,33 +320,39 @@ struct TNArgs {
     const float* row_div; // optional [N]: results (and dbias) are divided by row_div[n] (P was pre-multiplied by the per-channel weight scale)
 };
 
+template <int ROWB>  // ROWB: bytes per LDS row of the image (256 for a 128-column tile, 768 for a 384-column tile)
 __device__ inline bf16x8 tr_frag(const char* img, int row0, int col0, int lane) {
     // 16x16x32 operand fragment whose k index runs over LDS rows row0 + 8g + (0..7) and whose
     // row/col index is LDS column col0 + (lane & 15): two transposed 4x16 block reads.
+    // (the XOR swizzle only touches the low 4 bits of the chunk index, so it stays inside a 256-B group of any row length)
     const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
     const int row = row0 + 8 * g + q;
     const int chunk = (col0 >> 3) + (pp >> 1);
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tn_off(row, chunk) + (pp & 1) * 8));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tn_off(row + 4, chunk) + (pp & 1) * 8));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + row * ROWB + ((chunk ^ tn_sw(row)) << 4) + (pp & 1) * 8));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (row + 4) * ROWB + ((chunk ^ tn_sw(row + 4)) << 4) + (pp & 1) * 8));
     // whole-vector bit cast: per-element short->__bf16 inserts are miscompiled by hipcc 7.2 (every element becomes lo[0])
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TQ, int NSTAGE, int WM>
-__global__ __launch_bounds__(WM * 128) void k_gemm_tn(const TNArgs p) {
-    // WM x 2 waves over a 128 (N) x 128 (Kw) output tile: each wave (128/WM) x 64
-    constexpr int BN = 128, BKW = 128, BK = 64, NW = 2 * WM;
+// Output tile 128 (N) x BKW (Kw), WM x WNK waves each (16*TM) x (16*TNT); BK token rows per step.
+template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK>
+__global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
+    constexpr int BN = 128, NW = WM * WNK;
     constexpr int TM = BN / WM / 16;                // 16-row fragments of P per wave
-    constexpr int IMG = BK * 256;                   // bytes of one [64][128] bf16 image
-    constexpr int STAGE = (2 + TQ) * IMG;
-    constexpr int PP = 16 / NW;                     // 1-KiB DMA pieces per wave per image
-    constexpr int NDMA = (2 + TQ) * PP;
+    constexpr int BKW = WNK * TNT * 16;             // Kw columns per workgroup (128 or 384)
+    constexpr int PROWB = 256, QROWB = BKW * 2;     // LDS row bytes
+    constexpr int IMGP = BK * PROWB, IMGQ = BK * QROWB;
+    constexpr int STAGE = 2 * IMGP + TQ * IMGQ;
+    constexpr int PP = (IMGP / 1024) / NW, PQ = (IMGQ / 1024) / NW;   // 1-KiB DMA pieces per wave per image
+    static_assert((IMGP / 1024) % NW == 0 && (IMGQ / 1024) % NW == 0, "pieces must divide evenly over the waves");
+    constexpr int NDMA = 2 * PP + TQ * PQ;
+    constexpr int QCH = QROWB / 16;                 // 16-B chunks per Q row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNK, wn = wave % WNK;
     const int tilesK = p.Kw / BKW;
     const int n0 = (blockIdx.x / tilesK) * BN, k0 = (blockIdx.x % tilesK) * BKW;
     const int total_steps = (p.M + BK - 1) / BK;
@@ -331,31 +364,36 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_tn(const TNArgs p) {
     const __amdgpu_buffer_rsrc_t rP1 = make_rsrc(p.P1, (int64_t)p.M * p.ldp * 2);
     const __amdgpu_buffer_rsrc_t rQ0 = make_rsrc(p.Q0, (int64_t)p.M * p.ldq * 2);
     const __amdgpu_buffer_rsrc_t rQ1 = make_rsrc(TQ == 2 ? p.Q1 : p.Q0, (int64_t)p.M * p.ldq * 2);
-    // this lane's place inside a 1-KiB DMA piece (4 rows x 256 B)
-    const int lr = lane >> 4;
 
     auto issue = [&](int s) {
         char* st = smem + (s % NSTAGE) * STAGE;
         const int mrow0 = (s_begin + s) * BK;
 #pragma unroll
         for (int c = 0; c < PP; ++c) {
-            const int piece = wave * PP + c;                   // 16 pieces per image
-            const int row = piece * 4 + lr;                    // 0..63
+            const int piece = wave * PP + c;
+            const int row = piece * 4 + (lane >> 4);           // 4 rows of 256 B per piece
             const int src_chunk = (lane & 15) ^ tn_sw(row);
             const uint32_t offP = (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + src_chunk * 8) * 2);
-            const uint32_t offQ = (uint32_t)(((int64_t)(mrow0 + row) * p.ldq + k0 + src_chunk * 8) * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rP0, (lds_void*)(st + piece * 1024), 16, offP, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rP1, (lds_void*)(st + IMG + piece * 1024), 16, offP, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ0, (lds_void*)(st + 2 * IMG + piece * 1024), 16, offQ, 0, 0, 0);
-            if constexpr (TQ == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ1, (lds_void*)(st + 3 * IMG + piece * 1024), 16, offQ, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rP1, (lds_void*)(st + IMGP + piece * 1024), 16, offP, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < PQ; ++c) {
+            const int piece = wave * PQ + c;
+            const int L = piece * 64 + lane;                   // linear 16-B chunk index inside the image
+            const int row = L / QCH, cp = L % QCH;
+            const int src_chunk = cp ^ tn_sw(row);
+            const uint32_t offQ = (uint32_t)(((int64_t)(mrow0 + row) * p.ldq + k0 + src_chunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ0, (lds_void*)(st + 2 * IMGP + piece * 1024), 16, offQ, 0, 0, 0);
+            if constexpr (TQ == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ1, (lds_void*)(st + 2 * IMGP + IMGQ + piece * 1024), 16, offQ, 0, 0, 0);
         }
     };
 
-    f32x4 acc[TM][4];
+    f32x4 acc[TM][TNT];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.dbias != nullptr && (blockIdx.x % tilesK) == 0 && wn == 0;  // wave-uniform
     f32x4 accb[TM];
 #pragma unroll
@@ -376,22 +414,22 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_tn(const TNArgs p) {
         if (s + NSTAGE - 1 < nsteps) issue(s + NSTAGE - 1);
         const char* st = smem + (s % NSTAGE) * STAGE;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 qf[TQ][4];
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 qf[TQ][TNT];
 #pragma unroll
             for (int t = 0; t < TQ; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) qf[t][j] = tr_frag(st + (2 + t) * IMG, 32 * kk, wn * 64 + 16 * j, lane);
+                for (int j = 0; j < TNT; ++j) qf[t][j] = tr_frag<QROWB>(st + 2 * IMGP + t * IMGQ, 32 * kk, wn * (16 * TNT) + 16 * j, lane);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const bf16x8 ph = tr_frag(st, 32 * kk, wm * (16 * TM) + 16 * i, lane);
-                const bf16x8 pl = tr_frag(st + IMG, 32 * kk, wm * (16 * TM) + 16 * i, lane);
+                const bf16x8 ph = tr_frag<PROWB>(st, 32 * kk, wm * (16 * TM) + 16 * i, lane);
+                const bf16x8 pl = tr_frag<PROWB>(st + IMGP, 32 * kk, wm * (16 * TM) + 16 * i, lane);
                 if (do_bias) {
                     accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ones, accb[i], 0, 0, 0);
                     accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, ones, accb[i], 0, 0, 0);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < TNT; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[0][j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, qf[0][j], acc[i][j], 0, 0, 0);
                     if constexpr (TQ == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[1][j], acc[i][j], 0, 0, 0);
@@ -418,8 +456,8 @@ __global__ __launch_bounds__(WM * 128) void k_gemm_tn(const TNArgs p) {
                 fzp = (float)p.w_zp[ci];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kw = k0 + wn * 64 + 16 * j + r;
+            for (int j = 0; j < TNT; ++j) {
+                const int kw = k0 + wn * (16 * TNT) + 16 * j + r;
                 float v = acc[i][j][e] * (alpha * rdiv);
                 if (p.W) {
                     const float q = rintf(p.W[(int64_t)n * p.ldc + kw] * inv) + fzp;
@@ -440,27 +478,39 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     }
     TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), reinterpret_cast<const __bf16*>(Q_hi),
              reinterpret_cast<const __bf16*>(Q_lo), C, M, N, Kw, ldp, ldq, ldc, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div};
-    const int steps = (M + 63) / 64;
-    const int tiles = (N / 128) * (Kw / 128);
-    // One workgroup per CU is resident (96-144 KiB of LDS): split the token reduction so that the grid is as close
-    // to (but not above) a whole number of 256-CU rounds as possible - 513 workgroups would cost a third round.
+    // Kw-panel-wide tiles (128 x 384) read the heavy operand P = dY (hi, lo) once per N tile when Kw = 384; every Kw of
+    // ViT-S/B (384, 1536, 768, 3072) is a multiple of 384.  QATVIT_TN_WIDE=0 forces the 128 x 128 tile (tuning).
+    static const int wide_env = getenv("QATVIT_TN_WIDE") ? atoi(getenv("QATVIT_TN_WIDE")) : 1;
+    // (measured at B=256: wide wins for a grid Q operand, 161/191 us vs 169/225; with a split Q the 32-row steps it
+    //  then needs lose, 131 vs 91 us - so only wide_env == 2 forces it there)
+    const bool wide = (wide_env == 2 || (wide_env == 1 && !Q_lo)) && (Kw % 384 == 0);
+    const int bk = (wide && Q_lo) ? 32 : 64;        // the split-Q wide stage only fits with 32-row steps
+    const int steps = (M + bk - 1) / bk;
+    const int tiles = (N / 128) * (Kw / (wide ? 384 : 128));
+    // One workgroup per CU is resident: split the token reduction so that the grid is as close to (but not above) a whole
+    // number of 256-CU rounds as possible - 513 workgroups would cost a third round.
     int splits = 512 / tiles;
-    if (splits > steps / 4) splits = steps / 4 > 0 ? steps / 4 : 1;
+    const int min_steps = 256 / bk;                 // >= 256 token rows per split
+    if (splits > steps / min_steps) splits = steps / min_steps > 0 ? steps / min_steps : 1;
     if (splits < 1) splits = 1;
     a.steps_per_split = (steps + splits - 1) / splits;
     splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
     dim3 grid(tiles, splits);
-    if (Q_lo) {
-        constexpr size_t lds = 2 * 4 * 16384;  // 2 stages x (P_hi, P_lo, Q_hi, Q_lo)
-        static bool once = (allow_lds(k_gemm_tn<2, 2, 4>, lds), true);
-        (void)once;
-        k_gemm_tn<2, 2, 4><<<grid, 512, lds, st>>>(a);
+#define QV_TN_LAUNCH(TQ_, NS_, WM_, WNK_, TNT_, BK_)                                                               \
+    do {                                                                                                           \
+        constexpr size_t lds = (size_t)NS_ * (2 * BK_ * 256 + TQ_ * BK_ * (WNK_ * TNT_ * 32));                      \
+        static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_>, lds), true);                      \
+        (void)once;                                                                                                \
+        k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);                          \
+    } while (0)
+    if (wide) {
+        if (Q_lo) QV_TN_LAUNCH(2, 2, 2, 4, 6, 32);   // 2 x (16 + 48) KiB = 128 KiB
+        else QV_TN_LAUNCH(1, 2, 2, 4, 6, 64);        // 2 x (32 + 48) KiB = 160 KiB
     } else {
-        constexpr size_t lds = 3 * 3 * 16384;  // 3 stages x (P_hi, P_lo, Q)
-        static bool once = (allow_lds(k_gemm_tn<1, 3, 4>, lds), true);
-        (void)once;
-        k_gemm_tn<1, 3, 4><<<grid, 512, lds, st>>>(a);
+        if (Q_lo) QV_TN_LAUNCH(2, 2, 4, 2, 4, 64);   // 2 x 64 KiB
+        else QV_TN_LAUNCH(1, 3, 4, 2, 4, 64);        // 3 x 48 KiB
     }
+#undef QV_TN_LAUNCH
     return 0;
 }
 
