@@ -218,14 +218,12 @@ template <int HD, int NKT>
 __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
     constexpr int IMG = NKT * 16 * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;             // row image (A operand of S^T)
-    char* sKt = smem + IMG;      // tr image (B operand of dQ)
-    char* sV = smem + 2 * IMG;   // row image (A operand of dP^T)
+    char* sKt = smem;            // [token][d] image of K: transposed reads (B operand of dQ) AND plain row reads (A operand of S^T)
+    char* sV = smem + IMG;       // row image (A operand of dP^T)
     const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
     const float* base = p.qkv + (int64_t)b * T * ld + h * HD;
-    stage_tokens<HD, false, NKT>(sK, base + D, T, ld, q);
     stage_tokens<HD, true, NKT>(sKt, base + D, T, ld, q);
     stage_tokens<HD, false, NKT>(sV, base + 2 * D, T, ld, q);
     __syncthreads();
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < HD / 32; ++kk) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + row_off<HD>(16 * j + r, 4 * kk + g));
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sKt + tr_off<HD>(16 * j + r, 4 * kk + g));
                     const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + row_off<HD>(16 * j + r, 4 * kk + g));
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dh[kk], dp, 0, 0, 0);
@@ -359,11 +357,13 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dkv(const AttnArgs p) {
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int qt = 2 * qs + v;
-            const int qrow = min(16 * qt + r, T - 1);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                qa[v][kk] = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
-                load_split8(dObase + (int64_t)qrow * D + 32 * kk + 8 * g, da[v][kk], db[v][kk]);
+                // row fragments straight from the [token][d] images staged for the transposed reads: a plain 16-B read at
+                // (token row, chunk) is conflict-free under the same XOR swizzle, and rows >= T are zero
+                qa[v][kk] = *reinterpret_cast<const bf16x8*>(sQt + tr_off<HD>(16 * qt + r, 4 * kk + g));
+                da[v][kk] = *reinterpret_cast<const bf16x8*>(sDh + tr_off<HD>(16 * qt + r, 4 * kk + g));
+                db[v][kk] = *reinterpret_cast<const bf16x8*>(sDl + tr_off<HD>(16 * qt + r, 4 * kk + g));
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -462,11 +462,11 @@ static void launch3(int which, const AttnArgs& a, hipStream_t st) {
     const size_t img = (size_t)NKT * 16 * HD * 2;
     const int grid = a.B * a.H;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img)),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img)),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)), true);
     (void)once;
     if (which == 0) k_attn_fwd<HD, NKT><<<grid, kAW * 64, 2 * img, st>>>(a);
-    else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, kAW * 64, 3 * img, st>>>(a);
+    else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, kAW * 64, 2 * img, st>>>(a);
     else k_attn_bwd_dkv<HD, NKT><<<grid, kAW * 64, 3 * img, st>>>(a);
 }
 

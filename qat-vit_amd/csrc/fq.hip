@@ -138,27 +138,40 @@ __device__ inline float ema(float running, float cur, float c) {
 __global__ void k_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point,
                           const int64_t* observer_on, const int64_t* fake_quant_on, float c, int qmin, int qmax,
                           int64_t channels, int symmetric, float* qp_out, int reset_ws, int nslots) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= channels) return;
-    float mn = running_min[i], mx = running_max[i];
-    uint32_t omn = ws[2 * i], omx = ws[2 * i + 1];
-    if (nslots > 1) {  // per-tensor accumulator spread over nslots pairs (channels == 1)
-        for (int s = 1; s < nslots; ++s) {
-            omn = min(omn, ws[s * kStatStride]);
-            omx = max(omx, ws[s * kStatStride + 1]);
+    // Per-tensor (nslots > 1, channels == 1): launched with one 64-lane wave; lane s folds accumulator pair s (one parallel
+    // round of loads instead of a dependent chain - this kernel sits on the critical path between a producer and its consumer).
+    // Per-channel: one thread per channel, a single pair each.
+    const int64_t i = nslots > 1 ? 0 : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    uint32_t omn, omx;
+    if (nslots > 1) {
+        const int l = threadIdx.x;
+        omn = l < nslots ? ws[l * kStatStride] : kOrdPosInf;
+        omx = l < nslots ? ws[l * kStatStride + 1] : kOrdNegInf;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            omn = min(omn, (uint32_t)__shfl_xor((int)omn, o, 64));
+            omx = max(omx, (uint32_t)__shfl_xor((int)omx, o, 64));
+        }
+        if (reset_ws && l < nslots) {  // re-arm the accumulators for the next step
+            ws[l * kStatStride] = kOrdPosInf;
+            ws[l * kStatStride + 1] = kOrdNegInf;
+        }
+        if (l != 0) return;
+    } else {
+        if (i >= channels) return;
+        omn = ws[2 * i];
+        omx = ws[2 * i + 1];
+        if (reset_ws) {
+            ws[2 * i] = kOrdPosInf;
+            ws[2 * i + 1] = kOrdNegInf;
         }
     }
+    float mn = running_min[i], mx = running_max[i];
     if (*observer_on != 0) {
         mn = ema(mn, ord2f(omn), c);
         mx = ema(mx, ord2f(omx), c);
         running_min[i] = mn;
         running_max[i] = mx;
-    }
-    if (reset_ws) {  // the slots are atomic min/max accumulators: re-arm them for the next step
-        for (int s = 0; s < (nslots > 1 ? nslots : 1); ++s) {
-            ws[(nslots > 1 ? s * kStatStride : 2 * i)] = kOrdPosInf;
-            ws[(nslots > 1 ? s * kStatStride : 2 * i) + 1] = kOrdNegInf;
-        }
     }
     float s = scale[i];
     int32_t z = zero_point[i];

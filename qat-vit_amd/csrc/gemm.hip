@@ -487,9 +487,10 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     const int bk = (wide && Q_lo) ? 32 : 64;        // the split-Q wide stage only fits with 32-row steps
     const int steps = (M + bk - 1) / bk;
     const int tiles = (N / 128) * (Kw / (wide ? 384 : 128));
-    // One workgroup per CU is resident: split the token reduction so that the grid is as close to (but not above) a whole
-    // number of 256-CU rounds as possible - 513 workgroups would cost a third round.
-    int splits = 512 / tiles;
+    // Split the token reduction over blockIdx.y so that the grid fills the 256 CUs once.
+    // (the 128-160 KiB stage ring admits ONE workgroup per CU, so one round of <= 256 long-running workgroups beats two rounds
+    //  of short ones: same MFMA time, half the prologues and half the fp32 atomics of the epilogue, which run at ~1.3 TB/s chip-wide)
+    int splits = 256 / tiles;
     const int min_steps = 256 / bk;                 // >= 256 token rows per split
     if (splits > steps / min_steps) splits = steps / min_steps > 0 ? steps / min_steps : 1;
     if (splits < 1) splits = 1;
