@@ -173,10 +173,8 @@ __global__ __launch_bounds__(256) void k_ln_apply_quant(const float* __restrict_
 }
 
 // ---------------------------------------------------------------- GELU(fq(Y)) forward / backward
-__device__ inline float gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ inline float dgelu(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-}
+__device__ inline float gelu(float x) { return gelu_fwd(x); }
+__device__ inline float dgelu(float x) { return gelu_bwd(x); }
 
 __global__ __launch_bounds__(256) void k_fq_gelu(const float* __restrict__ Y, const float* __restrict__ qp, int qmin, int qmax,
                                                  __bf16* __restrict__ G_hi, __bf16* __restrict__ G_lo, int64_t n4) {

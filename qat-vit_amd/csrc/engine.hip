@@ -201,12 +201,12 @@ struct Ctx {
     // the per-channel weight scale of layer wi, which its dY producer folds in (nullptr for per-tensor)
     const float* dy_colscale(int wi) const { return c.w_per_channel ? wfq[wi].scale : nullptr; }
     // dgrad: dX[M,K] = dY[M,N] . W_fq[N,K]   (per-channel: dY already carries s_w[n])
-    int linear_dgrad(const void* dY_hi, const void* dY_lo, int M, int wi, float* dX) const {
+    int linear_dgrad(const void* dY_hi, const void* dY_lo, int M, int wi, float* dX, const NTPost* post = nullptr) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
         ProfScope ps(1, 2.0 * M * N * K, st);
         return launch_gemm_nt(dY_hi, dY_lo, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr,
-                              nullptr, nullptr, 1, st);
+                              nullptr, nullptr, 1, st, nullptr, post);
     }
     // wgrad: dW[N,K] += sum_m dY[m,N] X[m,K] * s_x, masked by the weight FQ; db[N] += sum_m dY
     int linear_wgrad(const void* dY_hi, const void* dY_lo, int M, int wi, const void* X_hi, const void* X_lo, const float* s_x, float* dW, float* db,
@@ -334,9 +334,11 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             // ---- MLP branch
             launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
             if (x.linear_wgrad(dYh, dYl, M, w_fc2, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
-            if (x.linear_dgrad(dYh, dYl, M, w_fc2, x.at<float>(p.dG))) return 1;
-            launch_mask_bwd(1, x.at<float>(p.dG), x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), d.Hd,
-                            x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), d.M * d.Hd, st);
+            {   // fc2 dgrad with the GELU backward + fc1's STE mask fused into its epilogue: dY1 = (dYs . W_fc2) * gelu'(fq(Y1)) * mask(Y1)
+                const NTPost post{x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), x.at<void>(p.dY1_hi),
+                                  x.at<void>(p.dY1_lo)};
+                if (x.linear_dgrad(dYh, dYl, M, w_fc2, nullptr, &post)) return 1;
+            }
             if (x.linear_wgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.blk<void>(p.h2q, i), nullptr, x.act_qp(x.aidx(i, AB_N2)),
                                BG(i, B_FC1W), BG(i, B_FC1B)))
                 return 1;

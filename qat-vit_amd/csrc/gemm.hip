@@ -67,6 +67,14 @@ struct NTArgs {
     const float* bias;       // optional [N]
     uint32_t* stats;         // optional {ordered-min, ordered-max} accumulator of the stored values
     int stat_slots;          // number of 128-B-spaced accumulator pairs (power of two; 1 = a single pair)
+    // Optional fused consumer (fc2 dgrad -> GELU backward): instead of storing C, store the (hi, lo) bf16 pair of
+    //   C * gelu'(fq(Y)) * mask(Y) * post_colscale[col],  Y = the pre-FQ fc1 output [M,ldc], post_qp = {scale, 1/scale, zp, enabled}
+    const float* postY;
+    const float* post_qp;
+    int post_qmin, post_qmax;
+    const float* post_colscale;
+    __bf16* out_hi;
+    __bf16* out_lo;
 };
 
 template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4>  // ABL: timing-only ablation (1 = no LDS reads / MFMA)
@@ -201,8 +209,33 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
         for (int idx = tid; idx < 64 * C4; idx += NW * 64) {
             const int rl = idx / C4, c4 = idx % C4;
             const int row = m0 + 64 * h + rl;
-            if (row < p.M)
-                *reinterpret_cast<float4*>(p.C + (int64_t)row * p.ldc + n0 + 4 * c4) = *reinterpret_cast<const float4*>(sC + rl * LDC + 4 * c4);
+            if (row < p.M) {
+                const float4 v = *reinterpret_cast<const float4*>(sC + rl * LDC + 4 * c4);
+                const int64_t off = (int64_t)row * p.ldc + n0 + 4 * c4;
+                if (p.postY) {
+                    const float4 y = *reinterpret_cast<const float4*>(p.postY + off);
+                    const float qs = p.post_qp[0], qinv = p.post_qp[1], qzp = p.post_qp[2], qon = p.post_qp[3];
+                    const float fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
+                    float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + 4 * c4);
+                    const float yv[4] = {y.x, y.y, y.z, y.w}, cv[4] = {v.x, v.y, v.z, v.w}, sv[4] = {cs.x, cs.y, cs.z, cs.w};
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = rintf(yv[e] * qinv) + qzp;
+                        const bool in = (t >= fmin_ && t <= fmax_) || qon == 0.f;
+                        const float f = qon != 0.f ? (fminf(fmaxf(t, fmin_), fmax_) - qzp) * qs : yv[e];
+                        const float o = in ? cv[e] * gelu_bwd(f) * sv[e] : 0.f;
+                        oh[e] = (__bf16)o;
+                        ol[e] = (__bf16)(o - (float)oh[e]);
+                    }
+                    *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
+                    *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
+                } else {
+                    *reinterpret_cast<float4*>(p.C + off) = v;
+                }
+            }
         }
     }
     if (p.stats) {
@@ -228,14 +261,23 @@ static void allow_lds(K kernel, size_t bytes) {
 
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                   const void* B_lo) {
+                   const void* B_lo, const NTPost* post) {
     if (M < 1 || N % 128 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) {
         set_error("gemm_nt: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d ldc=%d (need N%%128==0, K%%64==0, lda/ldb%%8==0, ldc%%4==0)", M, N, K,
                   lda, ldb, ldc);
         return 1;
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
-             reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots};
+             reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
+             nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+    if (post) {
+        a.postY = post->Y; a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.post_colscale = post->colscale;
+        a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
+        if (!a.postY || !a.post_qp || !a.out_hi || !a.out_lo) { set_error("gemm_nt: incomplete fused GELU-backward epilogue arguments"); return 1; }
+    } else if (!C) {
+        set_error("gemm_nt: null output");
+        return 1;
+    }
     if (B_lo) {  // float x float (teacher): A must be split too; 128 x 128 tile, 8 waves, 2 stages x 64 KiB
         if (!A_lo) { set_error("gemm_nt: a split B operand needs a split A operand"); return 1; }
         constexpr size_t lds = 2 * 4 * 16384;

@@ -78,4 +78,10 @@ __device__ inline float fq_one(float x, float inv_scale, float scale, float fzp,
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// exact-erf GELU (nn.GELU() default) and its derivative
+__device__ inline float gelu_fwd(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ inline float gelu_bwd(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
 }  // namespace qv

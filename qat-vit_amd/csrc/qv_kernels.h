@@ -25,10 +25,20 @@ int launch_qparams(uint32_t* ws, float* running_min, float* running_max, float* 
                    const int64_t* fake_quant_on, float c, int qmin, int qmax, int64_t channels, int symmetric, float* qp_out, int reset_ws,
                    int nslots, hipStream_t st);
 
+// fused consumer of an NT GEMM: store split(C * gelu'(fq(Y)) * mask(Y) * colscale[col]) instead of C (fc2 dgrad -> GELU backward)
+struct NTPost {
+    const float* Y;         // pre-FQ tensor, same [M, ldc] geometry as C
+    const float* qp;        // {scale, 1/scale, zp, enabled}
+    int qmin, qmax;
+    const float* colscale;  // optional [N]
+    void* out_hi;
+    void* out_lo;
+};
+
 // ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                   const void* B_lo = nullptr);
+                   const void* B_lo = nullptr, const NTPost* post = nullptr);
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                    const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
                    float* dbias, const float* row_div, hipStream_t st);
