@@ -183,6 +183,14 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
     float mn = INFINITY, mx = -INFINITY;
     constexpr int LDC = BN + 4;                 // fp32 words per staged row (pad: conflict-free b32 writes)
     float* sC = reinterpret_cast<float*>(smem); // [64][LDC]
+    // fused GELU backward: fq(Y) only takes qmax-qmin+1 (<= 256) values, so gelu'(fq(Y)) is a table (no erf/exp per element)
+    float* sLut = sC + 64 * LDC;
+    bool use_lut = false;
+    if (p.postY) {
+        use_lut = p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256;
+        if (use_lut && tid <= p.post_qmax - p.post_qmin) sLut[tid] = gelu_bwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
+        // (published by the __syncthreads() between staging and the store loop below)
+    }
 #pragma unroll
     for (int h = 0; h < BM / 64; ++h) {
         if (h) __syncthreads();
@@ -225,8 +233,10 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
                     for (int e = 0; e < 4; ++e) {
                         const float t = rintf(yv[e] * qinv) + qzp;
                         const bool in = (t >= fmin_ && t <= fmax_) || qon == 0.f;
-                        const float f = qon != 0.f ? (fminf(fmaxf(t, fmin_), fmax_) - qzp) * qs : yv[e];
-                        const float o = in ? cv[e] * gelu_bwd(f) * sv[e] : 0.f;
+                        float dg;
+                        if (use_lut) dg = sLut[(int)(fminf(fmaxf(t, fmin_), fmax_) - fmin_)];
+                        else dg = gelu_bwd(qon != 0.f ? (fminf(fmaxf(t, fmin_), fmax_) - qzp) * qs : yv[e]);
+                        const float o = in ? cv[e] * dg * sv[e] : 0.f;
                         oh[e] = (__bf16)o;
                         ol[e] = (__bf16)(o - (float)oh[e]);
                     }
