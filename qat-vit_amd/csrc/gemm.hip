@@ -369,6 +369,7 @@ struct TNArgs {
     const int32_t* w_zp;  // [1] or [N]
     int w_per_channel, w_qmin, w_qmax;
     float* dbias;         // optional [N]: += sum_m P[m, n]  (bias gradient, ones-fragment MFMA)
+    int abl;              // timing-only ablation (tools/bench_gemm.py): 1 = skip the atomic epilogue
     const float* row_div; // optional [N]: results (and dbias) are divided by row_div[n] (P was pre-multiplied by the per-channel weight scale)
 };
 
@@ -491,6 +492,13 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     }
 
     // ---- epilogue: scale, weight-FQ STE mask, accumulate
+    if (p.abl == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     const float alpha = p.s1 ? *p.s1 : 1.f;
     const int r = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -529,7 +537,9 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
         return 1;
     }
     TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), reinterpret_cast<const __bf16*>(Q_hi),
-             reinterpret_cast<const __bf16*>(Q_lo), C, M, N, Kw, ldp, ldq, ldc, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div};
+             reinterpret_cast<const __bf16*>(Q_lo), C, M, N, Kw, ldp, ldq, ldc, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, 0, row_div};
+    static const int tn_abl = getenv("QATVIT_TN_ABL") ? atoi(getenv("QATVIT_TN_ABL")) : 0;
+    a.abl = tn_abl;
     // Kw-panel-wide tiles (128 x 384) read the heavy operand P = dY (hi, lo) once per N tile when Kw = 384; every Kw of
     // ViT-S/B (384, 1536, 768, 3072) is a multiple of 384.  QATVIT_TN_WIDE=0 forces the 128 x 128 tile (tuning).
     static const int wide_env = getenv("QATVIT_TN_WIDE") ? atoi(getenv("QATVIT_TN_WIDE")) : 1;

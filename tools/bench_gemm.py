@@ -7,7 +7,7 @@ from qat_vit_amd import native
 L = native.lib()
 dev = "cuda"
 st = torch.cuda.current_stream().cuda_stream
-M = 50432
+M = int(os.environ.get("BENCH_M", 50432))
 
 def timeit(fn, n=10):
     for _ in range(2): fn()
