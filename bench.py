@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
     ap.add_argument("--backend", default="qnnpack")
     ap.add_argument("--teacher", action="store_true", help="KD against a frozen ViT-B teacher (configs C3/C4)")
+    ap.add_argument("--student", default="vit_small", choices=["vit_small", "vit_base"], help="vit_base = config C5 (use --batch 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rates", action="store_true")
     args = ap.parse_args()
@@ -139,7 +140,10 @@ def main():
 
     L = native.lib()  # fail loudly before any timing if the HIP library is missing
     torch.manual_seed(0)
-    student = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True).to(dev)
+    if args.student == "vit_small":
+        student = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True).to(dev)
+    else:
+        student = qat_vit_amd.create_model("vit_base_patch16_224_teacher", pretrained=False, num_classes=10, qat_wrapper=True).to(dev)
     model = prepare(student, args.backend).to(dev)
     teacher = None
     if args.teacher:
@@ -199,7 +203,7 @@ def main():
             "value": round(imgs / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 semantics (bf16 MFMA on exact grid / hi+lo split operands, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"vit_small_patch16_224 student + QATWrapper, {args.backend} qconfig, "
+            "config": {"workload": f"{args.student}_patch16_224 student + QATWrapper, {args.backend} qconfig, "
                                    f"{'vit_base teacher KD (native teacher forward inside the timed step)' if args.teacher else 'no teacher'}, "
                                    f"batch {args.batch}/GPU, 224x224x3 (BASELINE configs[{2 if args.teacher else 1}])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},

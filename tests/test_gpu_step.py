@@ -109,20 +109,25 @@ def test_tiny_x86_vs_reference_fixture(native_lib, golden_dir):
     assert eng.cfg.w_per_channel == 1 and eng.cfg.act_qmax == 127
 
 
-def _full_size_case(backend, seed, teacher, fixture=None, golden_dir=None):
-    w = step_ref.build_student("vit_small_patch16_224", seed=seed)
+def _full_size_case(backend, seed, teacher, fixture=None, golden_dir=None, arch="vit_small_patch16_224", B=8):
+    w = step_ref.build_student(arch, seed=seed)
     po = step_ref.enable_qat(w, backend)                       # oracle, CPU
     pg = copy.deepcopy(po).cuda()                              # the same stock tree on the GPU: fp32 noise-floor probe
-    p = _product_from(w, backend)                              # product
+    if arch == "vit_small_patch16_224":
+        p = _product_from(w, backend)                          # product
+    else:  # ViT-B student (BASELINE config C5): same registry entry the reference would wrap
+        stu = qat_vit_amd.create_model("vit_base_patch16_224_teacher", pretrained=False, num_classes=10, qat_wrapper=True)
+        stu.load_state_dict(w.state_dict())
+        p = prepare(stu.cuda(), backend)
     if fixture is not None:
         z = np.load(os.path.join(golden_dir, fixture))
         g = torch.Generator().manual_seed(int(z["x_seed"]))
     else:
         z = None
         g = torch.Generator().manual_seed(77)
-    x = torch.randn(8, 3, 224, 224, generator=g)
-    y = torch.randint(0, 10, (8,), generator=g)
-    t = torch.randn(8, 10, generator=g) * 2 if teacher else None
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
+    t = torch.randn(B, 10, generator=g) * 2 if teacher else None
     caps_o = capture_fq_io(po)
     ro, rloss, _, _ = step_ref.student_step(po, x, y, t)
     go, gloss, _, _ = step_ref.student_step(pg, x.cuda(), y.cuda(), None if t is None else t.cuda())
@@ -134,7 +139,7 @@ def _full_size_case(backend, seed, teacher, fixture=None, golden_dir=None):
         # (observed 3e-2 qnnpack, 8e-2 x86), so only a coarse bound can tie this run to the committed fixture.
         assert rel_l2(ro, z["s0/logits"]) < 0.2
         assert abs(rloss.item() - z["s0/loss"][0]) < 0.02 * abs(z["s0/loss"][0])
-    B, T, D = 8, 197, 384
+    T, D = 197, eng.cfg.embed_dim
     M = B * T
     # ---- (2) first stages: <= 1e-3 against the oracle's own tensors
     y0 = caps_o["model.patch_embed.proj.activation_post_process"][0].permute(0, 2, 3, 1).reshape(-1, D)
@@ -182,6 +187,11 @@ def test_c1_vits_b8_qnnpack(native_lib, golden_dir):
 def test_c3_vits_b8_x86_kd(native_lib, golden_dir):
     """BASELINE config C3 semantics at batch 8: per-channel weights, [0,127] activations, KD on."""
     print(_full_size_case("x86", 22, True, "step_c3_vits_b8_x86.npz", golden_dir))
+
+
+def test_c5_vitb_b4_x86(native_lib):
+    """BASELINE config C5 architecture (ViT-B student self-QAT, x86 qconfig) at batch 4."""
+    print(_full_size_case("x86", 31, False, arch="vit_base_patch16_224", B=4))
 
 
 def test_second_step_and_eval_mode_keep_observing(native_lib):
