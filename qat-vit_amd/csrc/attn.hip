@@ -79,6 +79,43 @@ __device__ inline void split_acc2(const f32x4& a, const f32x4& b, bf16x8& hi, bf
     }
 }
 
+// Re-tile one wave's 16 x HD fp32 accumulator block (MFMA layout: column on the lane, 4 rows per register group) through a
+// private LDS scratch into row-major runs: afterwards lane (row = lane / (HD/16), c16 = lane % (HD/16)) holds 16 consecutive
+// features of one token row -> 32-B bf16 stores instead of 2-B scatters.  LDS is in-order per wave; the asm fences stop the
+// compiler from reordering across the hand-off.
+template <int HD>
+__device__ inline bool wave_retile(float* sO, const f32x4 (&acc)[HD / 16], float scale, int lane, float (&out)[16], int& row, int& c16) {
+    constexpr int LDO = HD + 4;
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int jd = 0; jd < HD / 16; ++jd)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sO[(4 * g + e) * LDO + 16 * jd + r] = acc[jd][e] * scale;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    row = lane / (HD / 16);
+    c16 = lane % (HD / 16);
+    const bool active = row < 16;
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(sO + row * LDO + 16 * c16 + 4 * k);
+            out[4 * k] = v.x; out[4 * k + 1] = v.y; out[4 * k + 2] = v.z; out[4 * k + 3] = v.w;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return active;
+}
+__device__ inline void store_split16(__bf16* hi, __bf16* lo, int64_t off, const float (&v)[16]) {
+    bf16x8 h0, h1, l0, l1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h0[j] = (__bf16)v[j]; l0[j] = (__bf16)(v[j] - (float)h0[j]);
+        h1[j] = (__bf16)v[8 + j]; l1[j] = (__bf16)(v[8 + j] - (float)h1[j]);
+    }
+    *reinterpret_cast<bf16x8*>(hi + off) = h0; *reinterpret_cast<bf16x8*>(hi + off + 8) = h1;
+    *reinterpret_cast<bf16x8*>(lo + off) = l0; *reinterpret_cast<bf16x8*>(lo + off + 8) = l1;
+}
+
 struct AttnArgs {
     const float* qkv;   // pre-FQ fp32 [B*T, 3*D]
     const float* qp;    // {scale, 1/scale, zp, enabled} of the qkv activation FQ
@@ -133,6 +170,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;         // row image
     char* sV = smem + IMG;   // tr image
+    float* sO = reinterpret_cast<float*>(smem + 2 * IMG) + (threadIdx.x >> 6) * (16 * (HD + 4));  // per-wave output re-tiling scratch
     const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
@@ -175,7 +213,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
         for (int j = 0; j < NKT; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s[j][e] = expf(s[j][e] - m);
+                s[j][e] = fast_exp(s[j][e] - m);
                 l += s[j][e];
             }
         l += __shfl_xor(l, 16, 64);
@@ -197,19 +235,13 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
                 o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vf, o[jd], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int jd = 0; jd < HD / 16; ++jd)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int qq = qt * 16 + 4 * g + e;
-                if (qq < T) {
-                    const float v = o[jd][e] * q.s;
-                    const __bf16 hi = (__bf16)v;
-                    const int64_t off = ((int64_t)b * T + qq) * D + h * HD + 16 * jd + r;
-                    p.O_hi[off] = hi;
-                    p.O_lo[off] = (__bf16)(v - (float)hi);
-                }
-            }
+        {
+            float ov[16];
+            int orow, oc;
+            const bool act = wave_retile<HD>(sO, o, q.s, lane, ov, orow, oc);
+            const int qq = qt * 16 + orow;
+            if (act && qq < T) store_split16(p.O_hi, p.O_lo, ((int64_t)b * T + qq) * D + h * HD + 16 * oc, ov);
+        }
     }
 }
 
@@ -220,6 +252,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sKt = smem;            // [token][d] image of K: transposed reads (B operand of dQ) AND plain row reads (A operand of S^T)
     char* sV = smem + IMG;       // row image (A operand of dP^T)
+    float* sO = reinterpret_cast<float*>(smem + 2 * IMG) + (threadIdx.x >> 6) * (16 * (HD + 4));  // per-wave output re-tiling scratch
     const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
@@ -273,7 +306,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bool valid = 16 * j + 4 * g + e < T;
-                    const float pr = valid ? expf(s[e] * c - lse) : 0.f;
+                    const float pr = valid ? fast_exp(s[e] * c - lse) : 0.f;
                     ds2[u][e] = pr * (dp[e] * q.s - delta);
                 }
             }
@@ -286,21 +319,26 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
                 dq[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl, kt, dq[jd], 0, 0, 0);
             }
         }
-        const float a = q.s * p.softmax_scale;
+        {
+            float gv[16];
+            int orow, oc;
+            const bool act = wave_retile<HD>(sO, dq, q.s * p.softmax_scale, lane, gv, orow, oc);
+            const int qq = qt * 16 + orow;
+            if (act && qq < T) {
+                const int64_t off = ((int64_t)b * T + qq) * ld + h * HD + 16 * oc;
 #pragma unroll
-        for (int jd = 0; jd < HD / 16; ++jd)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int qq = qt * 16 + 4 * g + e;
-                if (qq < T) {
-                    const int64_t off = ((int64_t)b * T + qq) * ld + h * HD + 16 * jd + r;
-                    float v = qin(p.qkv[off], q) ? dq[jd][e] * a : 0.f;
-                    if (p.col_scale) v *= p.col_scale[h * HD + 16 * jd + r];
-                    const __bf16 hi = (__bf16)v;
-                    p.dqkv_hi[off] = hi;
-                    p.dqkv_lo[off] = (__bf16)(v - (float)hi);
+                for (int k = 0; k < 4; ++k) {  // STE mask of the qkv fake-quant (+ optional per-channel weight scale), 16 contiguous features
+                    const float4 xq = *reinterpret_cast<const float4*>(p.qkv + off + 4 * k);
+                    float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (p.col_scale) cs = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 16 * oc + 4 * k);
+                    gv[4 * k] = qin(xq.x, q) ? gv[4 * k] * cs.x : 0.f;
+                    gv[4 * k + 1] = qin(xq.y, q) ? gv[4 * k + 1] * cs.y : 0.f;
+                    gv[4 * k + 2] = qin(xq.z, q) ? gv[4 * k + 2] * cs.z : 0.f;
+                    gv[4 * k + 3] = qin(xq.w, q) ? gv[4 * k + 3] * cs.w : 0.f;
                 }
+                store_split16(p.dqkv_hi, p.dqkv_lo, off, gv);
             }
+        }
     }
 }
 
@@ -396,7 +434,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dkv(const AttnArgs p) {
                 // S orientation: this lane's key = 16*jt[u] + r, query = 16*(2qs+v) + 4g + e
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pr = (qval[v][e] && kvalid[u]) ? expf(sacc[e] * c - lse_r[v][e]) : 0.f;
+                    const float pr = (qval[v][e] && kvalid[u]) ? fast_exp(sacc[e] * c - lse_r[v][e]) : 0.f;
                     p2[v][e] = pr;
                     ds2[v][e] = pr * (dp[e] * q.s - dlt_r[v][e]);
                 }
@@ -461,12 +499,13 @@ template <int HD, int NKT>
 static void launch3(int which, const AttnArgs& a, hipStream_t st) {
     const size_t img = (size_t)NKT * 16 * HD * 2;
     const int grid = a.B * a.H;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img)),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img)),
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 16 * (HD + 4) * 4)),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 16 * (HD + 4) * 4)),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)), true);
     (void)once;
-    if (which == 0) k_attn_fwd<HD, NKT><<<grid, kAW * 64, 2 * img, st>>>(a);
-    else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, kAW * 64, 2 * img, st>>>(a);
+    const size_t scratch = (size_t)kAW * 16 * (HD + 4) * sizeof(float);
+    if (which == 0) k_attn_fwd<HD, NKT><<<grid, kAW * 64, 2 * img + scratch, st>>>(a);
+    else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, kAW * 64, 2 * img + scratch, st>>>(a);
     else k_attn_bwd_dkv<HD, NKT><<<grid, kAW * 64, 3 * img, st>>>(a);
 }
 

@@ -78,6 +78,10 @@ __device__ inline float fq_one(float x, float inv_scale, float scale, float fzp,
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// exp(x) for x <= 0 as one v_exp_f32 (2^y) after a multiply by log2(e): the attention kernels are VALU-bound and the libm
+// expf expands to ~20 instructions; v_exp_f32 is accurate to ~1 ulp, far inside the 3e-5 kernel tolerance.
+__device__ inline float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 // exact-erf GELU (nn.GELU() default) and its derivative
 __device__ inline float gelu_fwd(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ inline float gelu_bwd(float x) {

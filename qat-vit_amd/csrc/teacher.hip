@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kTW * 64) void k_attn_fwd_float(const float* __rest
 #pragma unroll
         for (int j = 0; j < NKT; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s[j][e] = expf(s[j][e] - m); l += s[j][e]; }
+            for (int e = 0; e < 4; ++e) { s[j][e] = fast_exp(s[j][e] - m); l += s[j][e]; }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float invl = 1.0f / l;
