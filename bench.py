@@ -112,8 +112,8 @@ def cpu_baseline(seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
     ap.add_argument("--backend", default="qnnpack")
     ap.add_argument("--teacher", action="store_true", help="KD against a frozen ViT-B teacher (configs C3/C4)")
@@ -210,12 +210,28 @@ def main():
         }
         tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         res["roofline"] = {
-            "bound": "mfma", "kernel": "qv::k_gemm_nt<2,3,4,2> (split-bf16 A: proj/fc2 forward + all dgrads; the largest single kernel of the step)",
+            "bound": "mfma", "kernel": "qv::k_gemm_nt, split-bf16 A operand (proj/fc2 forward + all dgrads; 128x384 tiles when N%384==0; "
+                                       "the largest single kernel of the step)",
             "achieved": round(tflops, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / BF16_PEAK_TFLOPS, 4), "traffic": None,
             "launches": cnt.value, "avg_us_per_launch": round(1e3 * ms.value / max(1, cnt.value), 1),
             "note": "algorithmic FLOPs 2*M*N*K per launch / HIP-event time of that launch inside the timed steps; every launch issues two "
                     "bf16 MFMA passes (hi and lo), so issued MFMA work is 2x this figure",
         }
+        # MFMA utilisation of the other two GEMM kernels (fused-QKV / MLP GEMMs), two extra untimed steps each
+        other = {}
+        for kind, name in ((2, "k_gemm_nt grid A (patch-embed, qkv, fc1 forward; one bf16 pass)"),
+                           (3, "k_gemm_tn (all weight gradients; split dY, grid or split X)")):
+            native.check(L.qatvit_profile_start(kind, 8 * eng.cfg.depth + 16), "profile_start")
+            if world == 1:
+                step(); step()
+                torch.cuda.synchronize()
+            native.check(L.qatvit_profile_stop(ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl)), "profile_stop")
+            if ms.value > 0:
+                tf = fl.value / (ms.value * 1e-3) / 1e12
+                other[name] = {"algorithmic_TFLOPs": round(tf, 1), "frac_of_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4),
+                               "launches": cnt.value, "avg_us_per_launch": round(1e3 * ms.value / max(1, cnt.value), 1)}
+        if other:
+            res["mfma_gemms"] = other
         if not args.no_kernel_rates:
             res["hbm_kernels"] = hbm_kernel_rates(args.batch)
         if world == 1 and not args.no_cpu_baseline:
