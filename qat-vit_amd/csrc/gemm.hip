@@ -77,102 +77,11 @@ struct NTArgs {
     __bf16* out_lo;
 };
 
-template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4>  // ABL: timing-only ablation (1 = no LDS reads / MFMA)
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
-    // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
-    constexpr int WR = 16 * TM, WC = 16 * TNT;      // rows / columns per wave
-    constexpr int BM = WR * WM, BN = WC * WN, BK = 64, NW = WN * WM;
-    constexpr int IMGA = BM * 128;                  // bytes of one [BM][64] bf16 image
-    constexpr int IMGB = BN * 128;
-    constexpr int STAGE = TA * IMGA + TB * IMGB;
-    constexpr int PA = (BM / 8) / NW;               // 1-KiB DMA pieces per wave per A image
-    constexpr int PB = (BN / 8) / NW;
-    constexpr int NDMA = TA * PA + TB * PB;         // LDS-DMA instructions per wave per k-tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int wm = wave / WN, wn = wave % WN;
-    const int tilesN = p.N / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
-
-    const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(p.A0, (int64_t)p.M * p.lda * 2);
-    const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(TA == 2 ? p.A1 : p.A0, (int64_t)p.M * p.lda * 2);
-    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, (int64_t)p.N * p.ldb * 2);
-    const __amdgpu_buffer_rsrc_t rB1 = make_rsrc(TB == 2 ? p.B1 : p.B, (int64_t)p.N * p.ldb * 2);
-    // this lane's place inside a 1-KiB DMA piece (8 rows x 128 B): row lr, swizzled source chunk
-    const int lr = lane >> 3;
-    const int src_chunk = (lane & 7) ^ lr;
-
-    auto issue = [&](int kt) {
-        char* st = smem + (kt % NSTAGE) * STAGE;
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int c = 0; c < PA; ++c) {
-            const int piece = wave * PA + c;
-            const uint32_t offA = (uint32_t)(((int64_t)(m0 + piece * 8 + lr) * p.lda + k0 + src_chunk * 8) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lds_void*)(st + piece * 1024), 16, offA, 0, 0, 0);
-            if constexpr (TA == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (lds_void*)(st + IMGA + piece * 1024), 16, offA, 0, 0, 0);
-        }
-#pragma unroll
-        for (int c = 0; c < PB; ++c) {
-            const int piece = wave * PB + c;
-            const uint32_t offB = (uint32_t)(((int64_t)(n0 + piece * 8 + lr) * p.ldb + k0 + src_chunk * 8) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(st + TA * IMGA + piece * 1024), 16, offB, 0, 0, 0);
-            if constexpr (TB == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, (lds_void*)(st + TA * IMGA + IMGB + piece * 1024), 16, offB, 0, 0, 0);
-        }
-    };
-
-    f32x4 acc[TM][TNT];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk) issue(s);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most the (NSTAGE-2) younger tiles' DMAs are still outstanding
-        if (NSTAGE == 3 && kt + 1 < nk) wait_vmcnt<NDMA>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone left buffer (kt-1)%NSTAGE
-        asm volatile("" ::: "memory");
-        if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
-        const char* st = smem + (kt % NSTAGE) * STAGE;
-        const char* sB = st + TA * IMGA;
-        if constexpr (ABL == 1) continue;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 bfrag[TNT], blo[TB == 2 ? TNT : 1], afrag[TA][TM];
-#pragma unroll
-            for (int j = 0; j < TNT; ++j) {
-                bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off(wn * WC + 16 * j + r, 4 * kk + g));
-                if constexpr (TB == 2) blo[j] = *reinterpret_cast<const bf16x8*>(sB + IMGB + nt_off(wn * WC + 16 * j + r, 4 * kk + g));
-            }
-#pragma unroll
-            for (int t = 0; t < TA; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) afrag[t][i] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + nt_off(wm * WR + 16 * i + r, 4 * kk + g));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int t = 0; t < TA; ++t)
-#pragma unroll
-                    for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t][i], bfrag[j], acc[i][j], 0, 0, 0);
-            if constexpr (TB == 2) {  // third pass of a float x float product: A_hi . B_lo
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][i], blo[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    }
-    __syncthreads();  // all fragment reads done: the ring is free for the epilogue
-
+// ---- shared epilogue of the NT kernels.  WM x WN waves, wave (wm, wn) holds a (16*TM) x (16*TNT) sub-tile in acc[][].
+template <int WM, int WN, int TM, int TNT>
+__device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char* smem, int m0, int n0, int tid, int lane, int wave, int wm, int wn,
+                                   int r, int g) {
+    constexpr int WR = 16 * TM, WC = 16 * TNT, BM = WR * WM, BN = WC * WN, NW = WN * WM;
     // ---- epilogue: C = acc * alpha[col] + bias[col]; min/max of what is stored.
     // The accumulator layout (16 consecutive columns per 16 lanes, rows on registers) would give 64-B store
     // segments; stage 64-row halves of the tile through LDS instead and store whole 16-B-per-lane row runs
@@ -191,30 +100,36 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
         if (use_lut && tid <= p.post_qmax - p.post_qmin) sLut[tid] = gelu_bwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
         // (published by the __syncthreads() between staging and the store loop below)
     }
+    float ca[TNT], cb[TNT];
 #pragma unroll
-    for (int h = 0; h < BM / 64; ++h) {
+    for (int j = 0; j < TNT; ++j) {
+        const int cl = wn * WC + 16 * j + r;
+        ca[j] = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
+        cb[j] = p.bias ? p.bias[n0 + cl] : 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < (BM + 63) / 64; ++h) {
         if (h) __syncthreads();
-        if ((wm * WR) / 64 == h) {
-            const int rbase = wm * WR - 64 * h;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rt = wm * WR + 16 * i;    // first tile row of this 16-row fragment
+            if (rt / 64 != h) continue;
 #pragma unroll
             for (int j = 0; j < TNT; ++j) {
                 const int cl = wn * WC + 16 * j + r;
-                const float a = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
-                const float b = p.bias ? p.bias[n0 + cl] : 0.f;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int rl = rbase + 16 * i + 4 * g + e;
-                        const float v = acc[i][j][e] * a + b;
-                        sC[rl * LDC + cl] = v;
-                        if (m0 + 64 * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const int rl = rt - 64 * h + 4 * g + e;
+                    const float v = acc[i][j][e] * ca[j] + cb[j];
+                    sC[rl * LDC + cl] = v;
+                    if (m0 + 64 * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+                }
             }
         }
         __syncthreads();
         constexpr int C4 = BN / 4;              // float4 per staged row
-        for (int idx = tid; idx < 64 * C4; idx += NW * 64) {
+        const int rows_h = BM - 64 * h < 64 ? BM - 64 * h : 64;
+        for (int idx = tid; idx < rows_h * C4; idx += NW * 64) {
             const int rl = idx / C4, c4 = idx % C4;
             const int row = m0 + 64 * h + rl;
             if (row < p.M) {
@@ -262,6 +177,179 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
             stat_atomic(p.stats, p.stat_slots, mn, mx);
         }
     }
+}
+
+// timing-only ablations: keep the accumulators alive without an epilogue
+template <int TM, int TNT>
+__device__ inline void nt_keep_alive(const NTArgs& p, f32x4 (&acc)[TM][TNT]) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 1.2345e-30f) p.C[1 << 20] = t;
+}
+
+// LDS image of a BK = 32 tile: two 64-B tile rows share one 128-B LDS row; chunk index ((row & 1) * 4 + k-chunk) XOR (LDS row & 7).
+__device__ inline int nt_off32(int row, int chunk) {
+    const int R = row >> 1;
+    return R * 128 + (((((row & 1) << 2) | chunk) ^ (R & 7)) << 4);
+}
+
+// ABL: timing-only ablations (tools/bench_gemm.py, tools/stamp_nt.py): 1 = no LDS reads / MFMA, 2 = no DMA, 3 = no epilogue,
+// 5 = s_memtime stamps of the k-loop into p.C (no epilogue)
+template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
+    // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
+    static_assert(BK == 64 || BK == 32, "BK");
+    constexpr int WR = 16 * TM, WC = 16 * TNT;      // rows / columns per wave
+    constexpr int BM = WR * WM, BN = WC * WN, NW = WN * WM;
+    constexpr int IMGA = BM * BK * 2;               // bytes of one [BM][BK] bf16 image
+    constexpr int IMGB = BN * BK * 2;
+    constexpr int STAGE = TA * IMGA + TB * IMGB;
+    constexpr int RPP = 512 / BK;                   // tile rows per 1-KiB DMA piece
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows per piece");
+    constexpr int PAI = BM / RPP, PBI = BN / RPP;   // pieces per A / B image
+    constexpr int NP = TA * PAI + TB * PBI;         // pieces per k-tile, dealt round-robin to the waves
+    constexpr int NDF = NP / NW, NDX = NP % NW;     // every wave issues NDF, waves < NDX one more
+    constexpr int NPW = NDF + (NDX ? 1 : 0);        // DMA slots per wave per k-tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int wm = WM == 1 ? 0 : wave / WN, wn = WM == 1 ? wave : wave % WN;
+    const int tilesN = p.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
+
+    const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(p.A0, (int64_t)p.M * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(TA == 2 ? p.A1 : p.A0, (int64_t)p.M * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, (int64_t)p.N * p.ldb * 2);
+    const __amdgpu_buffer_rsrc_t rB1 = make_rsrc(TB == 2 ? p.B1 : p.B, (int64_t)p.N * p.ldb * 2);
+    // this lane's place inside a 1-KiB DMA piece: the destination is lane-linear (LDS row lane>>3, chunk lane&7), so the
+    // swizzle is applied to the SOURCE: tile row `prow` of the piece, 8-element k-chunk `pk`
+    const int lR = lane >> 3, lL = (lane & 7) ^ lR;
+    const int prow = BK == 64 ? lR : 2 * lR + (lL >> 2);
+    const int pk = BK == 64 ? lL : (lL & 3);
+
+    auto issue_piece = [&](int kt, int c) {   // this wave's c-th DMA piece of k-tile kt
+        char* st = smem + (kt % NSTAGE) * STAGE;
+        const int k0 = kt * BK;
+        const int pc = c * NW + wave;
+        if (c == NDF && wave >= NDX) return;
+        if (pc < TA * PAI) {
+            const int img = (TA == 2 && pc >= PAI) ? 1 : 0, q = pc - img * PAI;
+            const uint32_t off = (uint32_t)(((int64_t)(m0 + q * RPP + prow) * p.lda + k0 + pk * 8) * 2);
+            if (img == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lds_void*)(st + q * 1024), 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (lds_void*)(st + IMGA + q * 1024), 16, off, 0, 0, 0);
+        } else {
+            const int pb = pc - TA * PAI;
+            const int img = (TB == 2 && pb >= PBI) ? 1 : 0, q = pb - img * PBI;
+            const uint32_t off = (uint32_t)(((int64_t)(n0 + q * RPP + prow) * p.ldb + k0 + pk * 8) * 2);
+            if (img == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(st + TA * IMGA + q * 1024), 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, (lds_void*)(st + TA * IMGA + IMGB + q * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int c = 0; c < NPW; ++c) issue_piece(kt, c);
+    };
+    auto foff = [&](int row, int kk) { return BK == 64 ? nt_off(row, 4 * kk + g) : nt_off32(row, g); };
+
+    f32x4 acc[TM][TNT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (ABL != 2 && s < nk) issue(s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        uint64_t t0 = 0, t1 = 0, t2 = 0;
+        if constexpr (ABL == 5) t0 = __builtin_amdgcn_s_memtime();
+        // tile kt has landed once at most the (NSTAGE-2) younger tiles' DMAs are still outstanding
+        if (NSTAGE >= 3 && kt + NSTAGE - 2 < nk) {
+            if (NDX && wave < NDX) wait_vmcnt<(NSTAGE - 2) * (NDF + 1)>();
+            else wait_vmcnt<(NSTAGE - 2) * NDF>();
+        } else wait_vmcnt<0>();
+        if constexpr (ABL == 5) t1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone left buffer (kt-1)%NSTAGE
+        asm volatile("" ::: "memory");
+        if constexpr (ABL == 5) {
+            t2 = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && kt < 48 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+                uint64_t* dbg = reinterpret_cast<uint64_t*>(p.C) + (((blockIdx.x ? 1 : 0) * NW + wave) * 48 + kt) * 3;
+                dbg[0] = t0; dbg[1] = t1; dbg[2] = t2;
+            }
+        }
+        constexpr bool SPREAD = TM > 4 && TM >= NPW;   // tall tiles: DMA issue spread between the MFMA groups below
+        const bool more = ABL != 2 && kt + NSTAGE - 1 < nk;
+        if (!SPREAD && more) issue(kt + NSTAGE - 1);
+        const char* st = smem + (kt % NSTAGE) * STAGE;
+        const char* sB = st + TA * IMGA;
+        if constexpr (ABL == 1) {
+            if (SPREAD && more) issue(kt + NSTAGE - 1);
+            continue;
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 bfrag[TNT], blo[TB == 2 ? TNT : 1];
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) {
+                bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + foff(wn * WC + 16 * j + r, kk));
+                if constexpr (TB == 2) blo[j] = *reinterpret_cast<const bf16x8*>(sB + IMGB + foff(wn * WC + 16 * j + r, kk));
+            }
+            if constexpr (TM <= 4) {
+                bf16x8 afrag[TA][TM];
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) afrag[t][i] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + foff(wm * WR + 16 * i + r, kk));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int t = 0; t < TA; ++t)
+#pragma unroll
+                        for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t][i], bfrag[j], acc[i][j], 0, 0, 0);
+                if constexpr (TB == 2) {  // third pass of a float x float product: A_hi . B_lo
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][i], blo[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+                // tall sub-tiles: A fragments stream through a few registers, B fragments stay resident
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (SPREAD && kk == 0 && more) {
+#pragma unroll
+                        for (int c = 0; c < NPW; ++c)
+                            if ((c * TM) / NPW == i) issue_piece(kt + NSTAGE - 1, c);
+                    }
+                    bf16x8 af[TA];
+#pragma unroll
+                    for (int t = 0; t < TA; ++t) af[t] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + foff(wm * WR + 16 * i + r, kk));
+#pragma unroll
+                    for (int t = 0; t < TA; ++t)
+#pragma unroll
+                        for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bfrag[j], acc[i][j], 0, 0, 0);
+                    if constexpr (TB == 2) {
+#pragma unroll
+                        for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], blo[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();  // all fragment reads done: the ring is free for the epilogue
+    if constexpr (ABL == 3 || ABL == 5) {
+        nt_keep_alive<TM, TNT>(p, acc);
+        return;
+    }
+    nt_epilogue<WM, WN, TM, TNT>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
 
 template <typename K>
@@ -312,6 +400,27 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     // multiple of 384, so for N = 384 the A operand is streamed into LDS exactly once (the kernels are bound by the
     // fabric -> LDS-DMA rate, ~7 TB/s chip-wide, not by MFMA: profiles/round1_gemm_ablation.txt).
     static const int wide = getenv("QATVIT_NT_WIDE") ? atoi(getenv("QATVIT_NT_WIDE")) : 1;
+    // Tall tiles for split-A operands: 208 x 384 (1 x 8 waves, each 208 x 48), BK 32, 3 stages, DMA issue spread between the MFMA
+    // groups.  M = B*197 rows over 256 CUs is 197 rows per CU: 243 tiles of 208 rows fill the chip in ONE round for N = 384
+    // (128-row tiles: 394 tiles = 2 rounds at 77 %), and a 208-row tile moves 7.7 B into LDS per row and k against 10 B for 128 rows.
+    static const int tall = getenv("QATVIT_NT_TALL") ? atoi(getenv("QATVIT_NT_TALL")) : 1;
+    if (tall && A_lo && N % 384 == 0 && K % 32 == 0) {
+        constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
+        static const int tabl = getenv("QATVIT_NT_ABL") ? atoi(getenv("QATVIT_NT_ABL")) : 0;   // timing-only ablations
+#define QV_TALL(ABL_)                                                                                  \
+        do {                                                                                           \
+            static bool once = (allow_lds(k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32>, lds), true);      \
+            (void)once;                                                                                \
+            k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32><<<cdiv(M, 208) * (N / 384), 512, lds, st>>>(a);  \
+        } while (0)
+        if (tabl == 1) QV_TALL(1);
+        else if (tabl == 2) QV_TALL(2);
+        else if (tabl == 3) QV_TALL(3);
+        else if (tabl == 5) QV_TALL(5);
+        else QV_TALL(0);
+#undef QV_TALL
+        return 0;
+    }
     if (((wide == 1 && A_lo) || wide == 2) && N % 384 == 0) {   // grid-A GEMMs (K = 384, store-bound) measured equal or better on 128^2 tiles
         const int nwg = cdiv(M, 128) * (N / 384);
         if (A_lo) {

@@ -9,7 +9,7 @@ dev = "cuda"
 st = torch.cuda.current_stream().cuda_stream
 M = int(os.environ.get("BENCH_M", 50432))
 
-def timeit(fn, n=10):
+def timeit(fn, n=int(os.environ.get("BENCH_N", 30))):
     for _ in range(2): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
