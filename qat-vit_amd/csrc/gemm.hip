@@ -198,7 +198,8 @@ __device__ inline int nt_off32(int row, int chunk) {
 
 // ABL: timing-only ablations (tools/bench_gemm.py, tools/stamp_nt.py): 1 = no LDS reads / MFMA, 2 = no DMA, 3 = no epilogue,
 // 5 = s_memtime stamps of the k-loop into p.C (no epilogue)
-template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64>
+// NWD: number of waves (the first NWD, the older wave of each SIMD pair) that issue the LDS-DMA pieces; 0 = all of them
+template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
     // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
     static_assert(BK == 64 || BK == 32, "BK");
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows per piece");
     constexpr int PAI = BM / RPP, PBI = BN / RPP;   // pieces per A / B image
     constexpr int NP = TA * PAI + TB * PBI;         // pieces per k-tile, dealt round-robin to the waves
-    constexpr int NDF = NP / NW, NDX = NP % NW;     // every wave issues NDF, waves < NDX one more
+    constexpr int NWD = NWD_ ? NWD_ : NW;
+    constexpr int NDF = NP / NWD, NDX = NP % NWD;   // every issuing wave issues NDF, waves < NDX one more
     constexpr int NPW = NDF + (NDX ? 1 : 0);        // DMA slots per wave per k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
     auto issue_piece = [&](int kt, int c) {   // this wave's c-th DMA piece of k-tile kt
         char* st = smem + (kt % NSTAGE) * STAGE;
         const int k0 = kt * BK;
-        const int pc = c * NW + wave;
-        if (c == NDF && wave >= NDX) return;
+        const int pc = c * NWD + wave;
+        if ((c == NDF && wave >= NDX) || wave >= NWD) return;
         if (pc < TA * PAI) {
             const int img = (TA == 2 && pc >= PAI) ? 1 : 0, q = pc - img * PAI;
             const uint32_t off = (uint32_t)(((int64_t)(m0 + q * RPP + prow) * p.lda + k0 + pk * 8) * 2);
@@ -265,20 +267,20 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
     const int nk = p.K / BK;
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-        if (ABL != 2 && s < nk) issue(s);
+        if (ABL != 2 && ABL != 6 && s < nk) issue(s);
 
     for (int kt = 0; kt < nk; ++kt) {
         uint64_t t0 = 0, t1 = 0, t2 = 0;
-        if constexpr (ABL == 5) t0 = __builtin_amdgcn_s_memtime();
+        if constexpr (ABL == 5 || ABL == 6) t0 = __builtin_amdgcn_s_memtime();
         // tile kt has landed once at most the (NSTAGE-2) younger tiles' DMAs are still outstanding
         if (NSTAGE >= 3 && kt + NSTAGE - 2 < nk) {
             if (NDX && wave < NDX) wait_vmcnt<(NSTAGE - 2) * (NDF + 1)>();
             else wait_vmcnt<(NSTAGE - 2) * NDF>();
         } else wait_vmcnt<0>();
-        if constexpr (ABL == 5) t1 = __builtin_amdgcn_s_memtime();
+        if constexpr (ABL == 5 || ABL == 6) t1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone left buffer (kt-1)%NSTAGE
         asm volatile("" ::: "memory");
-        if constexpr (ABL == 5) {
+        if constexpr (ABL == 5 || ABL == 6) {
             t2 = __builtin_amdgcn_s_memtime();
             if (lane == 0 && kt < 48 && (blockIdx.x == 0 || blockIdx.x == 100)) {
                 uint64_t* dbg = reinterpret_cast<uint64_t*>(p.C) + (((blockIdx.x ? 1 : 0) * NW + wave) * 48 + kt) * 3;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
             }
         }
         constexpr bool SPREAD = TM > 4 && TM >= NPW;   // tall tiles: DMA issue spread between the MFMA groups below
-        const bool more = ABL != 2 && kt + NSTAGE - 1 < nk;
+        const bool more = ABL != 2 && ABL != 6 && kt + NSTAGE - 1 < nk;
         if (!SPREAD && more) issue(kt + NSTAGE - 1);
         const char* st = smem + (kt % NSTAGE) * STAGE;
         const char* sB = st + TA * IMGA;
@@ -321,7 +323,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
                         for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][i], blo[j], acc[i][j], 0, 0, 0);
                 }
             } else {
-                // tall sub-tiles: A fragments stream through a few registers, B fragments stay resident
+                // tall sub-tiles: A fragments stream through a PF-deep register ring (LDS latency covered by PF groups of MFMAs),
+                // B fragments stay resident
+                constexpr int PF = 3;
+                bf16x8 af[PF][TA];
+                auto read_a = [&](int i) {
+#pragma unroll
+                    for (int t = 0; t < TA; ++t) af[i % PF][t] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + foff(wm * WR + 16 * i + r, kk));
+                };
+#pragma unroll
+                for (int i = 0; i < PF - 1 && i < TM; ++i) read_a(i);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     if (SPREAD && kk == 0 && more) {
@@ -329,23 +340,21 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
                         for (int c = 0; c < NPW; ++c)
                             if ((c * TM) / NPW == i) issue_piece(kt + NSTAGE - 1, c);
                     }
-                    bf16x8 af[TA];
-#pragma unroll
-                    for (int t = 0; t < TA; ++t) af[t] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + foff(wm * WR + 16 * i + r, kk));
+                    if (i + PF - 1 < TM) read_a(i + PF - 1);
 #pragma unroll
                     for (int t = 0; t < TA; ++t)
 #pragma unroll
-                        for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bfrag[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % PF][t], bfrag[j], acc[i][j], 0, 0, 0);
                     if constexpr (TB == 2) {
 #pragma unroll
-                        for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], blo[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % PF][0], blo[j], acc[i][j], 0, 0, 0);
                     }
                 }
             }
         }
     }
     __syncthreads();  // all fragment reads done: the ring is free for the epilogue
-    if constexpr (ABL == 3 || ABL == 5) {
+    if constexpr (ABL == 3 || ABL == 5 || ABL == 6) {
         nt_keep_alive<TM, TNT>(p, acc);
         return;
     }
@@ -407,16 +416,23 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     if (tall && A_lo && N % 384 == 0 && K % 32 == 0) {
         constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
         static const int tabl = getenv("QATVIT_NT_ABL") ? atoi(getenv("QATVIT_NT_ABL")) : 0;   // timing-only ablations
-#define QV_TALL(ABL_)                                                                                  \
-        do {                                                                                           \
-            static bool once = (allow_lds(k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32>, lds), true);      \
-            (void)once;                                                                                \
-            k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32><<<cdiv(M, 208) * (N / 384), 512, lds, st>>>(a);  \
+#define QV_TALL(ABL_)                                                                                         \
+        do {                                                                                                  \
+            if (tall == 2) {                                                                                  \
+                static bool once = (allow_lds(k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 4>, lds), true);      \
+                (void)once;                                                                                   \
+                k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 4><<<cdiv(M, 208) * (N / 384), 512, lds, st>>>(a);  \
+            } else {                                                                                          \
+                static bool once = (allow_lds(k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32>, lds), true);         \
+                (void)once;                                                                                   \
+                k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32><<<cdiv(M, 208) * (N / 384), 512, lds, st>>>(a);     \
+            }                                                                                                 \
         } while (0)
         if (tabl == 1) QV_TALL(1);
         else if (tabl == 2) QV_TALL(2);
         else if (tabl == 3) QV_TALL(3);
         else if (tabl == 5) QV_TALL(5);
+        else if (tabl == 6) QV_TALL(6);
         else QV_TALL(0);
 #undef QV_TALL
         return 0;
