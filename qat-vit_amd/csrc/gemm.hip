@@ -437,6 +437,14 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 #undef QV_TALL
         return 0;
     }
+    static const int tall1 = getenv("QATVIT_NT_TALL1") ? atoi(getenv("QATVIT_NT_TALL1")) : 1;
+    if (tall1 && !A_lo && N % 384 == 0 && K % 32 == 0) {   // grid A operand on the tall tile
+        constexpr size_t lds1 = 3 * (208 + 384) * 64;       // 111 KiB
+        static bool once = (allow_lds(k_gemm_nt<1, 3, 1, 13, 1, 0, 8, 3, 32>, lds1), true);
+        (void)once;
+        k_gemm_nt<1, 3, 1, 13, 1, 0, 8, 3, 32><<<cdiv(M, 208) * (N / 384), 512, lds1, st>>>(a);
+        return 0;
+    }
     if (((wide == 1 && A_lo) || wide == 2) && N % 384 == 0) {   // grid-A GEMMs (K = 384, store-bound) measured equal or better on 128^2 tiles
         const int nwg = cdiv(M, 128) * (N / 384);
         if (A_lo) {
