@@ -85,6 +85,16 @@ def hbm_kernel_rates(batch, iters=20):
                                                          dg.data_ptr(), db.data_ptr(), rows, D, st), "lnb"))
     out["layernorm_bwd_GBps"] = round(12.0 * rows * D / (ms * 1e-3) / 1e9, 1)
     out["hbm_peak_GBps"] = HBM_PEAK_GBS
+    # clip + AdamW over a ViT-S sized parameter set (outside the timed step: SURVEY 8(d)); 4 B/param norm + 28 B/param update
+    from qat_vit_amd.optim import ClipAdamW
+
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda") * 0.02) for s in [(384, 768)] + [(1152, 384), (384, 384), (1536, 384), (384, 1536)] * 12]
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    opt = ClipAdamW(ps, lr=1.5e-4, weight_decay=1e-3)
+    ms = timed(lambda: opt.step(max_norm=1.0))
+    out["clip_adamw_GBps"] = round(32.0 * sum(p.numel() for p in ps) / (ms * 1e-3) / 1e9, 1)
+    out["clip_adamw_ms_vit_small"] = round(ms, 3)
     return out
 
 

@@ -178,6 +178,27 @@ int64_t qatvit_teacher_workspace_bytes(const qatvit_cfg* cfg);
 int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* const* w_hi, void* const* w_lo,
                            const float* images, float* logits, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Gradient clipping + AdamW: the two statements that follow the hot path in the reference's loop.
+ * Replaces: torch.nn.utils.clip_grad_norm_(ddp_model.parameters(), 1.0); optimizer.step()   (qat_trainer.py:360-361)
+ *           with optimizer = torch.optim.AdamW(params, lr=..., weight_decay=...)             (qat_trainer.py:271-276).
+ * Tensors stay separate torch allocations: *_ptrs are DEVICE arrays of n_tensors device pointers (fp32), numel a device
+ * int64 array.  Work is dealt in chunks of chunk_elems (a multiple of 4): chunk c covers elements
+ * [chunk_index[c]*chunk_elems, ...) of tensor chunk_tensor[c]; both tables are device int32 arrays of n_chunks entries
+ * built once by the host.  No atomics: results are bit-reproducible run to run.
+ *
+ * grad_norm: partials = device scratch [n_chunks] fp32; out2 = {total L2 norm, min(1, max_norm/(total+1e-6))};
+ *            max_norm < 0 -> coefficient 1 (norm only).  Gradients are NOT modified: pass out2 to qatvit_optim_adamw.
+ * adamw:     in-place update of params / exp_avg / exp_avg_sq for 1-based step `step`; hyper-parameters are doubles because
+ *            torch forms 1-beta, lr*wd, lr/(1-beta1^t), sqrt(1-beta2^t) in double before narrowing to fp32; clip_out2 = NULL or the out2 above
+ *            (gradients enter multiplied by out2[1], as if clip_grad_norm_ had scaled them). */
+int qatvit_optim_grad_norm(const void* grad_ptrs, const int64_t* numel, const int32_t* chunk_tensor, const int32_t* chunk_index,
+                           int32_t n_chunks, int64_t chunk_elems, float max_norm, float* partials, float* out2, void* stream);
+int qatvit_optim_adamw(const void* param_ptrs, const void* grad_ptrs, const void* exp_avg_ptrs, const void* exp_avg_sq_ptrs,
+                       const int64_t* numel, const int32_t* chunk_tensor, const int32_t* chunk_index, int32_t n_chunks,
+                       int64_t chunk_elems, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                       const float* clip_out2, void* stream);
+
 /* Measurement hooks (bench.py): bracket every launch of one GEMM class inside the step with HIP events on the
  * launch stream.  kind: 1 = NT with split (hi+lo) A operand, 2 = NT with grid A operand, 3 = TN (wgrad).
  * stop() synchronises on the recorded events and returns the summed kernel time, launch count and the summed

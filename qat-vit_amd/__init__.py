@@ -10,4 +10,6 @@ from .model_registry import (  # noqa: F401
     register_model,
 )
 
-__all__ = ["PLATFORM", "QATWrapper", "create_model", "create_student", "create_teacher", "list_available_models", "register_model"]
+from .optim import ClipAdamW  # noqa: F401,E402
+
+__all__ = ["ClipAdamW", "PLATFORM", "QATWrapper", "create_model", "create_student", "create_teacher", "list_available_models", "register_model"]

@@ -303,7 +303,7 @@ int launch_fq_forward(const float* x, float* y, uint8_t* mask_bits, float* runni
         dim3 grid(stream_grid(inner >> 3), (unsigned)channels);
         k_quantize<<<grid, 256, 0, st>>>(x, y, mask_bits, qp, qmin, qmax, channels, inner);
     } else {
-        if (mask_bits) hipMemsetAsync(mask_bits, 0, (size_t)((n + 31) / 32) * 4, st);
+        if (mask_bits) (void)hipMemsetAsync(mask_bits, 0, (size_t)((n + 31) / 32) * 4, st);
         k_quantize_generic<<<stream_grid(n), 256, 0, st>>>(x, y, reinterpret_cast<uint32_t*>(mask_bits), qp, qmin, qmax, channels, inner);
     }
     return 0;

@@ -6,7 +6,6 @@
 
 namespace qv {
 
-constexpr int kMaxClasses = 64;
 
 __global__ __launch_bounds__(256) void k_kd_ce(const float* __restrict__ s, const float* __restrict__ t, const int64_t* __restrict__ labels,
                                                int B, int C, float T, float alpha, float eps, float* __restrict__ out3,

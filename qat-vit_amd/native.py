@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqatvit.so")
@@ -27,6 +27,8 @@ SIGNATURES = {
     "qatvit_ln_forward": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_float, c_void_p]),
     "qatvit_ln_backward": (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_void_p]),
     "qatvit_kd_ce_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "qatvit_optim_grad_norm": (c_int, [c_void_p] * 4 + [c_int32, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
+    "qatvit_optim_adamw": (c_int, [c_void_p] * 7 + [c_int32, c_int64] + [c_double] * 5 + [c_int64, c_void_p, c_void_p]),
     "qatvit_gemm_nt": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_tn": (c_int, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3),
     "qatvit_attn_padded_tokens": (c_int32, [c_int32]),
