@@ -111,6 +111,7 @@ class StudentEngine:
         self._ptr_params = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
         self._param_ptrs_key = tuple(p.data_ptr() for p in ps)
         self.pg = None
+        self.sync_state = True      # set per call by student_forward: grad mode of the caller (False under no_grad)
         self.bucket_bytes = 16 << 20
         self._build_fq_structs()
 
@@ -187,7 +188,10 @@ class StudentEngine:
         if images.shape != (c.batch, c.in_chans, c.img_size, c.img_size) or images.dtype != torch.float32:
             raise RuntimeError(f"expected fp32 images of shape {(c.batch, c.in_chans, c.img_size, c.img_size)}, got {tuple(images.shape)} {images.dtype}")
         self._check_ptrs()
-        if self.pg is not None:
+        # Rank 0's fake-quant state is authoritative at the start of every TRAINING forward (what DDP's buffer broadcast does
+        # for the reference).  A forward under no_grad - the reference's evaluate_fp32 runs on rank 0 only
+        # (qat_trainer.py:370-371) - issues no collective, so a one-rank evaluation cannot dead-lock the group.
+        if self.pg is not None and self.sync_state:
             self._broadcast_fq_state()
         images = images.contiguous()
         logits = torch.empty(c.batch, c.num_classes, dtype=torch.float32, device=self.device)
@@ -273,4 +277,5 @@ def student_forward(wrapper, images: torch.Tensor) -> torch.Tensor:
         if pg is not None:
             eng.enable_data_parallel(pg)
         _ENGINES[wrapper] = eng
+    eng.sync_state = torch.is_grad_enabled()   # read here: inside autograd.Function.forward grad mode is always off
     return _StudentStep.apply(images, eng, *eng.params)

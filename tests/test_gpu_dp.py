@@ -84,6 +84,14 @@ def _worker(rank, world, port, q):
                 if not torch.equal(a, b):
                     ok = False
                     msgs.append(f"it{it} buffer {n}")
+        # evaluation on rank 0 only (qat_trainer.py:370-371): must not issue a collective (would hang: rank 1 never joins)
+        if rank == 0:
+            dp.eval()
+            with torch.no_grad():
+                out = dp(x)
+            torch.cuda.synchronize()
+            ok &= bool(torch.isfinite(out).all())
+        dist.barrier()
         q.put((rank, ok, msgs[:8]))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
