@@ -50,6 +50,25 @@ template <int N> __device__ inline void wait_vmcnt() {
 #undef QV_W
 }
 
+// LDS-DMA through inline asm.  The TN kernel reads its fragments with the ds_read_tr16_b64 builtin; hipcc 7.2 cannot prove that such a
+// read does not alias the LDS destination of a __builtin_amdgcn_raw_ptr_buffer_load_lds still in flight (another ring stage) and puts
+// an s_waitcnt vmcnt(0) between every DMA issue and the next fragment read: no prefetch overlap at all.  An asm DMA is invisible to
+// that bookkeeping; completion is counted by hand (wait_vmcnt + s_barrier), exactly as the ring protocol requires anyway.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+__device__ inline v4i32 make_rsrc_v(const void* base, int64_t bytes) {
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    const uint32_t n = bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes;
+    return (v4i32){(int)(uint32_t)b, (int)(uint32_t)(b >> 32), (int)n, 0x00020000};
+}
+__device__ inline void dma16_asm(v4i32 rsrc, const char* lds_dst, uint32_t voff) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>((lds_void*)lds_dst));
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(m), "s"(rsrc)
+                 : "memory");
+}
+
 // ============================================================================ NT
 // LDS image of a [128 rows][64 bf16] tile: 128-B rows, 16-B chunk index XOR (row & 7).
 __device__ inline int nt_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -494,7 +513,8 @@ struct TNArgs {
     const __bf16* Q1;   // [M, ldq] lo part (TQ == 2)
     float* C;           // fp32 [N, ldc], accumulated with atomics (caller zeroes)
     int M, N, Kw, ldp, ldq, ldc;
-    int steps_per_split;  // 64-row steps each blockIdx.y slice reduces
+    int steps_per_split;  // token steps each split reduces
+    int tiles;            // output tiles; grid = tiles * splits workgroups, split-major
     const float* s1;      // optional device scalar (activation scale)
     // weight fake-quant STE mask, recomputed from the fp32 weight and its qparams:
     const float* W;       // optional fp32 [N, ldc]
@@ -523,7 +543,7 @@ __device__ inline bf16x8 tr_frag(const char* img, int row0, int col0, int lane) 
 }
 
 // Output tile 128 (N) x BKW (Kw), WM x WNK waves each (16*TM) x (16*TNT); BK token rows per step.
-template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK>
+template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK, bool SPREAD = false>
 __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     constexpr int BN = 128, NW = WM * WNK;
     constexpr int TM = BN / WM / 16;                // 16-row fragments of P per wave
@@ -540,39 +560,47 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNK, wn = wave % WNK;
     const int tilesK = p.Kw / BKW;
-    const int n0 = (blockIdx.x / tilesK) * BN, k0 = (blockIdx.x % tilesK) * BKW;
+    // XCD-aware order: workgroups b and b+8 share an XCD and its L2.  The tiles of one token split read the same P / Q rows, so each
+    // XCD gets a contiguous run of (split, tile) pairs: a split's rows are fetched into one or two L2s instead of all eight
+    // (PMC FETCH_SIZE 2-3.2x the algorithmic bytes with the 2-D grid, L2 hit rate < 20 %: profiles/round1_gemm_pmc_traffic.txt).
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = vb % p.tiles, split = vb / p.tiles;
+    const int n0 = (tile / tilesK) * BN, k0 = (tile % tilesK) * BKW;
     const int total_steps = (p.M + BK - 1) / BK;
-    const int s_begin = blockIdx.y * p.steps_per_split;
+    const int s_begin = split * p.steps_per_split;
     const int s_end = min(total_steps, s_begin + p.steps_per_split);
     const int nsteps = s_end - s_begin;
 
-    const __amdgpu_buffer_rsrc_t rP0 = make_rsrc(p.P0, (int64_t)p.M * p.ldp * 2);
-    const __amdgpu_buffer_rsrc_t rP1 = make_rsrc(p.P1, (int64_t)p.M * p.ldp * 2);
-    const __amdgpu_buffer_rsrc_t rQ0 = make_rsrc(p.Q0, (int64_t)p.M * p.ldq * 2);
-    const __amdgpu_buffer_rsrc_t rQ1 = make_rsrc(TQ == 2 ? p.Q1 : p.Q0, (int64_t)p.M * p.ldq * 2);
+    const v4i32 rP0 = make_rsrc_v(p.P0, (int64_t)p.M * p.ldp * 2);
+    const v4i32 rP1 = make_rsrc_v(p.P1, (int64_t)p.M * p.ldp * 2);
+    const v4i32 rQ0 = make_rsrc_v(p.Q0, (int64_t)p.M * p.ldq * 2);
+    const v4i32 rQ1 = make_rsrc_v(TQ == 2 ? p.Q1 : p.Q0, (int64_t)p.M * p.ldq * 2);
 
-    auto issue = [&](int s) {
+    // DMA group c of k-step s for this wave: c < PP -> its c-th P piece (hi and lo image), else its (c-PP)-th Q piece (both images)
+    constexpr int NGRP = PP + PQ;
+    auto issue_group = [&](int s, int c) {
         char* st = smem + (s % NSTAGE) * STAGE;
         const int mrow0 = (s_begin + s) * BK;
-#pragma unroll
-        for (int c = 0; c < PP; ++c) {
+        if (c < PP) {
             const int piece = wave * PP + c;
             const int row = piece * 4 + (lane >> 4);           // 4 rows of 256 B per piece
             const int src_chunk = (lane & 15) ^ tn_sw(row);
             const uint32_t offP = (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + src_chunk * 8) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rP0, (lds_void*)(st + piece * 1024), 16, offP, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rP1, (lds_void*)(st + IMGP + piece * 1024), 16, offP, 0, 0, 0);
-        }
-#pragma unroll
-        for (int c = 0; c < PQ; ++c) {
-            const int piece = wave * PQ + c;
+            dma16_asm(rP0, st + piece * 1024, offP);
+            dma16_asm(rP1, st + IMGP + piece * 1024, offP);
+        } else {
+            const int piece = wave * PQ + (c - PP);
             const int L = piece * 64 + lane;                   // linear 16-B chunk index inside the image
             const int row = L / QCH, cp = L % QCH;
             const int src_chunk = cp ^ tn_sw(row);
             const uint32_t offQ = (uint32_t)(((int64_t)(mrow0 + row) * p.ldq + k0 + src_chunk * 8) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ0, (lds_void*)(st + 2 * IMGP + piece * 1024), 16, offQ, 0, 0, 0);
-            if constexpr (TQ == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ1, (lds_void*)(st + 2 * IMGP + IMGQ + piece * 1024), 16, offQ, 0, 0, 0);
+            dma16_asm(rQ0, st + 2 * IMGP + piece * 1024, offQ);
+            if constexpr (TQ == 2) dma16_asm(rQ1, st + 2 * IMGP + IMGQ + piece * 1024, offQ);
         }
+    };
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int c = 0; c < NGRP; ++c) issue_group(s, c);
     };
 
     f32x4 acc[TM][TNT];
@@ -580,7 +608,7 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = p.dbias != nullptr && (blockIdx.x % tilesK) == 0 && wn == 0;  // wave-uniform
+    const bool do_bias = p.dbias != nullptr && (tile % tilesK) == 0 && wn == 0;  // wave-uniform
     f32x4 accb[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -597,7 +625,9 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + NSTAGE - 1 < nsteps) issue(s + NSTAGE - 1);
+        const bool more = s + NSTAGE - 1 < nsteps;
+        constexpr int NSLOT = (BK / 32) * TM;              // MFMA groups per k-step: the next tile's DMA issue can be spread between them
+        if (!SPREAD && more) issue(s + NSTAGE - 1);
         const char* st = smem + (s % NSTAGE) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -608,6 +638,11 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
                 for (int j = 0; j < TNT; ++j) qf[t][j] = tr_frag<QROWB>(st + 2 * IMGP + t * IMGQ, 32 * kk, wn * (16 * TNT) + 16 * j, lane);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                if (SPREAD && more) {
+#pragma unroll
+                    for (int c = 0; c < NGRP; ++c)
+                        if ((c * NSLOT) / NGRP == kk * TM + i) issue_group(s + NSTAGE - 1, c);
+                }
                 const bf16x8 ph = tr_frag<PROWB>(st, 32 * kk, wm * (16 * TM) + 16 * i, lane);
                 const bf16x8 pl = tr_frag<PROWB>(st + IMGP, 32 * kk, wm * (16 * TM) + 16 * i, lane);
                 if (do_bias) {
@@ -670,19 +705,20 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
         return 1;
     }
     TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), reinterpret_cast<const __bf16*>(Q_hi),
-             reinterpret_cast<const __bf16*>(Q_lo), C, M, N, Kw, ldp, ldq, ldc, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, 0, row_div};
+             reinterpret_cast<const __bf16*>(Q_lo), C, M, N, Kw, ldp, ldq, ldc, 0, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, 0, row_div};
     static const int tn_abl = getenv("QATVIT_TN_ABL") ? atoi(getenv("QATVIT_TN_ABL")) : 0;
     a.abl = tn_abl;
     // Kw-panel-wide tiles (128 x 384) read the heavy operand P = dY (hi, lo) once per N tile when Kw = 384; every Kw of
     // ViT-S/B (384, 1536, 768, 3072) is a multiple of 384.  QATVIT_TN_WIDE=0 forces the 128 x 128 tile (tuning).
     static const int wide_env = getenv("QATVIT_TN_WIDE") ? atoi(getenv("QATVIT_TN_WIDE")) : 1;
-    // (measured at B=256: wide wins for a grid Q operand, 161/191 us vs 169/225; with a split Q the 32-row steps it
-    //  then needs lose, 131 vs 91 us - so only wide_env == 2 forces it there)
-    const bool wide = (wide_env == 2 || (wide_env == 1 && !Q_lo)) && (Kw % 384 == 0);
+    // (measured at B=256: wide wins for a grid Q operand, 110/133 us vs 113/148; with a split Q (32-row steps) it wins when there
+    //  are enough wide tiles - fc2 wgrad, 12 tiles: 169 vs 181 us - and loses when few tiles mean many splits, each adding a full
+    //  tile of fp32 atomics - proj wgrad, 3 tiles: 84 vs 56 us; wide_env == 2 forces it)
+    const bool wide = (Kw % 384 == 0) && (wide_env == 2 || (wide_env == 1 && (!Q_lo || (N / 128) * (Kw / 384) >= 8)));
     const int bk = (wide && Q_lo) ? 32 : 64;        // the split-Q wide stage only fits with 32-row steps
     const int steps = (M + bk - 1) / bk;
     const int tiles = (N / 128) * (Kw / (wide ? 384 : 128));
-    // Split the token reduction over blockIdx.y so that the grid fills the 256 CUs once.
+    // Split the token reduction so that the grid fills the 256 CUs once.
     // (the 128-160 KiB stage ring admits ONE workgroup per CU, so one round of <= 256 long-running workgroups beats two rounds
     //  of short ones: same MFMA time, half the prologues and half the fp32 atomics of the epilogue, which run at ~1.3 TB/s chip-wide)
     int splits = 256 / tiles;
@@ -691,13 +727,21 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     if (splits < 1) splits = 1;
     a.steps_per_split = (steps + splits - 1) / splits;
     splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
-    dim3 grid(tiles, splits);
+    a.tiles = tiles;
+    const int grid = tiles * splits;
+    static const int tn_spread = getenv("QATVIT_TN_SPREAD") ? atoi(getenv("QATVIT_TN_SPREAD")) : 0;
 #define QV_TN_LAUNCH(TQ_, NS_, WM_, WNK_, TNT_, BK_)                                                               \
     do {                                                                                                           \
         constexpr size_t lds = (size_t)NS_ * (2 * BK_ * 256 + TQ_ * BK_ * (WNK_ * TNT_ * 32));                      \
-        static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_>, lds), true);                      \
-        (void)once;                                                                                                \
-        k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);                          \
+        if (tn_spread) {                                                                                           \
+            static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, true>, lds), true);            \
+            (void)once;                                                                                            \
+            k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, true><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);                \
+        } else {                                                                                                   \
+            static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, false>, lds), true);           \
+            (void)once;                                                                                            \
+            k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, false><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);               \
+        }                                                                                                          \
     } while (0)
     if (wide) {
         if (Q_lo) QV_TN_LAUNCH(2, 2, 2, 4, 6, 32);   // 2 x (16 + 48) KiB = 128 KiB
