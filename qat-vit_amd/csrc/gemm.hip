@@ -88,6 +88,7 @@ struct NTArgs {
     int stat_slots;          // number of 128-B-spaced accumulator pairs (power of two; 1 = a single pair)
     // Optional fused consumer (fc2 dgrad -> GELU backward): instead of storing C, store the (hi, lo) bf16 pair of
     //   C * gelu'(fq(Y)) * mask(Y) * post_colscale[col],  Y = the pre-FQ fc1 output [M,ldc], post_qp = {scale, 1/scale, zp, enabled}
+    int post_gelu_fwd;       // 1: store (hi, lo) of gelu(C) to out_hi / out_lo instead of C (no Y, no mask)
     const float* postY;
     const float* post_qp;
     int post_qmin, post_qmax;
@@ -171,6 +172,18 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
                         if (use_lut) dg = sLut[(int)(fminf(fmaxf(t, fmin_), fmax_) - fmin_)];
                         else dg = gelu_bwd(qon != 0.f ? (fminf(fmaxf(t, fmin_), fmax_) - qzp) * qs : yv[e]);
                         const float o = in ? cv[e] * dg * sv[e] : 0.f;
+                        oh[e] = (__bf16)o;
+                        ol[e] = (__bf16)(o - (float)oh[e]);
+                    }
+                    *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
+                    *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
+                } else if (p.post_gelu_fwd) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    const float cv[4] = {v.x, v.y, v.z, v.w};
+                    bf16x4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float o = gelu_fwd(cv[e]);
                         oh[e] = (__bf16)o;
                         ol[e] = (__bf16)(o - (float)oh[e]);
                     }
@@ -395,8 +408,12 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
              reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
-             nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
-    if (post) {
+             0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+    if (post && !post->Y) {
+        a.post_gelu_fwd = 1;
+        a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
+        if (!a.out_hi || !a.out_lo) { set_error("gemm_nt: fused GELU epilogue needs out_hi / out_lo"); return 1; }
+    } else if (post) {
         a.postY = post->Y; a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.post_colscale = post->colscale;
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
         if (!a.postY || !a.post_qp || !a.out_hi || !a.out_lo) { set_error("gemm_nt: incomplete fused GELU-backward epilogue arguments"); return 1; }
@@ -406,6 +423,14 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     if (B_lo) {  // float x float (teacher): A must be split too; 128 x 128 tile, 8 waves, 2 stages x 64 KiB
         if (!A_lo) { set_error("gemm_nt: a split B operand needs a split A operand"); return 1; }
+        static const int tall2 = getenv("QATVIT_NT_TALL2") ? atoi(getenv("QATVIT_NT_TALL2")) : 1;
+        if (tall2 && N % 384 == 0 && K % 32 == 0) {   // 208 x 384 tall tile, both operands split: 2 stages x (2 x 208 + 2 x 384) x 64 B = 148 KiB
+            constexpr size_t ldst = 2 * (2 * 208 + 2 * 384) * 64;
+            static bool once = (allow_lds(k_gemm_nt<2, 2, 1, 13, 2, 0, 8, 3, 32>, ldst), true);
+            (void)once;
+            k_gemm_nt<2, 2, 1, 13, 2, 0, 8, 3, 32><<<cdiv(M, 208) * (N / 384), 512, ldst, st>>>(a);
+            return 0;
+        }
         constexpr size_t lds = 2 * 4 * 16384;
         static bool once = (allow_lds(k_gemm_nt<2, 2, 4, 2, 2>, lds), true);
         (void)once;

@@ -27,6 +27,8 @@ int launch_qparams(uint32_t* ws, float* running_min, float* running_max, float* 
 
 // fused consumer of an NT GEMM: store split(C * gelu'(fq(Y)) * mask(Y) * colscale[col]) instead of C (fc2 dgrad -> GELU backward)
 struct NTPost {
+    // mode 1 (Y != nullptr): store (hi, lo) of C * gelu'(fq(Y)) * mask(Y) * colscale   (fc2 dgrad -> GELU backward)
+    // mode 2 (Y == nullptr): store (hi, lo) of gelu(C)                                  (teacher fc1 -> GELU forward)
     const float* Y;         // pre-FQ tensor, same [M, ldc] geometry as C
     const float* qp;        // {scale, 1/scale, zp, enabled}
     int qmin, qmax;

@@ -373,8 +373,12 @@ int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* con
         if (gemm(V(p.O_hi), V(p.O_lo), w0 + 1, bprm(i, 5), F(p.Y), (int)M, D, D)) return 1;
         k_resid_ln_split<1><<<rows_grid_t(M), 256, 0, st>>>(x, F(p.Y), nullptr, nullptr, x2, bprm(i, 6), bprm(i, 7), c.ln_eps, H16(p.h_hi),
                                                             H16(p.h_lo), M, D, T);
-        if (gemm(V(p.h_hi), V(p.h_lo), w0 + 2, bprm(i, 9), F(p.Y1), (int)M, Hd, D)) return 1;
-        k_gelu_split<<<flat_grid_t(M * Hd / 4), 256, 0, st>>>(F(p.Y1), H16(p.G_hi), H16(p.G_lo), M * Hd / 4);
+        {   // fc1 with GELU + hi/lo split in the GEMM epilogue (the fp32 [M, Hd] tensor never exists)
+            NTPost post{nullptr, nullptr, 0, 0, nullptr, V(p.G_hi), V(p.G_lo)};
+            if (launch_gemm_nt(V(p.h_hi), V(p.h_lo), w_hi[w0 + 2], nullptr, (int)M, Hd, D, D, D, Hd, nullptr, nullptr, nullptr, bprm(i, 9), nullptr, 1, st,
+                               w_lo[w0 + 2], &post))
+                return 1;
+        }
         if (gemm(V(p.G_hi), V(p.G_lo), w0 + 3, bprm(i, 11), F(p.Y), (int)M, D, Hd)) return 1;
         const bool last = (i + 1 == c.depth);
         // the next block's norm1 (for the last block the pair is unused: the head normalises the cls rows itself)
