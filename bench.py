@@ -219,10 +219,20 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         }
         tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        traffic, traffic_note = None, None
+        try:   # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh, B=256 shapes)
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_gemm_pmc_traffic_tall.json")))
+            per = [v for k, v in pm.items() if "k_gemm_nt<2, 3, 1, 13" in k][0]       # proj, fc2 fwd, qkv dgrad, fc1 dgrad, fc2 dgrad
+            mix = [per[0], per[1], per[2], per[0], per[3], per[4]]                      # + proj dgrad (= proj forward's shape)
+            if args.batch == 256 and args.student == "vit_small":
+                traffic = round(sum(x["fetch_MB"] + x["write_MB"] for x in mix) / len(mix) * 1e6)
+                traffic_note = "mean FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch over the kernel's six uses, separate --pmc passes: profiles/round1_gemm_pmc_traffic_tall.json"
+        except Exception:  # noqa: BLE001
+            pass
         res["roofline"] = {
-            "bound": "mfma", "kernel": "qv::k_gemm_nt, split-bf16 A operand (proj/fc2 forward + all dgrads; 128x384 tiles when N%384==0; "
+            "bound": "mfma", "kernel": "qv::k_gemm_nt<2,3,1,13,1,0,8,3,32>, split-bf16 A operand (proj/fc2 forward + all dgrads; 208x384 tiles; "
                                        "the largest single kernel of the step)",
-            "achieved": round(tflops, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "achieved": round(tflops, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
             "launches": cnt.value, "avg_us_per_launch": round(1e3 * ms.value / max(1, cnt.value), 1),
             "note": "algorithmic FLOPs 2*M*N*K per launch / HIP-event time of that launch inside the timed steps; every launch issues two "
                     "bf16 MFMA passes (hi and lo), so issued MFMA work is 2x this figure",
