@@ -415,12 +415,12 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dx0
 
 // ---------------------------------------------------------------- weight fake-quant -> GEMM operands
 // wq[n][k] = q(W[n][k]) - zp (bf16), wqT[k][n] = same, transposed (dgrad's B operand)
-__global__ __launch_bounds__(256) void k_wquant(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
-                                                __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K) {
+__device__ inline void wquant_body(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
+                                   __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K, int bx, int by) {
     // 32x32 tile transpose through LDS
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int n0 = by * 32, k0 = bx * 32;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + ty + 8 * i, k = k0 + tx;
@@ -440,6 +440,17 @@ __global__ __launch_bounds__(256) void k_wquant(const float* __restrict__ W, con
             if (n < N && k < K) wqT[(int64_t)k * N + n] = (__bf16)tile[tx][ty + 8 * i];
         }
     }
+}
+__global__ __launch_bounds__(256) void k_wquant(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
+                                                __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K) {
+    wquant_body(W, qp, per_channel, qmin, qmax, wq, wqT, N, K, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void k_w_quant_all(const WQuantTab t) {
+    int wi = 0;
+    while (wi + 1 < t.n && (int)blockIdx.x >= t.blk0[wi + 1]) ++wi;
+    const int b = blockIdx.x - t.blk0[wi], kt = (t.K[wi] + 31) / 32;
+    wquant_body(t.W[wi], t.qp[wi], t.per_channel, t.qmin, t.qmax, reinterpret_cast<__bf16*>(t.wq[wi]), reinterpret_cast<__bf16*>(t.wqT[wi]), t.N[wi],
+                t.K[wi], b % kt, b / kt);
 }
 
 // ============================================================================ launchers
@@ -521,6 +532,16 @@ int launch_embed_bwd(const float* dx0, const float* Y0, const float* qp, int qmi
     return 0;
 }
 
+int launch_w_quant_all(WQuantTab& t, hipStream_t st) {
+    int b = 0;
+    for (int i = 0; i < t.n; ++i) {
+        t.blk0[i] = b;
+        b += (int)(cdiv(t.K[i], 32) * cdiv(t.N[i], 32));
+    }
+    t.blk0[t.n] = b;
+    k_w_quant_all<<<b, 256, 0, st>>>(t);
+    return 0;
+}
 int launch_wquant(const float* W, const float* qp, int per_channel, int qmin, int qmax, void* wq, void* wqT, int N, int K, hipStream_t st) {
     dim3 grid(cdiv(K, 32), cdiv(N, 32));
     k_wquant<<<grid, 256, 0, st>>>(W, qp, per_channel, qmin, qmax, reinterpret_cast<__bf16*>(wq), reinterpret_cast<__bf16*>(wqT), N, K);

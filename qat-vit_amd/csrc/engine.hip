@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "../../include/qatvit.h"
+#include <stdlib.h>
+
 #include "qv_common.h"
 #include "qv_kernels.h"
 
@@ -225,16 +227,43 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
     const qatvit_cfg& c = x.c;
     hipStream_t st = x.st;
     const int qa = c.act_qmin, qb = c.act_qmax;
-    // ---- weights: observe, qparams, integer operands (row-major and transposed)
-    for (int wi = 0; wi < d.n_w; ++wi) {
-        int N, K; wshape(d, wi, &N, &K);
-        const qatvit_fq& f = x.wfq[wi];
-        const float* W = x.prm(wparam(d, wi));
-        uint32_t* ws = x.at<uint32_t>(p.stats) + p.w_stats[wi];
-        launch_minmax(W, c.w_per_channel ? N : 1, c.w_per_channel ? K : (int64_t)N * K, c.w_per_channel, ws, kStatSlots, st);
-        launch_qparams(ws, f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const, c.w_qmin, c.w_qmax,
-                       c.w_per_channel ? N : 1, 1, x.w_qp(wi), 1, c.w_per_channel ? 1 : kStatSlots, st);
-        launch_wquant(W, x.w_qp(wi), c.w_per_channel, c.w_qmin, c.w_qmax, x.at<void>(p.w_off[wi]), x.at<void>(p.wT_off[wi]), N, K, st);
+    // ---- weights: observe, qparams, integer operands (row-major and transposed) - all 50 tensors in three launches
+    static const int wbatch = getenv("QATVIT_WBATCH") ? atoi(getenv("QATVIT_WBATCH")) : 1;   // 0: one launch triple per weight (tuning)
+    if (wbatch && d.n_w <= kMaxW) {
+        WObsTab to{};
+        WQpTab tq{};
+        WQuantTab tw{};
+        to.n = tq.n = tw.n = d.n_w;
+        to.per_channel = tq.per_channel = tw.per_channel = c.w_per_channel;
+        to.nslots = tq.nslots = kStatSlots;
+        tq.qmin = tw.qmin = c.w_qmin; tq.qmax = tw.qmax = c.w_qmax; tq.c = c.averaging_const;
+        for (int wi = 0; wi < d.n_w; ++wi) {
+            int N, K; wshape(d, wi, &N, &K);
+            const qatvit_fq& f = x.wfq[wi];
+            uint32_t* ws = x.at<uint32_t>(p.stats) + p.w_stats[wi];
+            to.W[wi] = tw.W[wi] = x.prm(wparam(d, wi));
+            to.ws[wi] = tq.ws[wi] = ws;
+            to.N[wi] = tq.N[wi] = tw.N[wi] = N;
+            to.K[wi] = tw.K[wi] = K;
+            tq.rmin[wi] = f.min_val; tq.rmax[wi] = f.max_val; tq.scale[wi] = f.scale; tq.zp[wi] = f.zero_point;
+            tq.obs_on[wi] = f.observer_on; tq.fq_on[wi] = f.fake_quant_on;
+            tq.qp[wi] = x.w_qp(wi); tw.qp[wi] = x.w_qp(wi);
+            tw.wq[wi] = x.at<void>(p.w_off[wi]); tw.wqT[wi] = x.at<void>(p.wT_off[wi]);
+        }
+        launch_w_observe_all(to, st);
+        launch_w_qparams_all(tq, st);
+        launch_w_quant_all(tw, st);
+    } else {
+        for (int wi = 0; wi < d.n_w; ++wi) {
+            int N, K; wshape(d, wi, &N, &K);
+            const qatvit_fq& f = x.wfq[wi];
+            const float* W = x.prm(wparam(d, wi));
+            uint32_t* ws = x.at<uint32_t>(p.stats) + p.w_stats[wi];
+            launch_minmax(W, c.w_per_channel ? N : 1, c.w_per_channel ? K : (int64_t)N * K, c.w_per_channel, ws, kStatSlots, st);
+            launch_qparams(ws, f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const, c.w_qmin, c.w_qmax,
+                           c.w_per_channel ? N : 1, 1, x.w_qp(wi), 1, c.w_per_channel ? 1 : kStatSlots, st);
+            launch_wquant(W, x.w_qp(wi), c.w_per_channel, c.w_qmin, c.w_qmax, x.at<void>(p.w_off[wi]), x.at<void>(p.wT_off[wi]), N, K, st);
+        }
     }
     // ---- input image FQ + patch rows
     launch_minmax(images, 1, (int64_t)d.B * d.chans * d.img * d.img, 0, x.act_stats(A_IN), kStatSlots, st);

@@ -25,17 +25,18 @@ __global__ void k_ws_init(uint32_t* ws, int64_t channels) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_minmax_tensor(const float* __restrict__ x, int64_t n, uint32_t* ws, int nslots) {
+// body of the per-tensor min/max pass for (virtual) block `blk` of `nblk`
+__device__ inline void minmax_tensor_body(const float* __restrict__ x, int64_t n, uint32_t* ws, int nslots, int blk, int nblk) {
     float mn = INFINITY, mx = -INFINITY;
     const int64_t n4 = n >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t stride = (int64_t)nblk * blockDim.x;
+    for (int64_t i = blk * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 v = x4[i];
         mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
         mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    if (blk == 0 && threadIdx.x < (n & 3)) {
         float v = x[(n4 << 2) + threadIdx.x];
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
@@ -52,11 +53,14 @@ __global__ __launch_bounds__(256) void k_minmax_tensor(const float* __restrict__
         stat_atomic(ws, nslots, mn, mx);
     }
 }
+__global__ __launch_bounds__(256) void k_minmax_tensor(const float* __restrict__ x, int64_t n, uint32_t* ws, int nslots) {
+    minmax_tensor_body(x, n, ws, nslots, blockIdx.x, gridDim.x);
+}
 
 // per-channel (rows of `inner` contiguous floats): one wave per row, 4 rows per block
-__global__ __launch_bounds__(256) void k_minmax_rows(const float* __restrict__ x, int64_t channels, int64_t inner, uint32_t* ws) {
+__device__ inline void minmax_rows_body(const float* __restrict__ x, int64_t channels, int64_t inner, uint32_t* ws, int blk) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    const int64_t row = (int64_t)blk * 4 + w;
     if (row >= channels) return;
     const float* p = x + row * inner;
     float mn = INFINITY, mx = -INFINITY;
@@ -80,6 +84,20 @@ __global__ __launch_bounds__(256) void k_minmax_rows(const float* __restrict__ x
         ws[2 * row] = f2ord(mn);
         ws[2 * row + 1] = f2ord(mx);
     }
+}
+__global__ __launch_bounds__(256) void k_minmax_rows(const float* __restrict__ x, int64_t channels, int64_t inner, uint32_t* ws) {
+    minmax_rows_body(x, channels, inner, ws, blockIdx.x);
+}
+// which table entry does flat block b belong to (entries are few: linear scan, wave-uniform)
+__device__ inline int tab_find(const int* blk0, int n, int b) {
+    int wi = 0;
+    while (wi + 1 < n && b >= blk0[wi + 1]) ++wi;
+    return wi;
+}
+__global__ __launch_bounds__(256) void k_w_observe_all(const WObsTab t) {
+    const int wi = tab_find(t.blk0, t.n, blockIdx.x), blk = blockIdx.x - t.blk0[wi], nblk = t.blk0[wi + 1] - t.blk0[wi];
+    if (t.per_channel) minmax_rows_body(t.W[wi], t.N[wi], t.K[wi], t.ws[wi], blk);
+    else minmax_tensor_body(t.W[wi], (int64_t)t.N[wi] * t.K[wi], t.ws[wi], t.nslots, blk, nblk);
 }
 
 // ------------------------------------------------------------------ phase 2: qparams
@@ -135,13 +153,13 @@ __device__ inline float ema(float running, float cur, float c) {
     return __fadd_rn(running, __fmul_rn(c, __fsub_rn(cur, running)));
 }
 
-__global__ void k_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point,
-                          const int64_t* observer_on, const int64_t* fake_quant_on, float c, int qmin, int qmax,
-                          int64_t channels, int symmetric, float* qp_out, int reset_ws, int nslots) {
+__device__ inline void qparams_body(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point,
+                                    const int64_t* observer_on, const int64_t* fake_quant_on, float c, int qmin, int qmax,
+                                    int64_t channels, int symmetric, float* qp_out, int reset_ws, int nslots, int blk) {
     // Per-tensor (nslots > 1, channels == 1): launched with one 64-lane wave; lane s folds accumulator pair s (one parallel
     // round of loads instead of a dependent chain - this kernel sits on the critical path between a producer and its consumer).
     // Per-channel: one thread per channel, a single pair each.
-    const int64_t i = nslots > 1 ? 0 : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t i = nslots > 1 ? 0 : blk * (int64_t)blockDim.x + threadIdx.x;
     uint32_t omn, omx;
     if (nslots > 1) {
         const int l = threadIdx.x;
@@ -188,6 +206,17 @@ __global__ void k_qparams(uint32_t* ws, float* running_min, float* running_max, 
         qp_out[4 * i + 2] = (float)z;
         qp_out[4 * i + 3] = (*fake_quant_on != 0) ? 1.f : 0.f;
     }
+}
+__global__ void k_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point,
+                          const int64_t* observer_on, const int64_t* fake_quant_on, float c, int qmin, int qmax,
+                          int64_t channels, int symmetric, float* qp_out, int reset_ws, int nslots) {
+    qparams_body(ws, running_min, running_max, scale, zero_point, observer_on, fake_quant_on, c, qmin, qmax, channels, symmetric, qp_out, reset_ws,
+                 nslots, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_w_qparams_all(const WQpTab t) {
+    const int wi = tab_find(t.blk0, t.n, blockIdx.x), blk = blockIdx.x - t.blk0[wi];
+    qparams_body(t.ws[wi], t.rmin[wi], t.rmax[wi], t.scale[wi], t.zp[wi], t.obs_on[wi], t.fq_on[wi], t.c, t.qmin, t.qmax,
+                 t.per_channel ? t.N[wi] : 1, 1, t.qp[wi], 1, t.per_channel ? 1 : t.nslots, blk);
 }
 
 // ------------------------------------------------------------------ phase 3: quantize
@@ -327,6 +356,27 @@ int launch_qparams(uint32_t* ws, float* running_min, float* running_max, float* 
                    int nslots, hipStream_t st) {
     k_qparams<<<cdiv(channels, 64), 64, 0, st>>>(ws, running_min, running_max, scale, zero_point, observer_on, fake_quant_on, c, qmin, qmax,
                                                   channels, symmetric, qp_out, reset_ws, nslots);
+    return 0;
+}
+
+int launch_w_observe_all(WObsTab& t, hipStream_t st) {
+    int b = 0;
+    for (int i = 0; i < t.n; ++i) {
+        t.blk0[i] = b;
+        b += t.per_channel ? (int)cdiv(t.N[i], 4) : stream_grid(((int64_t)t.N[i] * t.K[i]) >> 4);
+    }
+    t.blk0[t.n] = b;
+    k_w_observe_all<<<b, 256, 0, st>>>(t);
+    return 0;
+}
+int launch_w_qparams_all(WQpTab& t, hipStream_t st) {
+    int b = 0;
+    for (int i = 0; i < t.n; ++i) {
+        t.blk0[i] = b;
+        b += t.per_channel ? (int)cdiv(t.N[i], 64) : 1;
+    }
+    t.blk0[t.n] = b;
+    k_w_qparams_all<<<b, 64, 0, st>>>(t);
     return 0;
 }
 

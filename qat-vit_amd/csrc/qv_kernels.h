@@ -66,6 +66,17 @@ int launch_head_bwd(const float* dlogits, const float* logits_pre, const float* 
                     float* dbias, float* dh, int B, int D, int C, hipStream_t st);
 int launch_embed_bwd(const float* dx0, const float* Y0, const float* qp, int qmin, int qmax, float* dpos, float* dcls, void* dY0_hi, void* dY0_lo,
                      int B, int T, int D, hipStream_t st);
+// ---- all weights of the step at once (three launches instead of three per weight): tables passed by value as kernel arguments
+constexpr int kMaxW = 52;   // patch-embed + 4 per block (depth <= 12) + head, with slack
+struct WObsTab { const float* W[kMaxW]; uint32_t* ws[kMaxW]; int N[kMaxW], K[kMaxW], blk0[kMaxW + 1]; int n, per_channel, nslots; };
+struct WQpTab {
+    uint32_t* ws[kMaxW]; float* rmin[kMaxW]; float* rmax[kMaxW]; float* scale[kMaxW]; int32_t* zp[kMaxW]; float* qp[kMaxW];
+    const int64_t* obs_on[kMaxW]; const int64_t* fq_on[kMaxW]; int N[kMaxW], blk0[kMaxW + 1]; int n, per_channel, nslots, qmin, qmax; float c;
+};
+struct WQuantTab { const float* W[kMaxW]; const float* qp[kMaxW]; void* wq[kMaxW]; void* wqT[kMaxW]; int N[kMaxW], K[kMaxW], blk0[kMaxW + 1]; int n, per_channel, qmin, qmax; };
+int launch_w_observe_all(WObsTab& t, hipStream_t st);      // fills blk0
+int launch_w_qparams_all(WQpTab& t, hipStream_t st);       // fills blk0
+int launch_w_quant_all(WQuantTab& t, hipStream_t st);      // fills blk0
 int launch_wquant(const float* W, const float* qp, int per_channel, int qmin, int qmax, void* wq, void* wqT, int N, int K, hipStream_t st);
 
 // ---- attn.hip
