@@ -104,12 +104,16 @@ int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 /* C[N,Kw] += sum_m (P_hi + P_lo)[m,N] * (Q_hi + Q_lo)[m,Kw] * (*s1) / row_div[n], masked by the weight fake-quant STE
  * mask of W; dbias[N] += sum_m P[m,N] / row_div[n].
  * Replaces: the weight/bias gradient of nnqat.Linear / nnqat.Conv2d (autograd of linear.py:49-50, conv.py:54-55,
- * followed by the weight_fake_quant backward).  C, dbias are accumulated with atomics (caller zeroes).
- * Q_lo, s1, W (fp32 [N,Kw], with w_scale/w_zp [1] or [N]), dbias, row_div may be NULL.  N % 128 == 0, Kw % 128 == 0. */
+ * followed by the weight_fake_quant backward).  The token reduction is split over up to 256 workgroups.  With
+ * scratch = NULL the splits add into C with fp32 atomics (caller zeroes C; bit patterns vary run to run).  With a device
+ * scratch buffer of qatvit_gemm_tn_scratch_bytes() the splits store raw partial tiles there and a second launch sums
+ * them in a fixed order, applies scale and mask and adds to C: no atomics on C, bit-reproducible.  dbias always uses
+ * atomics.  Q_lo, s1, W (fp32 [N,Kw], with w_scale/w_zp [1] or [N]), dbias, row_div may be NULL.  N % 128 == 0, Kw % 128 == 0. */
+int64_t qatvit_gemm_tn_scratch_bytes(void);
 int qatvit_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int32_t M, int32_t N,
                    int32_t Kw, int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale,
                    const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias,
-                   const float* row_div, void* stream);
+                   const float* row_div, float* scratch, int64_t scratch_bytes, void* stream);
 
 /* Attention core between attn.qkv and attn.proj (timm Attention; no fake-quant inside).
  *  qkv: PRE-fake-quant fp32 [B*T, 3*D]; qp: {scale, 1/scale, zero_point, enabled} of the qkv activation FQ

@@ -68,7 +68,7 @@ struct Plan {
     int64_t blk_stride;
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
-    int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo;
+    int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo, tn_scratch;
     int64_t total, stats_words;
     int TP;
 };
@@ -133,6 +133,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->delta = take((int64_t)d.B * d.H * p->TP * 4);
     p->dh = take((int64_t)d.B * D * 4);
     p->dY0_hi = take((int64_t)d.B * d.np * D * 2); p->dY0_lo = take((int64_t)d.B * d.np * D * 2);
+    p->tn_scratch = take(kTnScratchBytes);   // split partials of the weight-gradient GEMMs (two-phase, non-atomic reduction)
     p->total = o;
     return 0;
 }
@@ -217,7 +218,7 @@ struct Ctx {
         const qatvit_fq& f = wfq[wi];
         ProfScope ps(3, 2.0 * M * N * K, st);
         return launch_gemm_tn(dY_hi, dY_lo, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
-                              c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st);
+                              c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
     }
 };
 

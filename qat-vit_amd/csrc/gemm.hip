@@ -549,6 +549,7 @@ struct TNArgs {
     float* dbias;         // optional [N]: += sum_m P[m, n]  (bias gradient, ones-fragment MFMA)
     int abl;              // timing-only ablation (tools/bench_gemm.py): 1 = skip the atomic epilogue
     const float* row_div; // optional [N]: results (and dbias) are divided by row_div[n] (P was pre-multiplied by the per-channel weight scale)
+    float* partial;       // optional scratch [splits][tiles][tile elements]: splits store raw accumulators here, k_tn_reduce sums them in order
 };
 
 template <int ROWB>  // ROWB: bytes per LDS row of the image (256 for a 128-column tile, 768 for a 384-column tile)
@@ -694,6 +695,25 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     }
     const float alpha = p.s1 ? *p.s1 : 1.f;
     const int r = lane & 15, g = lane >> 4;
+    if (p.partial) {
+        // raw accumulators in their register layout, one float4 per lane per fragment: 1-KiB coalesced stores, no atomics;
+        // scale / mask / accumulate happen once per element in k_tn_reduce (fixed summation order: bit-reproducible)
+        float4* dst = reinterpret_cast<float4*>(p.partial) + ((int64_t)vb * NW + wave) * (TM * TNT * 64);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) dst[(i * TNT + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (do_bias && r == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + wm * (16 * TM) + 16 * i + 4 * g + e;
+                    if (n < p.N) atomicAdd(&p.dbias[n], accb[i][e] * (p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f));
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -722,15 +742,50 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     }
 }
 
+// Second phase of the split wgrad: element (tile, wave, i, j, lane, e) of every split's raw accumulator block, summed over the splits in
+// order, scaled, masked by the weight fake-quant STE mask and added to dW.  One thread per float4 of the accumulator layout.
+__global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, int WM, int WNK, int TM, int TNT) {
+    const int per_wave = TM * TNT * 64, NW = WM * WNK, per_tile = per_wave * NW;
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)p.tiles * per_tile) return;
+    const int tile = (int)(idx / per_tile), rem = (int)(idx % per_tile);
+    const int wave = rem / per_wave, f = (rem % per_wave) / 64, lane = rem & 63;
+    const int i = f / TNT, j = f % TNT, r = lane & 15, g = lane >> 4, wm = wave / WNK, wn = wave % WNK;
+    const float4* src = reinterpret_cast<const float4*>(p.partial) + idx;
+    float4 a = src[0];
+    for (int s = 1; s < splits; ++s) {
+        const float4 b = src[(int64_t)s * p.tiles * per_tile];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int BKW = WNK * TNT * 16, tilesK = p.Kw / BKW;
+    const int n0 = (tile / tilesK) * 128, k0 = (tile % tilesK) * BKW;
+    const int kw = k0 + wn * (16 * TNT) + 16 * j + r;
+    const float alpha = p.s1 ? *p.s1 : 1.f;
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wm * (16 * TM) + 16 * i + 4 * g + e;
+        if (n >= p.N) continue;
+        const float rdiv = p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f;
+        float v = av[e] * (alpha * rdiv);
+        if (p.W) {
+            const int ci = p.w_per_channel ? n : 0;
+            const float q = rintf(p.W[(int64_t)n * p.ldc + kw] * __fdiv_rn(1.0f, p.w_scale[ci])) + (float)p.w_zp[ci];
+            if (!(q >= (float)p.w_qmin && q <= (float)p.w_qmax)) v = 0.f;
+        }
+        p.C[(int64_t)n * p.ldc + kw] += v;
+    }
+}
+
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                    const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
-                   float* dbias, const float* row_div, hipStream_t st) {
+                   float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
     if (M < 1 || N % 128 != 0 || Kw % 128 != 0 || ldp % 8 != 0 || ldq % 8 != 0) {
         set_error("gemm_tn: unsupported shape M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%128==0, ld%%8==0)", M, N, Kw, ldp, ldq);
         return 1;
     }
     TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), reinterpret_cast<const __bf16*>(Q_hi),
-             reinterpret_cast<const __bf16*>(Q_lo), C, M, N, Kw, ldp, ldq, ldc, 0, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, 0, row_div};
+             reinterpret_cast<const __bf16*>(Q_lo), C, M, N, Kw, ldp, ldq, ldc, 0, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, 0, row_div, nullptr};
     static const int tn_abl = getenv("QATVIT_TN_ABL") ? atoi(getenv("QATVIT_TN_ABL")) : 0;
     a.abl = tn_abl;
     // Kw-panel-wide tiles (128 x 384) read the heavy operand P = dY (hi, lo) once per N tile when Kw = 384; every Kw of
@@ -755,9 +810,14 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     a.tiles = tiles;
     const int grid = tiles * splits;
     static const int tn_spread = getenv("QATVIT_TN_SPREAD") ? atoi(getenv("QATVIT_TN_SPREAD")) : 0;
+    static const int tn_atomic = getenv("QATVIT_TN_ATOMIC") ? atoi(getenv("QATVIT_TN_ATOMIC")) : 0;   // 1: fp32 atomics even when scratch is given (tuning)
 #define QV_TN_LAUNCH(TQ_, NS_, WM_, WNK_, TNT_, BK_)                                                               \
     do {                                                                                                           \
         constexpr size_t lds = (size_t)NS_ * (2 * BK_ * 256 + TQ_ * BK_ * (WNK_ * TNT_ * 32));                      \
+        constexpr int tm = 128 / WM_ / 16;                                                                         \
+        const int64_t tile_f4 = (int64_t)WM_ * WNK_ * tm * TNT_ * 64;                                              \
+        const bool two_phase = partial && splits > 1 && tn_atomic == 0 && (int64_t)grid * tile_f4 * 16 <= partial_bytes; \
+        a.partial = two_phase ? partial : nullptr;                                                                 \
         if (tn_spread) {                                                                                           \
             static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, true>, lds), true);            \
             (void)once;                                                                                            \
@@ -767,6 +827,7 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
             (void)once;                                                                                            \
             k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, false><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);               \
         }                                                                                                          \
+        if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, WM_, WNK_, tm, TNT_); \
     } while (0)
     if (wide) {
         if (Q_lo) QV_TN_LAUNCH(2, 2, 2, 4, 6, 32);   // 2 x (16 + 48) KiB = 128 KiB

@@ -41,9 +41,11 @@ struct NTPost {
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
                    const void* B_lo = nullptr, const NTPost* post = nullptr);
+// scratch that lets every wgrad shape take the two-phase (non-atomic, bit-reproducible) reduction: 256 workgroups x the largest tile
+constexpr int64_t kTnScratchBytes = 256ll * 128 * 384 * 4;
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                    const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
-                   float* dbias, const float* row_div, hipStream_t st);
+                   float* dbias, const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st);
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,

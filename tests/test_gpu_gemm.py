@@ -79,13 +79,16 @@ def test_gemm_rejects_bad_shapes(native_lib):
     assert native_lib.qatvit_gemm_nt(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), 64, 64, 64, 64, 64, 64, None, None, None, None, None, None) != 0
     assert b"unsupported shape" in native_lib.qatvit_last_error()
     assert native_lib.qatvit_gemm_tn(x.data_ptr(), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 128, 64, 128, 128, None, None, None,
-                                     None, 0, -128, 127, None, None, None) != 0
+                                     None, 0, -128, 127, None, None, None, 0, None) != 0
     assert b"unsupported shape" in native_lib.qatvit_last_error()
 
 
 @pytest.mark.parametrize("M,N,Kw", [(1576, 1152, 384), (1576, 384, 1536), (70, 128, 128), (1000, 256, 128), (5000, 384, 768)])
 @pytest.mark.parametrize("q_f32", [0, 1])
-def test_gemm_tn(native_lib, M, N, Kw, q_f32):
+@pytest.mark.parametrize("two_phase", [0, 1])
+def test_gemm_tn(native_lib, M, N, Kw, q_f32, two_phase):
+    """two_phase=1: split partials through the scratch buffer + ordered reduction (no atomics on C: bit-reproducible);
+    two_phase=0: fp32 atomics."""
     torch.manual_seed(M + N + Kw + q_f32)
     dev = "cuda"
     P = torch.randn(M, N, device=dev) * 1e-3
@@ -102,9 +105,21 @@ def test_gemm_tn(native_lib, M, N, Kw, q_f32):
     w_zp = torch.zeros(1, dtype=torch.int32, device=dev)
     C = torch.zeros(N, Kw, device=dev)
     db = torch.zeros(N, device=dev)
-    st = native_lib.qatvit_gemm_tn(Ph.data_ptr(), Pl.data_ptr(), Qh.data_ptr(), _ptr(Ql), C.data_ptr(), M, N, Kw, N, Kw, Kw, s1.data_ptr(),
-                                   W.data_ptr(), w_scale.data_ptr(), w_zp.data_ptr(), 0, -128, 127, db.data_ptr(), None, _st())
+    nb = native_lib.qatvit_gemm_tn_scratch_bytes()
+    scratch = torch.empty(nb if two_phase else 16, dtype=torch.uint8, device=dev)
+
+    def run(out):
+        return native_lib.qatvit_gemm_tn(Ph.data_ptr(), Pl.data_ptr(), Qh.data_ptr(), _ptr(Ql), out.data_ptr(), M, N, Kw, N, Kw, Kw, s1.data_ptr(),
+                                         W.data_ptr(), w_scale.data_ptr(), w_zp.data_ptr(), 0, -128, 127, db.data_ptr(), None,
+                                         scratch.data_ptr() if two_phase else None, nb if two_phase else 0, _st())
+
+    st = run(C)
     assert st == 0, native_lib.qatvit_last_error()
+    if two_phase:
+        C2 = torch.zeros_like(C)
+        db.zero_()
+        assert run(C2) == 0
+        assert torch.equal(C, C2)                 # no atomics on C: same bits every run
     inv = (torch.ones(1, device=dev) / w_scale)
     qv = torch.round(W * inv)
     mask = ((qv >= -128) & (qv <= 127)).double()
@@ -128,7 +143,7 @@ def test_gemm_tn_per_channel_mask_and_row_div(native_lib):
     Ph, Pl = split(P * w_scale[None, :])  # the producer folds the per-channel scale in ...
     Qh = Q.to(torch.bfloat16)
     st = native_lib.qatvit_gemm_tn(Ph.data_ptr(), Pl.data_ptr(), Qh.data_ptr(), None, C.data_ptr(), M, N, Kw, N, Kw, Kw, None, W.data_ptr(),
-                                   w_scale.data_ptr(), w_zp.data_ptr(), 1, -128, 127, db.data_ptr(), w_scale.data_ptr(), _st())  # ... row_div takes it out
+                                   w_scale.data_ptr(), w_zp.data_ptr(), 1, -128, 127, db.data_ptr(), w_scale.data_ptr(), None, 0, _st())  # ... row_div takes it out
     assert st == 0, native_lib.qatvit_last_error()
     qv = torch.round(W * (1.0 / w_scale)[:, None])
     mask = ((qv >= -128) & (qv <= 127)).double()

@@ -43,8 +43,10 @@ def tn(q_f32, N, Kw):
     else:
         Qh, Ql = torch.randint(-255, 256, (M, Kw), device=dev).to(torch.bfloat16), None
     C = torch.zeros(N, Kw, device=dev)
+    nb = L.qatvit_gemm_tn_scratch_bytes() if not os.environ.get("TN_NO_SCRATCH") else 0
+    scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
     t = timeit(lambda: L.qatvit_gemm_tn(Ph.data_ptr(), Pl.data_ptr(), Qh.data_ptr(), None if Ql is None else Ql.data_ptr(), C.data_ptr(), M, N, Kw,
-                                        N, Kw, Kw, None, None, None, None, 0, -128, 127, None, None, st))
+                                        N, Kw, Kw, None, None, None, None, 0, -128, 127, None, None, scratch.data_ptr() if nb else None, nb, st))
     passes = 3 if q_f32 else 2
     return t, 2.0 * M * N * Kw / t / 1e6, 2.0 * M * N * Kw * passes / t / 1e6
 
