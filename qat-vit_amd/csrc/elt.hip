@@ -376,30 +376,39 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dlog
                                                   const __bf16* __restrict__ wq, const float* __restrict__ W, const float* __restrict__ w_scale,
                                                   const int32_t* __restrict__ w_zp, int w_per_channel, int w_qmin, int w_qmax,
                                                   float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ dh, int B, int D, int C) {
-    // grid: (C + B) blocks: blocks [0,C) compute dW row c and db[c]; blocks [C, C+B) compute dh row b
+    // grid: C * ceil(D/64) + B blocks: the first group computes dW[c][64-column chunk] (and db[c]); the last B blocks compute dh row b.
+    // dW: 64 columns x 4 batch groups per block, the groups reduced through LDS in a fixed order (no atomics)
     const QP ql = load_qp(qp_logits);
-    if ((int)blockIdx.x < C) {
-        const int c = blockIdx.x;
+    const int kch = (D + 63) / 64;
+    if ((int)blockIdx.x < C * kch) {
+        const int c = blockIdx.x / kch, k = (blockIdx.x % kch) * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
         const float s_norm = qp_norm[0];
         const int ci = w_per_channel ? c : 0;
         const float inv = __fdiv_rn(1.0f, w_scale[ci]), fzp = (float)w_zp[ci];
-        float dbacc = 0.f;
-        for (int k = threadIdx.x; k < D; k += blockDim.x) {
-            float acc = 0.f;
-            for (int b = 0; b < B; ++b) {
+        float acc = 0.f, dbacc = 0.f;
+        const int bper = (B + 3) / 4, b_lo = grp * bper, b_hi = min(B, b_lo + bper);
+        if (k < D) {
+            for (int b = b_lo; b < b_hi; ++b) {
                 bool in;
                 fqv(logits_pre[(int64_t)b * C + c], ql, qmin, qmax, in);
                 const float dl = in ? dlogits[(int64_t)b * C + c] : 0.f;
                 acc += dl * hq[(int64_t)b * D + k];
-                if (k == 0) dbacc += dl;
+                dbacc += dl;
             }
+        }
+        __shared__ float sacc[4][64], sdb[4];
+        sacc[grp][threadIdx.x & 63] = acc;
+        if ((threadIdx.x & 63) == 0) sdb[grp] = dbacc;
+        __syncthreads();
+        if (grp == 0 && k < D) {
+            const float tot = ((sacc[0][threadIdx.x] + sacc[1][threadIdx.x]) + sacc[2][threadIdx.x]) + sacc[3][threadIdx.x];
             const float t = rintf(W[(int64_t)c * D + k] * inv) + fzp;
             const bool win = t >= (float)w_qmin && t <= (float)w_qmax;
-            dW[(int64_t)c * D + k] = win ? acc * s_norm : 0.f;
-            if (k == 0) dbias[c] = dbacc;
+            dW[(int64_t)c * D + k] = win ? tot * s_norm : 0.f;
+            if (k == 0) dbias[c] = ((sdb[0] + sdb[1]) + sdb[2]) + sdb[3];
         }
     } else {
-        const int b = blockIdx.x - C;
+        const int b = blockIdx.x - C * kch;
         for (int k = threadIdx.x; k < D; k += blockDim.x) {
             float acc = 0.f;
             for (int c = 0; c < C; ++c) {
@@ -415,24 +424,37 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dlog
 
 // ---------------------------------------------------------------- embedding backward
 // dx0 [B,T,D] -> dpos[t,:] = sum_b dx0[b,t,:]; dcls = sum_b dx0[b,0,:]; dY0[b*np+p,:] = dx0[b,1+p,:] * mask(Y0)
-__global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dx0, const float* __restrict__ Y0, const float* __restrict__ qp,
-                                                   int qmin, int qmax, float* __restrict__ dpos, float* __restrict__ dcls,
-                                                   __bf16* __restrict__ dY0_hi, __bf16* __restrict__ dY0_lo, int B, int T, int D) {
+__global__ __launch_bounds__(64) void k_embed_bwd(const float* __restrict__ dx0, const float* __restrict__ Y0, const float* __restrict__ qp,
+                                                  int qmin, int qmax, float* __restrict__ dpos, float* __restrict__ dcls,
+                                                  __bf16* __restrict__ dY0_hi, __bf16* __restrict__ dY0_lo, int B, int T, int D) {
+    // one thread per (token, 4 columns), summing over the batch in a fixed order (no atomics); only T*D/4 threads exist, so blocks are one
+    // wave (every CU gets work) and each thread keeps UNR images' loads in flight
     const QP q = load_qp(qp);
     const int d4 = D / 4;
     const int64_t n4 = (int64_t)T * d4;
+    constexpr int UNR = 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(i / d4), c = (int)(i % d4) * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int b = 0; b < B; ++b) {
-            const float4 g = *reinterpret_cast<const float4*>(dx0 + ((int64_t)b * T + t) * D + c);
-            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-            if (t > 0) {
-                const int64_t yo = ((int64_t)b * (T - 1) + (t - 1)) * D + c;
-                const float4 y = *reinterpret_cast<const float4*>(Y0 + yo);
-                bool i0, i1, i2, i3;
-                fqv(y.x, q, qmin, qmax, i0); fqv(y.y, q, qmin, qmax, i1); fqv(y.z, q, qmin, qmax, i2); fqv(y.w, q, qmin, qmax, i3);
-                store_split4(dY0_hi, dY0_lo, yo, i0 ? g.x : 0.f, i1 ? g.y : 0.f, i2 ? g.z : 0.f, i3 ? g.w : 0.f);
+        for (int b0 = 0; b0 < B; b0 += UNR) {
+            float4 g[UNR], y[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int b = b0 + u < B ? b0 + u : B - 1;
+                g[u] = *reinterpret_cast<const float4*>(dx0 + ((int64_t)b * T + t) * D + c);
+                y[u] = t > 0 ? *reinterpret_cast<const float4*>(Y0 + ((int64_t)b * (T - 1) + (t - 1)) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (b0 + u < B) {
+                    acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w;
+                    if (t > 0) {
+                        bool i0, i1, i2, i3;
+                        fqv(y[u].x, q, qmin, qmax, i0); fqv(y[u].y, q, qmin, qmax, i1); fqv(y[u].z, q, qmin, qmax, i2); fqv(y[u].w, q, qmin, qmax, i3);
+                        store_split4(dY0_hi, dY0_lo, ((int64_t)(b0 + u) * (T - 1) + (t - 1)) * D + c, i0 ? g[u].x : 0.f, i1 ? g[u].y : 0.f,
+                                     i2 ? g[u].z : 0.f, i3 ? g[u].w : 0.f);
+                    }
+                }
             }
         }
         *reinterpret_cast<float4*>(dpos + (int64_t)t * D + c) = acc;
@@ -547,14 +569,14 @@ int launch_logits_fq(const float* pre, const float* qp, int qmin, int qmax, floa
 int launch_head_bwd(const float* dlogits, const float* logits_pre, const float* qp_logits, int qmin, int qmax, const float* hq, const float* qp_norm,
                     const void* wq, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dW,
                     float* dbias, float* dh, int B, int D, int C, hipStream_t st) {
-    k_head_bwd<<<C + B, 256, 0, st>>>(dlogits, logits_pre, qp_logits, qmin, qmax, hq, qp_norm, reinterpret_cast<const __bf16*>(wq), W, w_scale, w_zp,
+    k_head_bwd<<<C * ((D + 63) / 64) + B, 256, 0, st>>>(dlogits, logits_pre, qp_logits, qmin, qmax, hq, qp_norm, reinterpret_cast<const __bf16*>(wq), W, w_scale, w_zp,
                                       w_per_channel, w_qmin, w_qmax, dW, dbias, dh, B, D, C);
     return 0;
 }
 
 int launch_embed_bwd(const float* dx0, const float* Y0, const float* qp, int qmin, int qmax, float* dpos, float* dcls, void* dY0_hi, void* dY0_lo,
                      int B, int T, int D, hipStream_t st) {
-    k_embed_bwd<<<flat_grid((int64_t)T * (D / 4)), 256, 0, st>>>(dx0, Y0, qp, qmin, qmax, dpos, dcls, reinterpret_cast<__bf16*>(dY0_hi),
+    k_embed_bwd<<<(int)cdiv((int64_t)T * (D / 4), 64), 64, 0, st>>>(dx0, Y0, qp, qmin, qmax, dpos, dcls, reinterpret_cast<__bf16*>(dY0_hi),
                                                                   reinterpret_cast<__bf16*>(dY0_lo), B, T, D);
     return 0;
 }
