@@ -23,6 +23,7 @@ import warnings
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 warnings.filterwarnings("ignore")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # multi-process GPU work on this host needs dmabuf IPC (RCCL)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

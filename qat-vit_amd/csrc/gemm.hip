@@ -483,6 +483,13 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     static const int tall1 = getenv("QATVIT_NT_TALL1") ? atoi(getenv("QATVIT_NT_TALL1")) : 1;
     if (tall1 && !A_lo && N % 384 == 0 && K % 32 == 0) {   // grid A operand on the tall tile
+        if (tall1 == 2 && K % 64 == 0) {   // experiment: BK 64, 2 stages (148 KiB): half the barriers
+            constexpr size_t lds2 = 2 * (208 + 384) * 128;
+            static bool once = (allow_lds(k_gemm_nt<1, 2, 1, 13, 1, 0, 8, 3, 64>, lds2), true);
+            (void)once;
+            k_gemm_nt<1, 2, 1, 13, 1, 0, 8, 3, 64><<<cdiv(M, 208) * (N / 384), 512, lds2, st>>>(a);
+            return 0;
+        }
         constexpr size_t lds1 = 3 * (208 + 384) * 64;       // 111 KiB
         static bool once = (allow_lds(k_gemm_nt<1, 3, 1, 13, 1, 0, 8, 3, 32>, lds1), true);
         (void)once;
