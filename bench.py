@@ -138,11 +138,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # rehearsal knobs for a ONE-GPU box (tests the N>1 code path, not its speed): all ranks on device 0, gloo as the transport
+    if os.environ.get("BENCH_ONE_DEVICE"):
+        local = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import qat_vit_amd
     from qat_vit_amd import functional as F
