@@ -116,6 +116,39 @@ __device__ inline void store_split16(__bf16* hi, __bf16* lo, int64_t off, const 
     *reinterpret_cast<bf16x8*>(lo + off) = l0; *reinterpret_cast<bf16x8*>(lo + off + 8) = l1;
 }
 
+// Half-tile variant (8 token rows at a time, 2.1 KiB of scratch per wave instead of 4.3 KiB): with it the forward and dQ kernels fit
+// TWO workgroups per CU (LDS <= 80 KiB, <= 128 VGPRs), so one workgroup's staging phase overlaps the other's compute.
+// half = 0: rows 0..7 (lanes with g < 2 hold them), half = 1: rows 8..15.  Afterwards lane (row = lane / (HD/8), c8 = lane % (HD/8))
+// holds 8 consecutive features of token row 8*half + row.
+template <int HD>
+__device__ inline bool wave_retile8(float* sO, const f32x4 (&acc)[HD / 16], float scale, int lane, int half, float (&out)[8], int& row, int& c8) {
+    constexpr int LDO = HD + 4;
+    const int r = lane & 15, g = lane >> 4;
+    if ((g >> 1) == half) {
+#pragma unroll
+        for (int jd = 0; jd < HD / 16; ++jd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sO[(4 * (g & 1) + e) * LDO + 16 * jd + r] = acc[jd][e] * scale;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    row = lane / (HD / 8);
+    c8 = lane % (HD / 8);
+    const bool active = row < 8;
+    if (active) {
+        const float4 v0 = *reinterpret_cast<const float4*>(sO + row * LDO + 8 * c8), v1 = *reinterpret_cast<const float4*>(sO + row * LDO + 8 * c8 + 4);
+        out[0] = v0.x; out[1] = v0.y; out[2] = v0.z; out[3] = v0.w; out[4] = v1.x; out[5] = v1.y; out[6] = v1.z; out[7] = v1.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return active;
+}
+__device__ inline void store_split8(__bf16* hi, __bf16* lo, int64_t off, const float (&v)[8]) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
+    *reinterpret_cast<bf16x8*>(hi + off) = h;
+    *reinterpret_cast<bf16x8*>(lo + off) = l;
+}
+
 struct AttnArgs {
     const float* qkv;   // pre-FQ fp32 [B*T, 3*D]
     const float* qp;    // {scale, 1/scale, zp, enabled} of the qkv activation FQ
@@ -170,7 +203,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;         // row image
     char* sV = smem + IMG;   // tr image
-    float* sO = reinterpret_cast<float*>(smem + 2 * IMG) + (threadIdx.x >> 6) * (16 * (HD + 4));  // per-wave output re-tiling scratch
+    float* sO = reinterpret_cast<float*>(smem + 2 * IMG) + (threadIdx.x >> 6) * (8 * (HD + 4));  // per-wave output re-tiling scratch (half tile)
     const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
@@ -235,12 +268,13 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
                 o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vf, o[jd], 0, 0, 0);
             }
         }
-        {
-            float ov[16];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float ov[8];
             int orow, oc;
-            const bool act = wave_retile<HD>(sO, o, q.s, lane, ov, orow, oc);
-            const int qq = qt * 16 + orow;
-            if (act && qq < T) store_split16(p.O_hi, p.O_lo, ((int64_t)b * T + qq) * D + h * HD + 16 * oc, ov);
+            const bool act = wave_retile8<HD>(sO, o, q.s, lane, half, ov, orow, oc);
+            const int qq = qt * 16 + 8 * half + orow;
+            if (act && qq < T) store_split8(p.O_hi, p.O_lo, ((int64_t)b * T + qq) * D + h * HD + 8 * oc, ov);
         }
     }
 }
@@ -252,7 +286,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sKt = smem;            // [token][d] image of K: transposed reads (B operand of dQ) AND plain row reads (A operand of S^T)
     char* sV = smem + IMG;       // row image (A operand of dP^T)
-    float* sO = reinterpret_cast<float*>(smem + 2 * IMG) + (threadIdx.x >> 6) * (16 * (HD + 4));  // per-wave output re-tiling scratch
+    float* sO = reinterpret_cast<float*>(smem + 2 * IMG) + (threadIdx.x >> 6) * (8 * (HD + 4));  // per-wave output re-tiling scratch (half tile)
     const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
@@ -319,24 +353,25 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
                 dq[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl, kt, dq[jd], 0, 0, 0);
             }
         }
-        {
-            float gv[16];
-            int orow, oc;
-            const bool act = wave_retile<HD>(sO, dq, q.s * p.softmax_scale, lane, gv, orow, oc);
-            const int qq = qt * 16 + orow;
-            if (act && qq < T) {
-                const int64_t off = ((int64_t)b * T + qq) * ld + h * HD + 16 * oc;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {  // STE mask of the qkv fake-quant (+ optional per-channel weight scale), 16 contiguous features
+        for (int half = 0; half < 2; ++half) {
+            float gv[8];
+            int orow, oc;
+            const bool act = wave_retile8<HD>(sO, dq, q.s * p.softmax_scale, lane, half, gv, orow, oc);
+            const int qq = qt * 16 + 8 * half + orow;
+            if (act && qq < T) {
+                const int64_t off = ((int64_t)b * T + qq) * ld + h * HD + 8 * oc;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {  // STE mask of the qkv fake-quant (+ optional per-channel weight scale), 8 contiguous features
                     const float4 xq = *reinterpret_cast<const float4*>(p.qkv + off + 4 * k);
                     float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (p.col_scale) cs = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 16 * oc + 4 * k);
+                    if (p.col_scale) cs = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 8 * oc + 4 * k);
                     gv[4 * k] = qin(xq.x, q) ? gv[4 * k] * cs.x : 0.f;
                     gv[4 * k + 1] = qin(xq.y, q) ? gv[4 * k + 1] * cs.y : 0.f;
                     gv[4 * k + 2] = qin(xq.z, q) ? gv[4 * k + 2] * cs.z : 0.f;
                     gv[4 * k + 3] = qin(xq.w, q) ? gv[4 * k + 3] * cs.w : 0.f;
                 }
-                store_split16(p.dqkv_hi, p.dqkv_lo, off, gv);
+                store_split8(p.dqkv_hi, p.dqkv_lo, off, gv);
             }
         }
     }
@@ -499,11 +534,11 @@ template <int HD, int NKT>
 static void launch3(int which, const AttnArgs& a, hipStream_t st) {
     const size_t img = (size_t)NKT * 16 * HD * 2;
     const int grid = a.B * a.H;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 16 * (HD + 4) * 4)),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 16 * (HD + 4) * 4)),
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 8 * (HD + 4) * 4)),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 8 * (HD + 4) * 4)),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)), true);
     (void)once;
-    const size_t scratch = (size_t)kAW * 16 * (HD + 4) * sizeof(float);
+    const size_t scratch = (size_t)kAW * 8 * (HD + 4) * sizeof(float);   // half-tile re-tiling scratch: 2 workgroups per CU (fwd, dQ)
     if (which == 0) k_attn_fwd<HD, NKT><<<grid, kAW * 64, 2 * img + scratch, st>>>(a);
     else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, kAW * 64, 2 * img + scratch, st>>>(a);
     else k_attn_bwd_dkv<HD, NKT><<<grid, kAW * 64, 3 * img, st>>>(a);
