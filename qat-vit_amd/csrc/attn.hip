@@ -11,6 +11,8 @@
 // accumulator registers ARE the next MFMA's A operand with k-slot -> key map
 //   kappa(g, j) = 16*(t0 + (j>>2)) + 4*g + (j&3); the other operand is read with the same map
 // through ds_read_b64_tr_b16 from a [token][d] LDS image.
+#include <stdlib.h>
+
 #include "qv_common.h"
 #include "qv_kernels.h"
 
@@ -166,10 +168,10 @@ struct AttnArgs {
 };
 
 // stage one [T][HD] slice (q, k or v of head h) into an LDS image; `which`: 0 q, 1 k, 2 v
-template <int HD, bool TR, int NKT>
+template <int HD, bool TR, int NKT, int NWV = kAW>
 __device__ inline void stage_tokens(char* img, const float* base, int T, int ld, const AQP& q) {
     constexpr int CH = HD / 8;  // 16-B chunks per token row
-    for (int i = threadIdx.x; i < NKT * 16 * CH; i += kAW * 64) {
+    for (int i = threadIdx.x; i < NKT * 16 * CH; i += NWV * 64) {
         const int tok = i / CH, ch = i % CH;
         bf16x8 f;
         if (tok < T) f = load_q8(base + (int64_t)tok * ld + ch * 8, q);
@@ -179,10 +181,10 @@ __device__ inline void stage_tokens(char* img, const float* base, int T, int ld,
         *reinterpret_cast<bf16x8*>(img + (TR ? tr_off<HD>(tok, ch) : row_off<HD>(tok, ch))) = f;
     }
 }
-template <int HD, int NKT>
+template <int HD, int NKT, int NWV = kAW>
 __device__ inline void stage_split_tr(char* img_hi, char* img_lo, const float* base, int T, int ld) {
     constexpr int CH = HD / 8;
-    for (int i = threadIdx.x; i < NKT * 16 * CH; i += kAW * 64) {
+    for (int i = threadIdx.x; i < NKT * 16 * CH; i += NWV * 64) {
         const int tok = i / CH, ch = i % CH;
         bf16x8 hi, lo;
         if (tok < T) load_split8(base + (int64_t)tok * ld + ch * 8, hi, lo);
@@ -378,8 +380,9 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
 }
 
 // ============================================================================ backward, dK and dV
-template <int HD, int NKT>
-__global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dkv(const AttnArgs p) {
+template <int HD, int NKT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
+    constexpr int U = (NKT + NWV - 1) / NWV;   // key tiles per wave (2 with 8 waves, 1 with 16)
     // Each wave owns up to two key tiles (j0 = wave, j1 = wave + kAW) and keeps their K/V fragments and the
     // dK^T / dV^T accumulators in registers; it sweeps the query tiles in pairs ONCE, loading (and quantizing /
     // splitting) each pair's Q and dO row fragments once for both owned key tiles.
@@ -394,8 +397,8 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
     const float* base = p.qkv + (int64_t)b * T * ld + h * HD;
     const float* dObase = p.dO + (int64_t)b * T * D + h * HD;
-    stage_tokens<HD, true, NKT>(sQt, base, T, ld, q);
-    stage_split_tr<HD, NKT>(sDh, sDl, dObase, T, D);
+    stage_tokens<HD, true, NKT, NWV>(sQt, base, T, ld, q);
+    stage_split_tr<HD, NKT, NWV>(sDh, sDl, dObase, T, D);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -403,14 +406,16 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     const int nkt = (T + 15) / 16;
     const float* lse = p.lse + (int64_t)blockIdx.x * TP;
     const float* delta = p.delta + (int64_t)blockIdx.x * TP;
-    const int jt[2] = {wave, wave + kAW};
-    const bool has[2] = {jt[0] < nkt, jt[1] < nkt};
-    if (!has[0]) return;  // (after the only barrier)
-    bf16x8 kf[2][KK], vf[2][KK];
-    bool kvalid[2];
-    f32x4 dk[2][ND], dv[2][ND];
+    int jt[U];
+    bool has[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) { jt[u] = wave + u * NWV; has[u] = jt[u] < nkt; }
+    if (!has[0]) return;  // (after the only barrier)
+    bf16x8 kf[U][KK], vf[U][KK];
+    bool kvalid[U];
+    f32x4 dk[U][ND], dv[U][ND];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
         const int krow = min(16 * jt[u] + r, T - 1);
         kvalid[u] = has[u] && 16 * jt[u] + r < T;
 #pragma unroll
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dkv(const AttnArgs p) {
             qtf[id] = tr_frag2<HD>(sQt, 32 * qs, 32 * qs + 16, 16 * id, lane);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (!has[u]) continue;  // wave-uniform
             f32x4 p2[2], ds2[2];
 #pragma unroll
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     // accumulators: row = feature 16id + 4g + e, col = key 16j + r  -> 8-B (4 x bf16) stores along d
     const float a = q.s * p.softmax_scale;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
         if (!kvalid[u]) continue;
 #pragma unroll
         for (int id = 0; id < ND; ++id) {
@@ -536,12 +541,17 @@ static void launch3(int which, const AttnArgs& a, hipStream_t st) {
     const int grid = a.B * a.H;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 8 * (HD + 4) * 4)),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 8 * (HD + 4) * 4)),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)), true);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)), true);
     (void)once;
     const size_t scratch = (size_t)kAW * 8 * (HD + 4) * sizeof(float);   // half-tile re-tiling scratch: 2 workgroups per CU (fwd, dQ)
     if (which == 0) k_attn_fwd<HD, NKT><<<grid, kAW * 64, 2 * img + scratch, st>>>(a);
     else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, kAW * 64, 2 * img + scratch, st>>>(a);
-    else k_attn_bwd_dkv<HD, NKT><<<grid, kAW * 64, 3 * img, st>>>(a);
+    else {
+        static const int dkv16 = getenv("QATVIT_ATTN_DKV16") ? atoi(getenv("QATVIT_ATTN_DKV16")) : 0;   // 16 waves x one key tile each (tuning)
+        if (dkv16 && NKT > 8) k_attn_bwd_dkv<HD, NKT, 16><<<grid, 16 * 64, 3 * img, st>>>(a);
+        else k_attn_bwd_dkv<HD, NKT, 8><<<grid, kAW * 64, 3 * img, st>>>(a);
+    }
 }
 
 static int dispatch(int which, const AttnArgs& a, hipStream_t st) {
