@@ -125,8 +125,9 @@ class StudentEngine:
         for f, w in [(f, None) for f in self.act_fq] + list(zip(self.w_fq, [self.params[i] for i in self._weight_param_indices()])):
             sizes.append(w.shape[0] if (w is not None and f.is_per_channel) else 1)
         tot = sum(sizes)
-        f32 = torch.empty(3 * tot, dtype=torch.float32, device=dev)
-        i32 = torch.empty(tot, dtype=torch.int32, device=dev)
+        arena = torch.empty(16 * tot, dtype=torch.uint8, device=dev)     # one buffer: a single broadcast carries the whole state
+        f32 = arena[:12 * tot].view(torch.float32)
+        i32 = arena[12 * tot:].view(torch.int32)
         o = 0
         for f, c in zip(self.act_fq + self.w_fq, sizes):
             obs = f.activation_post_process
@@ -145,7 +146,7 @@ class StudentEngine:
             f._buffers["scale"] = sc
             f._buffers["zero_point"] = zp
             o += c
-        self.fq_f32, self.fq_i32 = f32, i32
+        self.fq_f32, self.fq_i32, self.fq_arena = f32, i32, arena
 
     def _weight_param_indices(self):
         depth = (len(self.params) - 8) // 12
@@ -175,8 +176,7 @@ class StudentEngine:
 
     @torch.no_grad()
     def _broadcast_fq_state(self):
-        dist.broadcast(self.fq_f32, src=0, group=self.pg)
-        dist.broadcast(self.fq_i32, src=0, group=self.pg)
+        dist.broadcast(self.fq_arena, src=0, group=self.pg)
 
     # ------------------------------------------------------------------ step
     def _check_ptrs(self):
