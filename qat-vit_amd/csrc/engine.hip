@@ -133,7 +133,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->delta = take((int64_t)d.B * d.H * p->TP * 4);
     p->dh = take((int64_t)d.B * D * 4);
     p->dY0_hi = take((int64_t)d.B * d.np * D * 2); p->dY0_lo = take((int64_t)d.B * d.np * D * 2);
-    p->tn_scratch = take(kTnScratchBytes);   // split partials of the weight-gradient GEMMs (two-phase, non-atomic reduction)
+    p->tn_scratch = take(2 * kTnScratchBytes);   // split partials of the weight-gradient GEMMs (two-phase, non-atomic reduction), two halves
     p->total = o;
     return 0;
 }
@@ -166,6 +166,16 @@ struct ProfScope {
         if (on) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st); g_prof.used += 2; }
     }
 };
+
+// second phase of the split weight gradients on a side stream: QATVIT_TN_ASYNC=1.  Off by default: measured 28.4 vs 28.5 ms per step
+// (the reduction hardly overlaps the next GEMM although 13 CUs and 100 VGPRs per SIMD are free), not worth a second stream
+static TnAsync g_tn_async{};
+static TnAsync* tn_async() {
+    static const int on = getenv("QATVIT_TN_ASYNC") ? atoi(getenv("QATVIT_TN_ASYNC")) : 0;
+    if (!on) return nullptr;
+    if (!g_tn_async.ready && tn_async_init(&g_tn_async)) return nullptr;
+    return &g_tn_async;
+}
 
 struct Ctx {
     const qatvit_cfg& c;
@@ -218,7 +228,7 @@ struct Ctx {
         const qatvit_fq& f = wfq[wi];
         ProfScope ps(3, 2.0 * M * N * K, st);
         return launch_gemm_tn(dY_hi, dY_lo, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
-                              c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
+                              c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), 2 * kTnScratchBytes, tn_async());
     }
 };
 
@@ -451,7 +461,9 @@ int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qa
                  stage_from, stage_to);
     Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream};
     if (make_plan(*cfg, &x.p)) return 1;
-    if (bwd(x, dlogits, grads, stage_from, stage_to)) return 1;
+    const int rc = bwd(x, dlogits, grads, stage_from, stage_to);
+    tn_async_join(&g_tn_async, x.st);   // the caller's stream sees every dW complete (all-reduce / optimizer come next)
+    if (rc) return 1;
     QV_CHECK_LAUNCH("qatvit_student_backward");
     return 0;
 }
