@@ -11,11 +11,13 @@
 // Two layouts:
 //   NT  C[M,N]  = sum_k  A[M,K] * B[N,K]      (forward, and dgrad with B = Wq^T)   row reads
 //   TN  C[N,Kw] += sum_m P[m,N] * Q[m,Kw]     (wgrad; reduction over tokens)       ds_read_b64_tr_b16
-// Both: 128x128 output tile per 256-thread workgroup, BK = 64, operands streamed HBM/L2 -> LDS by
-// LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, out-of-range rows read as zero) through a
-// 2- or 3-stage ring with counted s_waitcnt vmcnt and ONE raw s_barrier per k-step; the LDS images are
-// XOR-swizzled on the DMA *source* address (the DMA destination is lane-linear) and on the fragment
-// read, so ds_read_b128 / ds_read_b64_tr_b16 are bank-conflict free.
+// Both: 8 waves per workgroup (two per SIMD), operands streamed HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no
+// staging registers, out-of-range rows read as zero) through a 2- or 3-stage ring with counted s_waitcnt vmcnt and ONE raw
+// s_barrier per k-step; the LDS images are XOR-swizzled on the DMA *source* address (the DMA destination is lane-linear) and
+// on the fragment read, so ds_read_b128 / ds_read_b64_tr_b16 are bank-conflict free.
+// NT tile: 208 rows x the whole 384-column weight panel when N % 384 == 0 (B*197 token rows over 256 CUs = 197 rows per CU: one
+// round), BK 32, DMA issue spread between the MFMA groups; 128 x 128 otherwise.  TN tile: 128 x 384 or 128 x 128, token
+// reduction split over <= 256 workgroups, partial tiles reduced in a second launch.
 #include <stdlib.h>
 
 #include "qv_common.h"
