@@ -8,6 +8,8 @@
 // Backward never stores masks: the STE mask (qmin <= rint(x/s)+zp <= qmax) is recomputed from the
 // saved pre-FQ tensor and the module's (scale, zp), which stay valid until the next forward.
 // Row kernels: one wave per row, 16 B per lane per load; all are single-pass over HBM.
+#include <stdlib.h>
+
 #include "qv_common.h"
 #include "qv_kernels.h"
 
@@ -245,7 +247,8 @@ __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ d, c
 // ---------------------------------------------------------------- LayerNorm backward with the aFQ mask of its output
 // g_in = dH * mask(LN(x));  dx_out = (ACC ? dx_in : 0) + LNbwd(g_in);  dgamma/dbeta += column sums
 // rows_sel: if non-null only rows listed there carry a gradient (final norm: cls tokens); others get dx_out = dx_in/0.
-template <int ACC>
+// NV = float4 column groups per lane (ceil(D / 256)): exact, so registers and the LDS column-sum staging scale with D
+template <int ACC, int NV>
 __global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH, int64_t dH_row_stride_rows, const float* __restrict__ x,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ qp, int qmin, int qmax,
@@ -253,16 +256,16 @@ __global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH,
                                                    float* __restrict__ dbeta, int64_t M, int D, int T, int cls_only) {
     const QP q = load_qp(qp);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = (D + 255) / 256;
-    float4 ag[kMaxV], ab[kMaxV];
+    constexpr int nv = NV;
+    float4 ag[NV], ab[NV];
 #pragma unroll
-    for (int j = 0; j < kMaxV; ++j) ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NV; ++j) ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
         const bool live = !cls_only || (row % T) == 0;
         if (!live) {
             // no gradient reaches this token through the (cls-pooled) head
 #pragma unroll
-            for (int j = 0; j < kMaxV; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 const int c = lane * 4 + 256 * j;
                 if (j < nv && c < D)
                     *reinterpret_cast<float4*>(dx_out + row * D + c) =
@@ -272,10 +275,10 @@ __global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH,
         }
         const float mu = mean[row], rs = rstd[row];
         const int64_t drow = cls_only ? row / T : row;  // dH is [B, D] for the cls-only case
-        float4 xh[kMaxV], gy[kMaxV];
+        float4 xh[NV], gy[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < kMaxV; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int c = lane * 4 + 256 * j;
             if (j < nv && c < D) {
                 const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c);
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH,
         }
         const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int j = 0; j < kMaxV; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int c = lane * 4 + 256 * j;
             if (j < nv && c < D) {
                 float4 o = make_float4((gy[j].x - m1 - xh[j].x * m2) * rs, (gy[j].y - m1 - xh[j].y * m2) * rs,
@@ -313,9 +316,9 @@ __global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH,
         }
     }
     // column sums: 4 waves through LDS, one atomic per column per block
-    __shared__ float sg[4][768 + 8], sb[4][768 + 8];
+    __shared__ float sg[4][256 * NV + 8], sb[4][256 * NV + 8];
 #pragma unroll
-    for (int j = 0; j < kMaxV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int c = lane * 4 + 256 * j;
         if (j < nv && c < D) {
             sg[wave][c] = ag[j].x; sg[wave][c + 1] = ag[j].y; sg[wave][c + 2] = ag[j].z; sg[wave][c + 3] = ag[j].w;
@@ -545,11 +548,15 @@ int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean
                      const float* qp, int qmin, int qmax, const float* dx_in, float* dx_out, float* dgamma, float* dbeta, int64_t M, int D, int T,
                      int cls_only, hipStream_t st) {
     if (D % 4 != 0 || D > 256 * kMaxV) { set_error("ln_bwd_fq: D=%d unsupported", D); return 1; }
-    int grid = (int)((M + 63) / 64);
-    if (grid > 2048) grid = 2048;
+    static const int rpw = getenv("QATVIT_LNB_ROWS") ? atoi(getenv("QATVIT_LNB_ROWS")) : 16;   // rows per wave (4 waves per block); measured 4/8/16/32/64: 28.8/28.6/28.1/28.7/30.6 ms per step
+    int grid = (int)((M + 4 * rpw - 1) / (4 * rpw));
+    if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    if (acc) k_ln_bwd_fq<1><<<grid, 256, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only);
-    else k_ln_bwd_fq<0><<<grid, 256, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only);
+#define QV_LNB(ACC_, NV_) k_ln_bwd_fq<ACC_, NV_><<<grid, 256, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only)
+    const int nv = (D + 255) / 256;
+    if (acc) { if (nv == 1) QV_LNB(1, 1); else if (nv == 2) QV_LNB(1, 2); else QV_LNB(1, 3); }
+    else { if (nv == 1) QV_LNB(0, 1); else if (nv == 2) QV_LNB(0, 2); else QV_LNB(0, 3); }
+#undef QV_LNB
     return 0;
 }
 
