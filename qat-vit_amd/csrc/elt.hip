@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ d, c
 // g_in = dH * mask(LN(x));  dx_out = (ACC ? dx_in : 0) + LNbwd(g_in);  dgamma/dbeta += column sums
 // rows_sel: if non-null only rows listed there carry a gradient (final norm: cls tokens); others get dx_out = dx_in/0.
 // NV = float4 column groups per lane (ceil(D / 256)): exact, so registers and the LDS column-sum staging scale with D
-template <int ACC, int NV>
-__global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH, int64_t dH_row_stride_rows, const float* __restrict__ x,
+template <int ACC, int NV, int WPB = 8>   // WPB waves per block: column sums meet in LDS, so more waves per block = same atomics, more rows in flight
+__global__ __launch_bounds__(WPB * 64) void k_ln_bwd_fq(const float* __restrict__ dH, int64_t dH_row_stride_rows, const float* __restrict__ x,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ qp, int qmin, int qmax,
                                                    const float* __restrict__ dx_in, float* __restrict__ dx_out, float* __restrict__ dgamma,
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH,
     float4 ag[NV], ab[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    for (int64_t row = (int64_t)blockIdx.x * WPB + wave; row < M; row += (int64_t)gridDim.x * WPB) {
         const bool live = !cls_only || (row % T) == 0;
         if (!live) {
             // no gradient reaches this token through the (cls-pooled) head
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH,
             }
         }
     }
-    // column sums: 4 waves through LDS, one atomic per column per block
-    __shared__ float sg[4][256 * NV + 8], sb[4][256 * NV + 8];
+    // column sums: the block's waves through LDS, one atomic per column per block
+    __shared__ float sg[WPB][256 * NV + 8], sb[WPB][256 * NV + 8];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = lane * 4 + 256 * j;
@@ -326,9 +326,12 @@ __global__ __launch_bounds__(256) void k_ln_bwd_fq(const float* __restrict__ dH,
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) {
-        atomicAdd(&dgamma[c], (sg[0][c] + sg[1][c]) + (sg[2][c] + sg[3][c]));
-        atomicAdd(&dbeta[c], (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]));
+    for (int c = threadIdx.x; c < D; c += WPB * 64) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) { a += sg[w][c]; b += sb[w][c]; }
+        atomicAdd(&dgamma[c], a);
+        atomicAdd(&dbeta[c], b);
     }
 }
 
@@ -548,11 +551,11 @@ int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean
                      const float* qp, int qmin, int qmax, const float* dx_in, float* dx_out, float* dgamma, float* dbeta, int64_t M, int D, int T,
                      int cls_only, hipStream_t st) {
     if (D % 4 != 0 || D > 256 * kMaxV) { set_error("ln_bwd_fq: D=%d unsupported", D); return 1; }
-    static const int rpw = getenv("QATVIT_LNB_ROWS") ? atoi(getenv("QATVIT_LNB_ROWS")) : 16;   // rows per wave (4 waves per block); measured 4/8/16/32/64: 28.8/28.6/28.1/28.7/30.6 ms per step
-    int grid = (int)((M + 4 * rpw - 1) / (4 * rpw));
+    static const int rpw = getenv("QATVIT_LNB_ROWS") ? atoi(getenv("QATVIT_LNB_ROWS")) : 16;   // rows per wave (8 waves per block): fewer blocks = fewer same-address dgamma/dbeta atomics (12 ns each, serialised)
+    int grid = (int)((M + 8 * rpw - 1) / (8 * rpw));
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-#define QV_LNB(ACC_, NV_) k_ln_bwd_fq<ACC_, NV_><<<grid, 256, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only)
+#define QV_LNB(ACC_, NV_) k_ln_bwd_fq<ACC_, NV_, 8><<<grid, 512, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only)
     const int nv = (D + 255) / 256;
     if (acc) { if (nv == 1) QV_LNB(1, 1); else if (nv == 2) QV_LNB(1, 2); else QV_LNB(1, 3); }
     else { if (nv == 1) QV_LNB(0, 1); else if (nv == 2) QV_LNB(0, 2); else QV_LNB(0, 3); }
