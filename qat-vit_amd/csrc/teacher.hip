@@ -165,6 +165,29 @@ __device__ inline void t_load_split8(const float* p, bf16x8& hi, bf16x8& lo) {
     for (int j = 0; j < 8; ++j) { hi[j] = (__bf16)v[j]; lo[j] = (__bf16)(v[j] - (float)hi[j]); }
 }
 
+// half-tile output re-tiling through a private LDS scratch (same scheme as attn.hip: 16-B row-major bf16 stores instead of 2-B scatters)
+template <int HD>
+__device__ inline bool t_wave_retile8(float* sO, const f32x4 (&acc)[HD / 16], float scale, int lane, int half, float (&out)[8], int& row, int& c8) {
+    constexpr int LDO = HD + 4;
+    const int r = lane & 15, g = lane >> 4;
+    if ((g >> 1) == half) {
+#pragma unroll
+        for (int jd = 0; jd < HD / 16; ++jd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sO[(4 * (g & 1) + e) * LDO + 16 * jd + r] = acc[jd][e] * scale;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    row = lane / (HD / 8);
+    c8 = lane % (HD / 8);
+    const bool active = row < 8;
+    if (active) {
+        const float4 v0 = *reinterpret_cast<const float4*>(sO + row * LDO + 8 * c8), v1 = *reinterpret_cast<const float4*>(sO + row * LDO + 8 * c8 + 4);
+        out[0] = v0.x; out[1] = v0.y; out[2] = v0.z; out[3] = v0.w; out[4] = v1.x; out[5] = v1.y; out[6] = v1.z; out[7] = v1.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return active;
+}
+
 constexpr int kTW = 8;  // waves per workgroup
 template <int HD, int NKT>
 __global__ __launch_bounds__(kTW * 64) void k_attn_fwd_float(const float* __restrict__ qkv, int B, int T, int H, int D, float scale,
@@ -175,6 +198,7 @@ __global__ __launch_bounds__(kTW * 64) void k_attn_fwd_float(const float* __rest
     char* sKl = smem + IMG;
     char* sVh = smem + 2 * IMG;  // tr images of V (hi, lo)
     char* sVl = smem + 3 * IMG;
+    float* sO = reinterpret_cast<float*>(smem + 4 * IMG) + (threadIdx.x >> 6) * (8 * (HD + 4));   // per-wave output re-tiling scratch
     const int b = blockIdx.x / H, h = blockIdx.x % H, ld = 3 * D;
     const float* base = qkv + (int64_t)b * T * ld + h * HD;
     for (int i = threadIdx.x; i < NKT * 16 * CH; i += kTW * 64) {
@@ -253,18 +277,20 @@ __global__ __launch_bounds__(kTW * 64) void k_attn_fwd_float(const float* __rest
             }
         }
 #pragma unroll
-        for (int jd = 0; jd < ND; ++jd)
+        for (int half = 0; half < 2; ++half) {
+            float ov[8];
+            int orow, oc;
+            const bool act = t_wave_retile8<HD>(sO, o, 1.0f, lane, half, ov, orow, oc);
+            const int qq = qt * 16 + 8 * half + orow;
+            if (act && qq < T) {
+                bf16x8 hv, lv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int qq = qt * 16 + 4 * g + e;
-                if (qq < T) {
-                    const float v = o[jd][e];
-                    const __bf16 hi = (__bf16)v;
-                    const int64_t off = ((int64_t)b * T + qq) * D + h * HD + 16 * jd + r;
-                    O_hi[off] = hi;
-                    O_lo[off] = (__bf16)(v - (float)hi);
-                }
+                for (int j = 0; j < 8; ++j) { hv[j] = (__bf16)ov[j]; lv[j] = (__bf16)(ov[j] - (float)hv[j]); }
+                const int64_t off = ((int64_t)b * T + qq) * D + h * HD + 8 * oc;
+                *reinterpret_cast<bf16x8*>(O_hi + off) = hv;
+                *reinterpret_cast<bf16x8*>(O_lo + off) = lv;
             }
+        }
     }
 }
 
@@ -279,7 +305,7 @@ static int rows_grid_t(int64_t rows) {
 
 template <int HD, int NKT>
 static void launch_attn_float(const float* qkv, int B, int T, int H, int D, void* O_hi, void* O_lo, hipStream_t st) {
-    const size_t lds = (size_t)4 * NKT * 16 * HD * 2;
+    const size_t lds = (size_t)4 * NKT * 16 * HD * 2 + (size_t)kTW * 8 * (HD + 4) * sizeof(float);
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd_float<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     k_attn_fwd_float<HD, NKT><<<B * H, kTW * 64, lds, st>>>(qkv, B, T, H, D, 1.0f / sqrtf((float)HD), reinterpret_cast<__bf16*>(O_hi),
