@@ -9,6 +9,8 @@
 //   -> GELU -> [GEMM fc2] -> (+res, LN) } -> cls LN -> head
 // with no stand-alone elementwise pass besides GELU.
 #include "../../include/qatvit.h"
+#include <stdlib.h>
+
 #include "qv_common.h"
 #include "qv_kernels.h"
 
@@ -382,8 +384,12 @@ int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* con
     auto H16 = [&](int64_t off) { return reinterpret_cast<__bf16*>(ws + off); };
     auto prm = [&](int i) { return reinterpret_cast<const float*>(params[i]); };
     auto bprm = [&](int blk, int k) { return prm(4 + 12 * blk + k); };
+    // QATVIT_TEACHER_PASSES=2 drops the activation_hi x weight_lo pass (weights as single bf16: ~1e-3 relative on the logits instead of
+    // 2e-5; a third less GEMM time).  Default 3: the teacher matches an fp64 evaluation to 2e-5.
+    static const int passes = getenv("QATVIT_TEACHER_PASSES") ? atoi(getenv("QATVIT_TEACHER_PASSES")) : 3;
+    auto wlo = [&](int wi) -> const void* { return passes == 2 ? nullptr : w_lo[wi]; };
     auto gemm = [&](const void* Ah, const void* Al, int wi, const float* bias, float* C, int Mrows, int N, int K) {
-        return launch_gemm_nt(Ah, Al, w_hi[wi], C, Mrows, N, K, K, K, N, nullptr, nullptr, nullptr, bias, nullptr, 1, st, w_lo[wi]);
+        return launch_gemm_nt(Ah, Al, w_hi[wi], C, Mrows, N, K, K, K, N, nullptr, nullptr, nullptr, bias, nullptr, 1, st, wlo(wi));
     };
     k_patches_split<<<flat_grid_t((int64_t)c.batch * np * Kpe / 4), 256, 0, st>>>(images, H16(p.p_hi), H16(p.p_lo), c.batch, c.in_chans, c.img_size,
                                                                                c.img_size, c.patch_size);
@@ -402,7 +408,7 @@ int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* con
         {   // fc1 with GELU + hi/lo split in the GEMM epilogue (the fp32 [M, Hd] tensor never exists)
             NTPost post{nullptr, nullptr, 0, 0, nullptr, V(p.G_hi), V(p.G_lo)};
             if (launch_gemm_nt(V(p.h_hi), V(p.h_lo), w_hi[w0 + 2], nullptr, (int)M, Hd, D, D, D, Hd, nullptr, nullptr, nullptr, bprm(i, 9), nullptr, 1, st,
-                               w_lo[w0 + 2], &post))
+                               wlo(w0 + 2), &post))
                 return 1;
         }
         if (gemm(V(p.G_hi), V(p.G_lo), w0 + 3, bprm(i, 11), F(p.Y), (int)M, D, Hd)) return 1;
