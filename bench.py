@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--backend", default="qnnpack")
     ap.add_argument("--teacher", action="store_true", help="KD against a frozen ViT-B teacher (configs C3/C4)")
     ap.add_argument("--student", default="vit_small", choices=["vit_small", "vit_base"], help="vit_base = config C5 (use --batch 128)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (launch-bound small batches; N=1, no teacher)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rates", action="store_true")
     args = ap.parse_args()
@@ -192,6 +193,16 @@ def main():
         loss, _ = F.kd_ce_loss(out, t_out, y, 4.0, 0.5, 0.1)
         loss.backward()
 
+    if args.graph:
+        if world > 1 or teacher is not None:
+            raise SystemExit("--graph: single GPU, no teacher")
+        from qat_vit_amd.graph import GraphedStudentStep
+
+        gstep = GraphedStudentStep(model, x, y)
+
+        def step():  # noqa: F811
+            gstep(x, y)
+
     for _ in range(args.warmup):
         step()
     n_nt2 = 6 * eng.cfg.depth  # proj fwd, fc2 fwd + 4 dgrads per block
@@ -224,7 +235,7 @@ def main():
             "config": {"workload": f"{args.student}_patch16_224 student + QATWrapper, {args.backend} qconfig, "
                                    f"{'vit_base teacher KD (native teacher forward inside the timed step)' if args.teacher else 'no teacher'}, "
                                    f"batch {args.batch}/GPU, 224x224x3 (BASELINE configs[{2 if args.teacher else 1}])",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(args.graph)},
         }
         tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         traffic, traffic_note = None, None

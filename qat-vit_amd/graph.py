@@ -1,0 +1,65 @@
+"""Whole-step hipGraph capture for launch-bound batch sizes.
+
+At batch 256 the step is GPU-bound (529 launches in 28 ms); at the reference's plumbing batch of 8 (BASELINE config C1) the same
+529 launches cost more host time than GPU time.  ``GraphedStudentStep`` captures one training step - student forward through
+``libqatvit.so``, the KD + CE loss, the native backward - into a hipGraph (``torch.cuda.CUDAGraph`` on ROCm) and replays it: one
+launch per step.  Everything the engine touches is already at fixed addresses (workspace, parameters, fake-quant buffers); the flat
+gradient buffer becomes graph-owned static memory that ``.grad`` keeps pointing into.
+
+The step it replaces is the body of the reference's loop, ``/root/reference/src/training/qat_trainer.py:341-359`` (forward, loss,
+``loss.backward()``); clip + optimizer (``ClipAdamW``) run after ``replay`` as usual.  Single-GPU only: collectives are not captured."""
+from typing import Optional
+
+import torch
+
+from . import functional as F
+from .engine import engine_of
+
+
+class GraphedStudentStep:
+    def __init__(self, model, images: torch.Tensor, labels: torch.Tensor, teacher_out: Optional[torch.Tensor] = None, kd_temp: float = 4.0,
+                 kd_alpha: float = 0.5, label_smoothing: float = 0.1, warmup: int = 2):
+        if not images.is_cuda:
+            raise RuntimeError("GraphedStudentStep runs on MI355X only")
+        self.model = model
+        self.x = images.clone()
+        self.y = labels.clone()
+        self.t = teacher_out.clone() if teacher_out is not None else None
+        self.hp = (kd_temp, kd_alpha, label_smoothing)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):          # warm-up on the side stream: builds the engine, sets kernel attributes, reads tuning env vars
+            for _ in range(max(1, warmup)):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(s)
+        eng = engine_of(model)
+        if eng is None or eng.pg is not None:
+            raise RuntimeError("GraphedStudentStep: needs a prepared single-GPU student (no data-parallel group)")
+        for p in model.parameters():
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out, self.loss, self.parts = self._eager()
+        self._grads = [p.grad for p in model.parameters()]
+
+    def _eager(self):
+        for p in self.model.parameters():
+            p.grad = None
+        out = self.model(self.x)
+        loss, parts = F.kd_ce_loss(out, self.t, self.y, *self.hp)
+        loss.backward()
+        return out, loss, parts
+
+    @torch.no_grad()
+    def __call__(self, images: torch.Tensor, labels: torch.Tensor, teacher_out: Optional[torch.Tensor] = None):
+        """Copies the batch into the captured buffers and replays; returns (logits, loss, parts) - tensors owned by the graph."""
+        self.x.copy_(images)
+        self.y.copy_(labels)
+        if self.t is not None:
+            if teacher_out is None:
+                raise RuntimeError("captured with a teacher: pass teacher_out")
+            self.t.copy_(teacher_out)
+        for p, g in zip(self.model.parameters(), self._grads):   # zero_grad(set_to_none=True) in the loop must not drop the static buffers
+            p.grad = g
+        self.graph.replay()
+        return self.out, self.loss, self.parts
