@@ -17,7 +17,6 @@ the ViT is oracle/vit_ref.py.
 """
 from __future__ import annotations
 
-import copy
 import warnings
 
 import torch

@@ -8,7 +8,6 @@ Stands where the reference's loop has (``/root/reference/src/training/qat_traine
 as ``optimizer.step(max_norm=1.0)`` (or ``optimizer.clip_grad_norm_(1.0); optimizer.step()``): two launches instead of
 ~10 foreach passes over 152 tensors.  ``state`` / ``state_dict()`` carry torch.optim.AdamW's keys (``step``, ``exp_avg``,
 ``exp_avg_sq``), so checkpoints move between the two.  There is no CPU path: CPU parameters raise."""
-import ctypes
 
 import torch
 

@@ -3,7 +3,6 @@ include/qatvit.h declares; the Python mirror keeps the reference's API and error
 (/root/reference/src/models/model_registry.py:333-440)."""
 import os
 import re
-import warnings
 
 import pytest
 import torch
