@@ -100,7 +100,7 @@ struct NTArgs {
 };
 
 // ---- shared epilogue of the NT kernels.  WM x WN waves, wave (wm, wn) holds a (16*TM) x (16*TNT) sub-tile in acc[][].
-template <int WM, int WN, int TM, int TNT>
+template <int WM, int WN, int TM, int TNT, int SLAB = 64>   // SLAB: rows staged through LDS at a time (a multiple of 16)
 __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char* smem, int m0, int n0, int tid, int lane, int wave, int wm, int wn,
                                    int r, int g) {
     constexpr int WR = 16 * TM, WC = 16 * TNT, BM = WR * WM, BN = WC * WN, NW = WN * WM;
@@ -113,9 +113,9 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
     if (p.s2) alpha *= *p.s2;
     float mn = INFINITY, mx = -INFINITY;
     constexpr int LDC = BN + 4;                 // fp32 words per staged row (pad: conflict-free b32 writes)
-    float* sC = reinterpret_cast<float*>(smem); // [64][LDC]
+    float* sC = reinterpret_cast<float*>(smem); // [SLAB][LDC]
     // fused GELU backward: fq(Y) only takes qmax-qmin+1 (<= 256) values, so gelu'(fq(Y)) is a table (no erf/exp per element)
-    float* sLut = sC + 64 * LDC;
+    float* sLut = sC + SLAB * LDC;
     bool use_lut = false;
     if (p.postY) {
         use_lut = p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256;
@@ -130,30 +130,30 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
         cb[j] = p.bias ? p.bias[n0 + cl] : 0.f;
     }
 #pragma unroll
-    for (int h = 0; h < (BM + 63) / 64; ++h) {
+    for (int h = 0; h < (BM + SLAB - 1) / SLAB; ++h) {
         if (h) __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int rt = wm * WR + 16 * i;    // first tile row of this 16-row fragment
-            if (rt / 64 != h) continue;
+            if (rt / SLAB != h) continue;
 #pragma unroll
             for (int j = 0; j < TNT; ++j) {
                 const int cl = wn * WC + 16 * j + r;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int rl = rt - 64 * h + 4 * g + e;
+                    const int rl = rt - SLAB * h + 4 * g + e;
                     const float v = acc[i][j][e] * ca[j] + cb[j];
                     sC[rl * LDC + cl] = v;
-                    if (m0 + 64 * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+                    if (m0 + SLAB * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
                 }
             }
         }
         __syncthreads();
         constexpr int C4 = BN / 4;              // float4 per staged row
-        const int rows_h = BM - 64 * h < 64 ? BM - 64 * h : 64;
+        const int rows_h = BM - SLAB * h < SLAB ? BM - SLAB * h : SLAB;
         for (int idx = tid; idx < rows_h * C4; idx += NW * 64) {
             const int rl = idx / C4, c4 = idx % C4;
-            const int row = m0 + 64 * h + rl;
+            const int row = m0 + SLAB * h + rl;
             if (row < p.M) {
                 const float4 v = *reinterpret_cast<const float4*>(sC + rl * LDC + 4 * c4);
                 const int64_t off = (int64_t)row * p.ldc + n0 + 4 * c4;
@@ -234,7 +234,7 @@ __device__ inline int nt_off32(int row, int chunk) {
 // 5 = s_memtime stamps of the k-loop into p.C (no epilogue)
 // NWD: number of waves (the first NWD, the older wave of each SIMD pair) that issue the LDS-DMA pieces; 0 = all of them
 template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {   // two waves per SIMD (one 8-wave or two 4-wave workgroups)
     // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
     static_assert(BK == 64 || BK == 32, "BK");
     constexpr int WR = 16 * TM, WC = 16 * TNT;      // rows / columns per wave
@@ -392,7 +392,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const NTArgs p) {
         nt_keep_alive<TM, TNT>(p, acc);
         return;
     }
-    nt_epilogue<WM, WN, TM, TNT>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
+    constexpr int SLAB = NSTAGE * STAGE >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;   // the staging slab (+ LUT) must fit inside the ring
+    static_assert(NSTAGE * STAGE >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
+    nt_epilogue<WM, WN, TM, TNT, SLAB>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
 
 template <typename K>
@@ -459,6 +461,13 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     // groups.  M = B*197 rows over 256 CUs is 197 rows per CU: 243 tiles of 208 rows fill the chip in ONE round for N = 384
     // (128-row tiles: 394 tiles = 2 rounds at 77 %), and a 208-row tile moves 7.7 B into LDS per row and k against 10 B for 128 rows.
     static const int tall = getenv("QATVIT_NT_TALL") ? atoi(getenv("QATVIT_NT_TALL")) : 1;
+    if (tall == 4 && A_lo && N % 384 == 0 && K % 32 == 0) {   // experiment: 112 x 384 tiles, 4 waves, 2 stages (76 KiB): two workgroups per CU
+        constexpr size_t lds4 = 2 * (2 * 112 + 384) * 64;
+        static bool once = (allow_lds(k_gemm_nt<2, 2, 1, 7, 1, 0, 4, 6, 32>, lds4), true);
+        (void)once;
+        k_gemm_nt<2, 2, 1, 7, 1, 0, 4, 6, 32><<<cdiv(M, 112) * (N / 384), 256, lds4, st>>>(a);
+        return 0;
+    }
     if (tall && A_lo && N % 384 == 0 && K % 32 == 0) {
         constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
         static const int tabl = getenv("QATVIT_NT_ABL") ? atoi(getenv("QATVIT_NT_ABL")) : 0;   // timing-only ablations
