@@ -494,6 +494,13 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     static const int tall1 = getenv("QATVIT_NT_TALL1") ? atoi(getenv("QATVIT_NT_TALL1")) : 1;
     if (tall1 && !A_lo && N % 384 == 0 && K % 32 == 0) {   // grid A operand on the tall tile
+        if (tall1 == 3) {   // experiment: 112 x 384, 4 waves, 2 stages (62 KiB): two workgroups per CU, epilogue of one over the k-loop of the other
+            constexpr size_t lds3 = 2 * (112 + 384) * 64;
+            static bool once = (allow_lds(k_gemm_nt<1, 2, 1, 7, 1, 0, 4, 6, 32>, lds3), true);
+            (void)once;
+            k_gemm_nt<1, 2, 1, 7, 1, 0, 4, 6, 32><<<cdiv(M, 112) * (N / 384), 256, lds3, st>>>(a);
+            return 0;
+        }
         if (tall1 == 2 && K % 64 == 0) {   // experiment: BK 64, 2 stages (148 KiB): half the barriers
             constexpr size_t lds2 = 2 * (208 + 384) * 128;
             static bool once = (allow_lds(k_gemm_nt<1, 2, 1, 13, 1, 0, 8, 3, 64>, lds2), true);
