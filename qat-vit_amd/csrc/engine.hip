@@ -177,6 +177,12 @@ static TnAsync* tn_async() {
     return &g_tn_async;
 }
 
+// QATVIT_FC1_RECOMPUTE=0: fc1 once, fp32 output, separate fq+gelu pass (the pre-recompute path; keeps Y1 as fp32 for diagnostics)
+static bool fc1_recompute() {
+    static const int on = getenv("QATVIT_FC1_RECOMPUTE") ? atoi(getenv("QATVIT_FC1_RECOMPUTE")) : 1;
+    return on != 0;
+}
+
 struct Ctx {
     const qatvit_cfg& c;
     Dims d;
@@ -204,12 +210,13 @@ struct Ctx {
     }
     // forward GEMM against fake-quantized weight wi: C = (A . wq^T) * s_act * s_w + bias, stats -> act FQ `ai_out`
     // (A_lo == nullptr: A holds grid integers; else A = A_hi + A_lo is a float operand)
-    int linear_fwd(const void* A_hi, const void* A_lo, int M, int wi, const float* s_act, const float* bias, float* C, int ai_out) const {
+    int linear_fwd(const void* A_hi, const void* A_lo, int M, int wi, const float* s_act, const float* bias, float* C, int ai_out,
+                   const NTPost* post = nullptr, bool with_stats = true) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(A_lo ? 1 : 2, 2.0 * M * N * K, st);
+        ProfScope ps(A_lo ? 1 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);   // a statistics-only pass is issued, not algorithmic, work
         return launch_gemm_nt(A_hi, A_lo, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
-                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st);
+                              c.w_per_channel ? f.scale : nullptr, bias, with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, nullptr, post);
     }
     // the per-channel weight scale of layer wi, which its dY producer folds in (nullptr for per-tensor)
     const float* dy_colscale(int wi) const { return c.w_per_channel ? wfq[wi].scale : nullptr; }
@@ -312,11 +319,28 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         x.qparams_act(x.aidx(i, AB_N2));
         launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
                               x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st);
-        if (x.linear_fwd(x.blk<void>(p.h2q, i), nullptr, M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), x.blk<float>(p.Y1, i),
-                         x.aidx(i, AB_FC1)))
-            return 1;
-        x.qparams_act(x.aidx(i, AB_FC1));
-        launch_fq_gelu(x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), d.M * d.Hd, st);
+        if (fc1_recompute()) {
+            // fc1 is a K = D GEMM whose [M, 4D] fp32 output would be written once and read twice: run it TWICE instead.  Pass 1 only
+            // feeds the observer (min/max, nothing stored); pass 2 - the same kernel on the same operands, so the same bits - quantises
+            // with the fresh qparams and stores gelu(fq(.)) as the (hi, lo) pair fc2 reads plus a uint16 code (grid index | in-range
+            // bit) for the backward.  The fp32 pre-FQ tensor and the separate fq+gelu pass (620 MB per block) disappear.
+            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
+            if (x.linear_fwd(x.blk<void>(p.h2q, i), nullptr, M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
+                             x.aidx(i, AB_FC1), &p1))
+                return 1;
+            x.qparams_act(x.aidx(i, AB_FC1));
+            const NTPost p2{nullptr, x.act_qp(x.aidx(i, AB_FC1)), qa, qb, nullptr, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), 4,
+                            x.blk<void>(p.Y1, i)};
+            if (x.linear_fwd(x.blk<void>(p.h2q, i), nullptr, M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
+                             x.aidx(i, AB_FC1), &p2, false))
+                return 1;
+        } else {
+            if (x.linear_fwd(x.blk<void>(p.h2q, i), nullptr, M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B),
+                             x.blk<float>(p.Y1, i), x.aidx(i, AB_FC1)))
+                return 1;
+            x.qparams_act(x.aidx(i, AB_FC1));
+            launch_fq_gelu(x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), d.M * d.Hd, st);
+        }
         if (x.linear_fwd(x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), M, x.widx(i, WB_FC2), nullptr, x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i),
                          x.aidx(i, AB_FC2)))
             return 1;
@@ -375,8 +399,9 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
             if (x.linear_wgrad(dYh, dYl, M, w_fc2, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
             {   // fc2 dgrad with the GELU backward + fc1's STE mask fused into its epilogue: dY1 = (dYs . W_fc2) * gelu'(fq(Y1)) * mask(Y1)
-                const NTPost post{x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), x.at<void>(p.dY1_hi),
-                                  x.at<void>(p.dY1_lo)};
+                NTPost post{x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), x.at<void>(p.dY1_hi),
+                            x.at<void>(p.dY1_lo)};
+                if (fc1_recompute()) { post.Y = nullptr; post.mode = 5; post.code = x.blk<void>(p.Y1, i); }   // the Y1 slot holds the uint16 codes
                 if (x.linear_dgrad(dYh, dYl, M, w_fc2, nullptr, &post)) return 1;
             }
             if (x.linear_wgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.blk<void>(p.h2q, i), nullptr, x.act_qp(x.aidx(i, AB_N2)),

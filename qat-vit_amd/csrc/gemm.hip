@@ -91,6 +91,8 @@ struct NTArgs {
     // Optional fused consumer (fc2 dgrad -> GELU backward): instead of storing C, store the (hi, lo) bf16 pair of
     //   C * gelu'(fq(Y)) * mask(Y) * post_colscale[col],  Y = the pre-FQ fc1 output [M,ldc], post_qp = {scale, 1/scale, zp, enabled}
     int post_gelu_fwd;       // 1: store (hi, lo) of gelu(C) to out_hi / out_lo instead of C (no Y, no mask)
+    int post_mode;           // NTPost::mode 3 / 4 / 5 (0 otherwise)
+    uint16_t* post_code;     // mode 4: out, mode 5: in
     const float* postY;
     const float* post_qp;
     int post_qmin, post_qmax;
@@ -117,10 +119,17 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
     // fused GELU backward: fq(Y) only takes qmax-qmin+1 (<= 256) values, so gelu'(fq(Y)) is a table (no erf/exp per element)
     float* sLut = sC + SLAB * LDC;
     bool use_lut = false;
-    if (p.postY) {
-        use_lut = p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256;
+    if (p.postY || p.post_mode == 5) {
+        use_lut = p.post_mode == 5 || (p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256);
         if (use_lut && tid <= p.post_qmax - p.post_qmin) sLut[tid] = gelu_bwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
         // (published by the __syncthreads() between staging and the store loop below)
+    }
+    uint32_t* sLutF = reinterpret_cast<uint32_t*>(sLut);   // mode 4: packed (hi | lo << 16) bf16 pair of gelu(grid value)
+    if (p.post_mode == 4 && tid <= p.post_qmax - p.post_qmin) {
+        const float gv = gelu_fwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
+        const __bf16 gh = (__bf16)gv;
+        const __bf16 gl = (__bf16)(gv - (float)gh);
+        sLutF[tid] = (uint32_t)__builtin_bit_cast(uint16_t, gh) | ((uint32_t)__builtin_bit_cast(uint16_t, gl) << 16);
     }
     float ca[TNT], cb[TNT];
 #pragma unroll
@@ -129,6 +138,17 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
         ca[j] = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
         cb[j] = p.bias ? p.bias[n0 + cl] : 0.f;
     }
+    if (p.post_mode == 3) {   // statistics only: no staging, no stores
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[i][j][e] * ca[j] + cb[j];
+                    if (m0 + wm * WR + 16 * i + 4 * g + e < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+                }
+    } else
 #pragma unroll
     for (int h = 0; h < (BM + SLAB - 1) / SLAB; ++h) {
         if (h) __syncthreads();
@@ -174,6 +194,40 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
                         if (use_lut) dg = sLut[(int)(fminf(fmaxf(t, fmin_), fmax_) - fmin_)];
                         else dg = gelu_bwd(qon != 0.f ? (fminf(fmaxf(t, fmin_), fmax_) - qzp) * qs : yv[e]);
                         const float o = in ? cv[e] * dg * sv[e] : 0.f;
+                        oh[e] = (__bf16)o;
+                        ol[e] = (__bf16)(o - (float)oh[e]);
+                    }
+                    *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
+                    *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
+                } else if (p.post_mode == 4) {
+                    const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
+                    const float cv[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t w[4], cd[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = rintf(cv[e] * qinv) + qzp;
+                        const uint32_t idx = (uint32_t)(int)(fminf(fmaxf(t, fmin_), fmax_) - fmin_);
+                        w[e] = sLutF[idx];
+                        cd[e] = idx | ((t >= fmin_ && t <= fmax_) ? 0x8000u : 0u);
+                    }
+                    uint2 hi2, lo2, c2;
+                    hi2.x = (w[0] & 0xffffu) | (w[1] << 16); hi2.y = (w[2] & 0xffffu) | (w[3] << 16);
+                    lo2.x = (w[0] >> 16) | (w[1] & 0xffff0000u); lo2.y = (w[2] >> 16) | (w[3] & 0xffff0000u);
+                    c2.x = cd[0] | (cd[1] << 16); c2.y = cd[2] | (cd[3] << 16);
+                    *reinterpret_cast<uint2*>(p.out_hi + off) = hi2;
+                    *reinterpret_cast<uint2*>(p.out_lo + off) = lo2;
+                    *reinterpret_cast<uint2*>(p.post_code + off) = c2;
+                } else if (p.post_mode == 5) {
+                    const uint2 c2 = *reinterpret_cast<const uint2*>(p.post_code + off);
+                    float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + 4 * c4);
+                    const uint32_t cd[4] = {c2.x & 0xffffu, c2.x >> 16, c2.y & 0xffffu, c2.y >> 16};
+                    const float cv[4] = {v.x, v.y, v.z, v.w}, sv[4] = {cs.x, cs.y, cs.z, cs.w};
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float o = (cd[e] & 0x8000u) ? cv[e] * sLut[cd[e] & 0x7fffu] * sv[e] : 0.f;
                         oh[e] = (__bf16)o;
                         ol[e] = (__bf16)(o - (float)oh[e]);
                     }
@@ -412,8 +466,17 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
              reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
-             0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
-    if (post && !post->Y) {
+             0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+    if (post && post->mode >= 3) {
+        a.post_mode = post->mode;
+        a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.post_colscale = post->colscale;
+        a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
+        a.post_code = reinterpret_cast<uint16_t*>(post->code);
+        if (post->mode > 5 || (post->mode != 3 && (!a.post_qp || !a.out_hi || !a.out_lo || !a.post_code || a.post_qmax - a.post_qmin >= 256))) {
+            set_error("gemm_nt: incomplete arguments for epilogue mode %d", post->mode);
+            return 1;
+        }
+    } else if (post && !post->Y) {
         a.post_gelu_fwd = 1;
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
         if (!a.out_hi || !a.out_lo) { set_error("gemm_nt: fused GELU epilogue needs out_hi / out_lo"); return 1; }

@@ -35,6 +35,13 @@ struct NTPost {
     const float* colscale;  // optional [N]
     void* out_hi;
     void* out_lo;
+    // explicit modes (0 = infer 1 / 2 from Y as above):
+    //   3: statistics only - nothing is stored, the min/max accumulator is updated (first pass of a recomputed K=384 GEMM)
+    //   4: store (hi, lo) of gelu(fq(C)) and the uint16 code  (q - qmin) | in_range << 15  of every element (fc1 second pass: the fp32
+    //      pre-FQ tensor never exists; qp = the qparams the first pass' statistics produced)
+    //   5: like 1, with the mask and the grid index taken from `code` instead of recomputed from Y
+    int mode = 0;
+    void* code = nullptr;   // uint16 [M, ldc]
 };
 
 // ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)
