@@ -92,6 +92,7 @@ struct NTArgs {
     //   C * gelu'(fq(Y)) * mask(Y) * post_colscale[col],  Y = the pre-FQ fc1 output [M,ldc], post_qp = {scale, 1/scale, zp, enabled}
     int post_gelu_fwd;       // 1: store (hi, lo) of gelu(C) to out_hi / out_lo instead of C (no Y, no mask)
     int post_mode;           // NTPost::mode 3 / 4 / 5 (0 otherwise)
+    int pm;                  // which epilogue the kernel instantiation contains (template parameter PM): 0 plain, 1 = postY, 2 = gelu fwd, 3 / 4 / 5
     uint16_t* post_code;     // mode 4: out, mode 5: in
     const float* postY;
     const float* post_qp;
@@ -102,7 +103,9 @@ struct NTArgs {
 };
 
 // ---- shared epilogue of the NT kernels.  WM x WN waves, wave (wm, wn) holds a (16*TM) x (16*TNT) sub-tile in acc[][].
-template <int WM, int WN, int TM, int TNT, int SLAB = 64>   // SLAB: rows staged through LDS at a time (a multiple of 16)
+// PM: the epilogue variant compiled into this instantiation (one per kernel: a monolithic epilogue with every mode selected at run time
+// needs 100 more registers than the accumulators leave and spills them)
+template <int WM, int WN, int TM, int TNT, int SLAB = 64, int PM = 0>   // SLAB: rows staged through LDS at a time (a multiple of 16)
 __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char* smem, int m0, int n0, int tid, int lane, int wave, int wm, int wn,
                                    int r, int g) {
     constexpr int WR = 16 * TM, WC = 16 * TNT, BM = WR * WM, BN = WC * WN, NW = WN * WM;
@@ -119,13 +122,13 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
     // fused GELU backward: fq(Y) only takes qmax-qmin+1 (<= 256) values, so gelu'(fq(Y)) is a table (no erf/exp per element)
     float* sLut = sC + SLAB * LDC;
     bool use_lut = false;
-    if (p.postY || p.post_mode == 5) {
-        use_lut = p.post_mode == 5 || (p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256);
+    if constexpr (PM == 1 || PM == 5) {
+        use_lut = PM == 5 || (p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256);
         if (use_lut && tid <= p.post_qmax - p.post_qmin) sLut[tid] = gelu_bwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
         // (published by the __syncthreads() between staging and the store loop below)
     }
     uint32_t* sLutF = reinterpret_cast<uint32_t*>(sLut);   // mode 4: packed (hi | lo << 16) bf16 pair of gelu(grid value)
-    if (p.post_mode == 4 && tid <= p.post_qmax - p.post_qmin) {
+    if (PM == 4 && tid <= p.post_qmax - p.post_qmin) {
         const float gv = gelu_fwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
         const __bf16 gh = (__bf16)gv;
         const __bf16 gl = (__bf16)(gv - (float)gh);
@@ -138,7 +141,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
         ca[j] = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
         cb[j] = p.bias ? p.bias[n0 + cl] : 0.f;
     }
-    if (p.post_mode == 3) {   // statistics only: no staging, no stores
+    if constexpr (PM == 3) {   // statistics only: no staging, no stores
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -177,7 +180,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
             if (row < p.M) {
                 const float4 v = *reinterpret_cast<const float4*>(sC + rl * LDC + 4 * c4);
                 const int64_t off = (int64_t)row * p.ldc + n0 + 4 * c4;
-                if (p.postY) {
+                if constexpr (PM == 1) {
                     const float4 y = *reinterpret_cast<const float4*>(p.postY + off);
                     const float qs = p.post_qp[0], qinv = p.post_qp[1], qzp = p.post_qp[2], qon = p.post_qp[3];
                     const float fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
@@ -199,7 +202,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
                     }
                     *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
                     *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
-                } else if (p.post_mode == 4) {
+                } else if constexpr (PM == 4) {
                     const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
                     const float cv[4] = {v.x, v.y, v.z, v.w};
                     uint32_t w[4], cd[4];
@@ -217,7 +220,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
                     *reinterpret_cast<uint2*>(p.out_hi + off) = hi2;
                     *reinterpret_cast<uint2*>(p.out_lo + off) = lo2;
                     *reinterpret_cast<uint2*>(p.post_code + off) = c2;
-                } else if (p.post_mode == 5) {
+                } else if constexpr (PM == 5) {
                     const uint2 c2 = *reinterpret_cast<const uint2*>(p.post_code + off);
                     float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + 4 * c4);
@@ -233,7 +236,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
                     }
                     *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
                     *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
-                } else if (p.post_gelu_fwd) {
+                } else if constexpr (PM == 2) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     const float cv[4] = {v.x, v.y, v.z, v.w};
                     bf16x4 oh, ol;
@@ -287,7 +290,7 @@ __device__ inline int nt_off32(int row, int chunk) {
 // ABL: timing-only ablations (tools/bench_gemm.py, tools/stamp_nt.py): 1 = no LDS reads / MFMA, 2 = no DMA, 3 = no epilogue,
 // 5 = s_memtime stamps of the k-loop into p.C (no epilogue)
 // NWD: number of waves (the first NWD, the older wave of each SIMD pair) that issue the LDS-DMA pieces; 0 = all of them
-template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0>
+template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0, int PM = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {   // two waves per SIMD (one 8-wave or two 4-wave workgroups)
     // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
     static_assert(BK == 64 || BK == 32, "BK");
@@ -448,12 +451,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     }
     constexpr int SLAB = NSTAGE * STAGE >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;   // the staging slab (+ LUT) must fit inside the ring
     static_assert(NSTAGE * STAGE >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
-    nt_epilogue<WM, WN, TM, TNT, SLAB>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
+    nt_epilogue<WM, WN, TM, TNT, SLAB, PM>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
 
 template <typename K>
 static void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// one kernel instantiation per epilogue variant (NTArgs::pm); the timing-only ablations exist for the plain epilogue only
+template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD>
+static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
+#define QV_PM(PM_)                                                                                                  \
+    do {                                                                                                            \
+        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_>, lds), true);       \
+        (void)once;                                                                                                 \
+        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_><<<grid, WM * WN * 64, lds, st>>>(a);              \
+    } while (0)
+    if constexpr (ABL != 0) {
+        QV_PM(0);
+    } else {
+        switch (a.pm) {
+            case 1: QV_PM(1); break;
+            case 2: QV_PM(2); break;
+            case 3: QV_PM(3); break;
+            case 4: QV_PM(4); break;
+            case 5: QV_PM(5); break;
+            default: QV_PM(0); break;
+        }
+    }
+#undef QV_PM
 }
 
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
@@ -466,9 +493,10 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
              reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
-             0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+             0, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
     if (post && post->mode >= 3) {
         a.post_mode = post->mode;
+        a.pm = post->mode;
         a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.post_colscale = post->colscale;
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
         a.post_code = reinterpret_cast<uint16_t*>(post->code);
@@ -478,9 +506,11 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         }
     } else if (post && !post->Y) {
         a.post_gelu_fwd = 1;
+        a.pm = 2;
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
         if (!a.out_hi || !a.out_lo) { set_error("gemm_nt: fused GELU epilogue needs out_hi / out_lo"); return 1; }
     } else if (post) {
+        a.pm = 1;
         a.postY = post->Y; a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.post_colscale = post->colscale;
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
         if (!a.postY || !a.post_qp || !a.out_hi || !a.out_lo) { set_error("gemm_nt: incomplete fused GELU-backward epilogue arguments"); return 1; }
@@ -493,15 +523,11 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         static const int tall2 = getenv("QATVIT_NT_TALL2") ? atoi(getenv("QATVIT_NT_TALL2")) : 1;
         if (tall2 && N % 384 == 0 && K % 32 == 0) {   // 208 x 384 tall tile, both operands split: 2 stages x (2 x 208 + 2 x 384) x 64 B = 148 KiB
             constexpr size_t ldst = 2 * (2 * 208 + 2 * 384) * 64;
-            static bool once = (allow_lds(k_gemm_nt<2, 2, 1, 13, 2, 0, 8, 3, 32>, ldst), true);
-            (void)once;
-            k_gemm_nt<2, 2, 1, 13, 2, 0, 8, 3, 32><<<cdiv(M, 208) * (N / 384), 512, ldst, st>>>(a);
+            nt_launch<2, 2, 1, 13, 2, 0, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), ldst, st);
             return 0;
         }
         constexpr size_t lds = 2 * 4 * 16384;
-        static bool once = (allow_lds(k_gemm_nt<2, 2, 4, 2, 2>, lds), true);
-        (void)once;
-        k_gemm_nt<2, 2, 4, 2, 2><<<cdiv(M, 128) * (N / 128), 512, lds, st>>>(a);
+        nt_launch<2, 2, 4, 2, 2, 0, 2, 4, 64, 0>(a, cdiv(M, 128) * (N / 128), lds, st);
         return 0;
     }
     // Tile/wave configurations (tools/bench_gemm.py picks per operand class; QATVIT_NT1 / QATVIT_NT2 override for tuning):
@@ -512,9 +538,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     do {                                                                                            \
         constexpr int bm = 16 * TM_ * WM_;                                                          \
         constexpr size_t lds = (size_t)NS_ * (TA_ * bm * 128 + 16384);                              \
-        static bool once = (allow_lds(k_gemm_nt<TA_, NS_, WM_, TM_>, lds), true);                   \
-        (void)once;                                                                                 \
-        k_gemm_nt<TA_, NS_, WM_, TM_><<<cdiv(M, bm) * (N / 128), WM_ * 128, lds, st>>>(a);          \
+        nt_launch<TA_, NS_, WM_, TM_, 1, 0, 2, 4, 64, 0>(a, cdiv(M, bm) * (N / 128), lds, st);          \
     } while (0)
     // N-panel-wide tiles: 128 x 384, 2 x 4 waves each 64 x 96.  Every N of ViT-S/B (384, 1152, 1536, 768, 2304, 3072) is a
     // multiple of 384, so for N = 384 the A operand is streamed into LDS exactly once (the kernels are bound by the
@@ -526,9 +550,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     static const int tall = getenv("QATVIT_NT_TALL") ? atoi(getenv("QATVIT_NT_TALL")) : 1;
     if (tall == 4 && A_lo && N % 384 == 0 && K % 32 == 0) {   // experiment: 112 x 384 tiles, 4 waves, 2 stages (76 KiB): two workgroups per CU
         constexpr size_t lds4 = 2 * (2 * 112 + 384) * 64;
-        static bool once = (allow_lds(k_gemm_nt<2, 2, 1, 7, 1, 0, 4, 6, 32>, lds4), true);
-        (void)once;
-        k_gemm_nt<2, 2, 1, 7, 1, 0, 4, 6, 32><<<cdiv(M, 112) * (N / 384), 256, lds4, st>>>(a);
+        nt_launch<2, 2, 1, 7, 1, 0, 4, 6, 32, 0>(a, cdiv(M, 112) * (N / 384), lds4, st);
         return 0;
     }
     if (tall && A_lo && N % 384 == 0 && K % 32 == 0) {
@@ -537,13 +559,9 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 #define QV_TALL(ABL_)                                                                                         \
         do {                                                                                                  \
             if (tall == 2) {                                                                                  \
-                static bool once = (allow_lds(k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 4>, lds), true);      \
-                (void)once;                                                                                   \
-                k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 4><<<cdiv(M, 208) * (N / 384), 512, lds, st>>>(a);  \
+                nt_launch<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 4>(a, cdiv(M, 208) * (N / 384), lds, st);  \
             } else {                                                                                          \
-                static bool once = (allow_lds(k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32>, lds), true);         \
-                (void)once;                                                                                   \
-                k_gemm_nt<2, 3, 1, 13, 1, ABL_, 8, 3, 32><<<cdiv(M, 208) * (N / 384), 512, lds, st>>>(a);     \
+                nt_launch<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), lds, st);     \
             }                                                                                                 \
         } while (0)
         if (tabl == 1) QV_TALL(1);
@@ -559,45 +577,33 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     if (tall1 && !A_lo && N % 384 == 0 && K % 32 == 0) {   // grid A operand on the tall tile
         if (tall1 == 3) {   // experiment: 112 x 384, 4 waves, 2 stages (62 KiB): two workgroups per CU, epilogue of one over the k-loop of the other
             constexpr size_t lds3 = 2 * (112 + 384) * 64;
-            static bool once = (allow_lds(k_gemm_nt<1, 2, 1, 7, 1, 0, 4, 6, 32>, lds3), true);
-            (void)once;
-            k_gemm_nt<1, 2, 1, 7, 1, 0, 4, 6, 32><<<cdiv(M, 112) * (N / 384), 256, lds3, st>>>(a);
+            nt_launch<1, 2, 1, 7, 1, 0, 4, 6, 32, 0>(a, cdiv(M, 112) * (N / 384), lds3, st);
             return 0;
         }
         if (tall1 == 2 && K % 64 == 0) {   // experiment: BK 64, 2 stages (148 KiB): half the barriers
             constexpr size_t lds2 = 2 * (208 + 384) * 128;
-            static bool once = (allow_lds(k_gemm_nt<1, 2, 1, 13, 1, 0, 8, 3, 64>, lds2), true);
-            (void)once;
-            k_gemm_nt<1, 2, 1, 13, 1, 0, 8, 3, 64><<<cdiv(M, 208) * (N / 384), 512, lds2, st>>>(a);
+            nt_launch<1, 2, 1, 13, 1, 0, 8, 3, 64, 0>(a, cdiv(M, 208) * (N / 384), lds2, st);
             return 0;
         }
         constexpr size_t lds1 = 3 * (208 + 384) * 64;       // 111 KiB
-        static bool once = (allow_lds(k_gemm_nt<1, 3, 1, 13, 1, 0, 8, 3, 32>, lds1), true);
-        (void)once;
-        k_gemm_nt<1, 3, 1, 13, 1, 0, 8, 3, 32><<<cdiv(M, 208) * (N / 384), 512, lds1, st>>>(a);
+        nt_launch<1, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), lds1, st);
         return 0;
     }
     if (((wide == 1 && A_lo) || wide == 2) && N % 384 == 0) {   // grid-A GEMMs (K = 384, store-bound) measured equal or better on 128^2 tiles
         const int nwg = cdiv(M, 128) * (N / 384);
         if (A_lo) {
             constexpr size_t lds = 2 * (2 * 16384 + 49152);   // 2 stages x (A_hi, A_lo [128x64], B [384x64]) = 160 KiB
-            static bool once = (allow_lds(k_gemm_nt<2, 2, 2, 4, 1, 0, 4, 6>, lds), true);
-            (void)once;
-            k_gemm_nt<2, 2, 2, 4, 1, 0, 4, 6><<<nwg, 512, lds, st>>>(a);
+            nt_launch<2, 2, 2, 4, 1, 0, 4, 6, 64, 0>(a, nwg, lds, st);
         } else {
             constexpr size_t lds = 2 * (16384 + 49152);       // 2 stages x (A, B) = 128 KiB
-            static bool once = (allow_lds(k_gemm_nt<1, 2, 2, 4, 1, 0, 4, 6>, lds), true);
-            (void)once;
-            k_gemm_nt<1, 2, 2, 4, 1, 0, 4, 6><<<nwg, 512, lds, st>>>(a);
+            nt_launch<1, 2, 2, 4, 1, 0, 4, 6, 64, 0>(a, nwg, lds, st);
         }
         return 0;
     }
     static const int abl = getenv("QATVIT_NT_ABL") ? atoi(getenv("QATVIT_NT_ABL")) : 0;
     if (abl == 1 && A_lo) {  // timing-only: DMA ring + barriers + epilogue, no math (tools/bench_gemm.py)
         constexpr size_t lds = 3 * (2 * 16384 + 16384);
-        static bool once = (allow_lds(k_gemm_nt<2, 3, 4, 2, 1, 1>, lds), true);
-        (void)once;
-        k_gemm_nt<2, 3, 4, 2, 1, 1><<<cdiv(M, 128) * (N / 128), 512, lds, st>>>(a);
+        nt_launch<2, 3, 4, 2, 1, 1, 2, 4, 64, 0>(a, cdiv(M, 128) * (N / 128), lds, st);
         return 0;
     }
     if (A_lo) {
