@@ -105,7 +105,7 @@ struct NTArgs {
 // ---- shared epilogue of the NT kernels.  WM x WN waves, wave (wm, wn) holds a (16*TM) x (16*TNT) sub-tile in acc[][].
 // PM: the epilogue variant compiled into this instantiation (one per kernel: a monolithic epilogue with every mode selected at run time
 // needs 100 more registers than the accumulators leave and spills them)
-template <int WM, int WN, int TM, int TNT, int SLAB = 64, int PM = 0>   // SLAB: rows staged through LDS at a time (a multiple of 16)
+template <int WM, int WN, int TM, int TNT, int SLAB = 64, int PM = 0, int RING = 0>   // SLAB: rows staged through LDS at a time; RING: LDS bytes
 __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char* smem, int m0, int n0, int tid, int lane, int wave, int wm, int wn,
                                    int r, int g) {
     constexpr int WR = 16 * TM, WC = 16 * TNT, BM = WR * WM, BN = WC * WN, NW = WN * WM;
@@ -128,6 +128,11 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
         // (published by the __syncthreads() between staging and the store loop below)
     }
     uint32_t* sLutF = reinterpret_cast<uint32_t*>(sLut);   // mode 4: packed (hi | lo << 16) bf16 pair of gelu(grid value)
+    // mode 5: the slab's uint16 codes come in by LDS-DMA next to the staged tile while the accumulators are being staged (a global load
+    // per store-loop iteration is a load-use chain at 8 waves per CU: fc2 dgrad took 296 us against 160 us for the plain store)
+    constexpr int CODE_BYTES = SLAB * BN * 2;
+    constexpr bool CODE_LDS = PM == 5 && RING >= SLAB * LDC * 4 + 1024 + CODE_BYTES && CODE_BYTES % 1024 == 0;
+    char* sCode = smem + SLAB * LDC * 4 + 1024;
     if (PM == 4 && tid <= p.post_qmax - p.post_qmin) {
         const float gv = gelu_fwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
         const __bf16 gh = (__bf16)gv;
@@ -155,6 +160,14 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
 #pragma unroll
     for (int h = 0; h < (BM + SLAB - 1) / SLAB; ++h) {
         if (h) __syncthreads();
+        if constexpr (CODE_LDS) {
+            const __amdgpu_buffer_rsrc_t rCode = make_rsrc(p.post_code, (int64_t)p.M * p.ldc * 2);
+            for (int pc = wave; pc < CODE_BYTES / 1024; pc += NW) {
+                const int f = pc * 512 + lane * 8;          // flat code index inside the slab, 8 codes (16 B) per lane, never across a row
+                const uint32_t voff = (uint32_t)(((int64_t)(m0 + SLAB * h + f / BN) * p.ldc + n0 + f % BN) * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rCode, (lds_void*)(sCode + pc * 1024), 16, voff, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int rt = wm * WR + 16 * i;    // first tile row of this 16-row fragment
@@ -171,6 +184,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
                 }
             }
         }
+        if constexpr (CODE_LDS) wait_vmcnt<0>();
         __syncthreads();
         constexpr int C4 = BN / 4;              // float4 per staged row
         const int rows_h = BM - SLAB * h < SLAB ? BM - SLAB * h : SLAB;
@@ -221,7 +235,9 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
                     *reinterpret_cast<uint2*>(p.out_lo + off) = lo2;
                     *reinterpret_cast<uint2*>(p.post_code + off) = c2;
                 } else if constexpr (PM == 5) {
-                    const uint2 c2 = *reinterpret_cast<const uint2*>(p.post_code + off);
+                    uint2 c2;
+                    if constexpr (CODE_LDS) c2 = *reinterpret_cast<const uint2*>(sCode + (rl * BN + 4 * c4) * 2);
+                    else c2 = *reinterpret_cast<const uint2*>(p.post_code + off);
                     float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + 4 * c4);
                     const uint32_t cd[4] = {c2.x & 0xffffu, c2.x >> 16, c2.y & 0xffffu, c2.y >> 16};
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     }
     constexpr int SLAB = NSTAGE * STAGE >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;   // the staging slab (+ LUT) must fit inside the ring
     static_assert(NSTAGE * STAGE >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
-    nt_epilogue<WM, WN, TM, TNT, SLAB, PM>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
+    nt_epilogue<WM, WN, TM, TNT, SLAB, PM, NSTAGE * STAGE>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
 
 template <typename K>
