@@ -168,31 +168,71 @@ struct AttnArgs {
 };
 
 // stage one [T][HD] slice (q, k or v of head h) into an LDS image; `which`: 0 q, 1 k, 2 v
+// Both staging helpers issue ALL of a thread's global loads before converting anything: with one or two workgroups per CU a
+// load -> convert -> LDS-store chain per iteration leaves the CU waiting on memory 3-4 times per image.
+__device__ inline bf16x8 quant8(const float4& a, const float4& b, const AQP& q) {
+    bf16x8 f;
+    f[0] = (__bf16)qint(a.x, q); f[1] = (__bf16)qint(a.y, q); f[2] = (__bf16)qint(a.z, q); f[3] = (__bf16)qint(a.w, q);
+    f[4] = (__bf16)qint(b.x, q); f[5] = (__bf16)qint(b.y, q); f[6] = (__bf16)qint(b.z, q); f[7] = (__bf16)qint(b.w, q);
+    return f;
+}
 template <int HD, bool TR, int NKT, int NWV = kAW>
 __device__ inline void stage_tokens(char* img, const float* base, int T, int ld, const AQP& q) {
     constexpr int CH = HD / 8;  // 16-B chunks per token row
-    for (int i = threadIdx.x; i < NKT * 16 * CH; i += NWV * 64) {
-        const int tok = i / CH, ch = i % CH;
-        bf16x8 f;
-        if (tok < T) f = load_q8(base + (int64_t)tok * ld + ch * 8, q);
-        else
+    constexpr int TOTAL = NKT * 16 * CH, ITERS = (TOTAL + NWV * 64 - 1) / (NWV * 64);
+    float4 a[ITERS], b[ITERS];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f;
-        *reinterpret_cast<bf16x8*>(img + (TR ? tr_off<HD>(tok, ch) : row_off<HD>(tok, ch))) = f;
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
+        if (i < TOTAL && tok < T) {
+            const float4* p = reinterpret_cast<const float4*>(base + (int64_t)tok * ld + ch * 8);
+            a[it] = p[0]; b[it] = p[1];
+        } else {
+            a[it] = b[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
+        if (i < TOTAL) {
+            bf16x8 f;
+            if (tok < T) f = quant8(a[it], b[it], q);
+            else
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f;
+            *reinterpret_cast<bf16x8*>(img + (TR ? tr_off<HD>(tok, ch) : row_off<HD>(tok, ch))) = f;
+        }
     }
 }
 template <int HD, int NKT, int NWV = kAW>
 __device__ inline void stage_split_tr(char* img_hi, char* img_lo, const float* base, int T, int ld) {
     constexpr int CH = HD / 8;
-    for (int i = threadIdx.x; i < NKT * 16 * CH; i += NWV * 64) {
-        const int tok = i / CH, ch = i % CH;
-        bf16x8 hi, lo;
-        if (tok < T) load_split8(base + (int64_t)tok * ld + ch * 8, hi, lo);
-        else
+    constexpr int TOTAL = NKT * 16 * CH, ITERS = (TOTAL + NWV * 64 - 1) / (NWV * 64);
+    float4 a[ITERS], b[ITERS];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) hi[j] = lo[j] = (__bf16)0.f;
-        *reinterpret_cast<bf16x8*>(img_hi + tr_off<HD>(tok, ch)) = hi;
-        *reinterpret_cast<bf16x8*>(img_lo + tr_off<HD>(tok, ch)) = lo;
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
+        if (i < TOTAL && tok < T) {
+            const float4* p = reinterpret_cast<const float4*>(base + (int64_t)tok * ld + ch * 8);
+            a[it] = p[0]; b[it] = p[1];
+        } else {
+            a[it] = b[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
+        if (i < TOTAL) {
+            const float v[8] = {a[it].x, a[it].y, a[it].z, a[it].w, b[it].x, b[it].y, b[it].z, b[it].w};
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hi[j] = (__bf16)v[j];
+                lo[j] = (__bf16)(v[j] - (float)hi[j]);
+            }
+            *reinterpret_cast<bf16x8*>(img_hi + tr_off<HD>(tok, ch)) = hi;
+            *reinterpret_cast<bf16x8*>(img_lo + tr_off<HD>(tok, ch)) = lo;
+        }
     }
 }
 
