@@ -534,6 +534,19 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     }
     // accumulators: row = feature 16id + 4g + e, col = key 16j + r  -> 8-B (4 x bf16) stores along d
     const float a = q.s * p.softmax_scale;
+    // the STE mask needs the pre-FQ k / v values: all of them are requested before any is used (one memory round trip for the
+    // epilogue instead of one per fragment; the sweep's operand registers are dead here)
+    float4 xk[U][ND], xv[U][ND];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int id = 0; id < ND; ++id) {
+            if (kvalid[u]) {
+                const int64_t offk = ((int64_t)b * T + 16 * jt[u] + r) * ld + D + h * HD + 16 * id + 4 * g;
+                xk[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk);
+                xv[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk + D);
+            }
+        }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (!kvalid[u]) continue;
@@ -541,16 +554,16 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
         for (int id = 0; id < ND; ++id) {
             const int64_t offk = ((int64_t)b * T + 16 * jt[u] + r) * ld + D + h * HD + 16 * id + 4 * g;
             const int64_t offv = offk + D;
-            const float4 xk = *reinterpret_cast<const float4*>(p.qkv + offk), xv = *reinterpret_cast<const float4*>(p.qkv + offv);
+            const float4 k4 = xk[u][id], v4 = xv[u][id];
             float4 ck = make_float4(1.f, 1.f, 1.f, 1.f), cv = ck;
             if (p.col_scale) {
                 ck = *reinterpret_cast<const float4*>(p.col_scale + D + h * HD + 16 * id + 4 * g);
                 cv = *reinterpret_cast<const float4*>(p.col_scale + 2 * D + h * HD + 16 * id + 4 * g);
             }
-            const float vk[4] = {qin(xk.x, q) ? dk[u][id][0] * a * ck.x : 0.f, qin(xk.y, q) ? dk[u][id][1] * a * ck.y : 0.f,
-                                 qin(xk.z, q) ? dk[u][id][2] * a * ck.z : 0.f, qin(xk.w, q) ? dk[u][id][3] * a * ck.w : 0.f};
-            const float vv[4] = {qin(xv.x, q) ? dv[u][id][0] * cv.x : 0.f, qin(xv.y, q) ? dv[u][id][1] * cv.y : 0.f,
-                                 qin(xv.z, q) ? dv[u][id][2] * cv.z : 0.f, qin(xv.w, q) ? dv[u][id][3] * cv.w : 0.f};
+            const float vk[4] = {qin(k4.x, q) ? dk[u][id][0] * a * ck.x : 0.f, qin(k4.y, q) ? dk[u][id][1] * a * ck.y : 0.f,
+                                 qin(k4.z, q) ? dk[u][id][2] * a * ck.z : 0.f, qin(k4.w, q) ? dk[u][id][3] * a * ck.w : 0.f};
+            const float vv[4] = {qin(v4.x, q) ? dv[u][id][0] * cv.x : 0.f, qin(v4.y, q) ? dv[u][id][1] * cv.y : 0.f,
+                                 qin(v4.z, q) ? dv[u][id][2] * cv.z : 0.f, qin(v4.w, q) ? dv[u][id][3] * cv.w : 0.f};
             bf16x4 kh, kl, vh, vl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
