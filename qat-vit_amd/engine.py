@@ -73,9 +73,11 @@ class StudentEngine:
         for f in wfq:
             if not f.is_symmetric_quant or f.is_per_channel != w0.is_per_channel or (f.is_per_channel and f.ch_axis != 0):
                 raise RuntimeError("weight fake-quant must be symmetric, all per-tensor or all per-channel (axis 0)")
-        flags = torch.stack([f.observer_enabled[0] for f in act + wfq] + [f.fake_quant_enabled[0] for f in act + wfq])
+        # fake-quant must be on everywhere (the GEMM operands ARE the quantisation grids); observers may be on or off - the kernels read
+        # `observer_enabled` on the device every step, so torch.ao.quantization.disable_observer / enable_observer work at any time
+        flags = torch.stack([f.fake_quant_enabled[0] for f in act + wfq])
         if not bool((flags == 1).all().item()):  # one-time host read
-            raise RuntimeError("the native step needs observer_enabled = fake_quant_enabled = 1 on every fake-quant module")
+            raise RuntimeError("the native step needs fake_quant_enabled = 1 on every fake-quant module")
         hd = blocks[0].attn.head_dim
         self.cfg = native.Cfg(
             batch=batch, img_size=m.patch_embed.img_size, patch_size=m.patch_embed.patch_size, in_chans=pe.weight.shape[1],

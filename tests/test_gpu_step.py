@@ -214,6 +214,38 @@ def test_second_step_and_eval_mode_keep_observing(native_lib):
     assert abs(m2 - (np.float32(m1) + np.float32(0.01) * (np.float32(x2.max().item()) - np.float32(m1)))) < 1e-6
 
 
+def test_observers_can_be_frozen(native_lib):
+    """torch.ao.quantization.disable_observer (a standard late-QAT step; the reference never calls it) is honoured on the device:
+    the fake-quant state stops moving, the step keeps running, and re-enabling resumes the EMA - as in stock torch."""
+    from torch.ao.quantization import disable_observer, enable_observer
+
+    w = step_ref.RefQATWrapper(randomize_(RefVisionTransformer("vit_tiny_test", num_classes=10, img_size=32), 3))
+    p = _product_from(w, "qnnpack", **TINY)
+    po = step_ref.enable_qat(copy.deepcopy(w), "qnnpack")
+    g = torch.Generator().manual_seed(1)
+    x1, x2 = torch.randn(4, 3, 32, 32, generator=g), torch.randn(4, 3, 32, 32, generator=g) * 3
+    y = torch.randint(0, 10, (4,), generator=g)
+    _step(p, x1.cuda(), y.cuda(), None)
+    step_ref.student_step(po, x1, y, None)
+    p.apply(disable_observer)
+    po.apply(disable_observer)
+    before = {n: b.clone() for n, b in p.named_buffers()}
+    out, _ = _step(p, x2.cuda(), y.cuda(), None)
+    ro, _, _, _ = step_ref.student_step(po, x2, y, None)
+    for n, b in p.named_buffers():
+        assert torch.equal(b, before[n]), n                      # nothing observed
+    assert rel_l2(out.cpu(), ro) < 0.15                          # same frozen network as stock torch (flips bounded)
+    fo = fq_modules(po)
+    for n, f in fq_modules(p).items():
+        if "weight_fake_quant" in n or n == "quant.activation_post_process":
+            assert torch.allclose(f.scale.cpu(), fo[n].scale, rtol=1e-6, atol=0), n
+    p.apply(enable_observer)
+    _step(p, x2.cuda(), y.cuda(), None)
+    f = fq_modules(p)["quant.activation_post_process"]
+    m1 = before["quant.activation_post_process.activation_post_process.max_val"].item()
+    assert abs(f.activation_post_process.max_val.item() - (np.float32(m1) + np.float32(0.01) * (np.float32(x2.max().item()) - np.float32(m1)))) < 1e-6
+
+
 def test_batch_size_change_rebuilds_engine(native_lib):
     w = step_ref.RefQATWrapper(randomize_(RefVisionTransformer("vit_tiny_test", num_classes=10, img_size=32), 3))
     p = _product_from(w, "qnnpack", **TINY)
