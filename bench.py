@@ -231,7 +231,7 @@ def main():
             "metric": "images/sec QAT student step (fwd+bwd+allreduce)",
             "value": round(imgs / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 semantics (bf16 MFMA on exact grid / hi+lo split operands, fp32 accumulate)", "data": "synthetic",
+            "dtype": "f32 semantics (int8 MFMA for grid x grid products, bf16 MFMA on exact grid / hi+lo split operands, exact or fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{args.student}_patch16_224 student + QATWrapper, {args.backend} qconfig, "
                                    f"{'vit_base teacher KD (native teacher forward inside the timed step)' if args.teacher else 'no teacher'}, "
                                    f"batch {args.batch}/GPU, 224x224x3 (BASELINE configs[{2 if args.teacher else 1}])",

@@ -101,6 +101,15 @@ int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                    int32_t lda, int32_t ldb, int32_t ldc, const float* s1, const float* s2, const float* col_scale,
                    const float* bias, uint32_t* stats, void* stream);
 
+/* The same product for two operands that both sit on a quantisation grid (qkv / fc1 / patch-embed forward), on int8 MFMA:
+ *   A8 int8 [M,lda] = q - center (center = (qmin+qmax+1)/2 of the activation range), B8 int8 [N,ldb] = weight integers,
+ *   wsum int32 [N] = row sums of B8, a_qp = {scale, 1/scale, zero_point, enabled} of A's quantizer (device):
+ *   C = (sum_k A8*B8 + (center - zero_point) * wsum[n]) * (*s1) * (*s2) * col_scale[n] + bias[n].
+ * Bit-identical to qatvit_gemm_nt on the bf16 integers (both accumulate the same integers exactly).  N % 384 == 0, K % 64 == 0. */
+int qatvit_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int32_t center, float* C, int32_t M,
+                      int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, const float* s1, const float* s2,
+                      const float* col_scale, const float* bias, uint32_t* stats, void* stream);
+
 /* C[N,Kw] += sum_m (P_hi + P_lo)[m,N] * (Q_hi + Q_lo)[m,Kw] * (*s1) / row_div[n], masked by the weight fake-quant STE
  * mask of W; dbias[N] += sum_m P[m,N] / row_div[n].
  * Replaces: the weight/bias gradient of nnqat.Linear / nnqat.Conv2d (autograd of linear.py:49-50, conv.py:54-55,

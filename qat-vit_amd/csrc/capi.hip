@@ -91,6 +91,15 @@ int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     return 0;
 }
 
+int qatvit_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int32_t center, float* C, int32_t M, int32_t N,
+                      int32_t K, int32_t lda, int32_t ldb, int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias,
+                      uint32_t* stats, void* stream) {
+    QV_CHECK_ARG(A8 && B8 && wsum && a_qp && C, "qatvit_gemm_nt_i8: null pointer argument");
+    if (launch_gemm_nt_i8(A8, B8, wsum, a_qp, center, C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream)) return 1;
+    QV_CHECK_LAUNCH("qatvit_gemm_nt_i8");
+    return 0;
+}
+
 int qatvit_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int32_t M, int32_t N, int32_t Kw, int32_t ldp,
                    int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel,
                    int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes, void* stream) {

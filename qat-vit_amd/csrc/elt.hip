@@ -53,7 +53,7 @@ static inline int flat_grid(int64_t n4) {
 // ---------------------------------------------------------------- K0: image -> patch rows
 // out[(b*gh+py)*gw+px][c*P*P + i*P + j] = q(img[b][c][py*P+i][px*P+j]) - zp   (bf16)
 __global__ __launch_bounds__(256) void k_img_patches(const float* __restrict__ img, __bf16* __restrict__ out, const float* __restrict__ qp,
-                                                     int qmin, int qmax, int B, int C, int H, int W, int P) {
+                                                     int qmin, int qmax, int B, int C, int H, int W, int P, int8_t* __restrict__ out8, int center) {
     const QP q = load_qp(qp);
     const int gw = W / P, gh = H / P, K = C * P * P;
     const int64_t n8 = (int64_t)B * gh * gw * K / 8;
@@ -71,6 +71,15 @@ __global__ __launch_bounds__(256) void k_img_patches(const float* __restrict__ i
         o[4] = (__bf16)fqi(bb.x, q, qmin, qmax); o[5] = (__bf16)fqi(bb.y, q, qmin, qmax);
         o[6] = (__bf16)fqi(bb.z, q, qmin, qmax); o[7] = (__bf16)fqi(bb.w, q, qmin, qmax);
         *reinterpret_cast<bf16x8*>(out + e) = o;
+        if (out8) {
+            const float sh = q.zp - (float)center;
+            signed char c8[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) c8[t] = (signed char)((float)o[t] + sh);
+            uint2 pk;
+            __builtin_memcpy(&pk, c8, 8);
+            *reinterpret_cast<uint2*>(out8 + e) = pk;
+        }
     }
 }
 
@@ -155,7 +164,10 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
 // h_q[row][c] = q(LN(x)[row][c]) - zp  as bf16 (the exact A operand of the following GEMM)
 __global__ __launch_bounds__(256) void k_ln_apply_quant(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ qp,
-                                                        int qmin, int qmax, __bf16* __restrict__ out, int64_t M, int D) {
+                                                        int qmin, int qmax, __bf16* __restrict__ out, int64_t M, int D,
+                                                        int8_t* __restrict__ out8, int center) {
+    // out = q - zp as bf16 (the exact operand of the weight-gradient GEMM); out8 (optional) = q - center as int8 (the operand of the
+    // int8-MFMA forward GEMM)
     const QP q = load_qp(qp);
     const int d4 = D / 4;
     const int64_t n4 = M * d4;
@@ -171,6 +183,12 @@ __global__ __launch_bounds__(256) void k_ln_apply_quant(const float* __restrict_
         o[2] = (__bf16)fqi((v.z - mu) * rs * g.z + b.z, q, qmin, qmax);
         o[3] = (__bf16)fqi((v.w - mu) * rs * g.w + b.w, q, qmin, qmax);
         *reinterpret_cast<bf16x4*>(out + row * D + c) = o;
+        if (out8) {
+            const float sh = q.zp - (float)center;
+            char4 o8 = make_char4((signed char)((float)o[0] + sh), (signed char)((float)o[1] + sh), (signed char)((float)o[2] + sh),
+                                  (signed char)((float)o[3] + sh));
+            *reinterpret_cast<char4*>(out8 + row * D + c) = o8;
+        }
     }
 }
 
@@ -471,7 +489,8 @@ __global__ __launch_bounds__(64) void k_embed_bwd(const float* __restrict__ dx0,
 // ---------------------------------------------------------------- weight fake-quant -> GEMM operands
 // wq[n][k] = q(W[n][k]) - zp (bf16), wqT[k][n] = same, transposed (dgrad's B operand)
 __device__ inline void wquant_body(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
-                                   __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K, int bx, int by) {
+                                   __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K, int bx, int by,
+                                   int8_t* __restrict__ w8 = nullptr, int32_t* __restrict__ wsum = nullptr) {
     // 32x32 tile transpose through LDS
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -484,10 +503,17 @@ __device__ inline void wquant_body(const float* __restrict__ W, const float* __r
             const QP q = load_qp(qp + 4 * (per_channel ? n : 0));
             v = q.on != 0.f ? fqi(W[(int64_t)n * K + k], q, qmin, qmax) : W[(int64_t)n * K + k];
             wq[(int64_t)n * K + k] = (__bf16)v;
+            if (w8) w8[(int64_t)n * K + k] = (int8_t)v;   // the same integer for the int8-MFMA forward GEMMs
         }
         tile[ty + 8 * i][tx] = v;
     }
     __syncthreads();
+    if (wsum && threadIdx.x < 32 && n0 + (int)threadIdx.x < N) {   // row sums of the integers (zero-point correction of the int8 GEMM)
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sacc += tile[threadIdx.x][k];
+        atomicAdd(&wsum[n0 + threadIdx.x], (int)sacc);
+    }
     if (wqT) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -505,14 +531,16 @@ __global__ __launch_bounds__(256) void k_w_quant_all(const WQuantTab t) {
     while (wi + 1 < t.n && (int)blockIdx.x >= t.blk0[wi + 1]) ++wi;
     const int b = blockIdx.x - t.blk0[wi], kt = (t.K[wi] + 31) / 32;
     wquant_body(t.W[wi], t.qp[wi], t.per_channel, t.qmin, t.qmax, reinterpret_cast<__bf16*>(t.wq[wi]), reinterpret_cast<__bf16*>(t.wqT[wi]), t.N[wi],
-                t.K[wi], b % kt, b / kt);
+                t.K[wi], b % kt, b / kt, reinterpret_cast<int8_t*>(t.w8[wi]), t.wsum[wi]);
 }
 
 // ============================================================================ launchers
-int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st) {
+int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st,
+                       void* out8, int center) {
     if (P % 8 != 0 || H % P != 0 || W % P != 0) { set_error("img_patches: patch %d must be a multiple of 8 and divide %dx%d", P, H, W); return 1; }
     const int64_t n8 = (int64_t)B * C * H * W / 8;
-    k_img_patches<<<flat_grid(n8), 256, 0, st>>>(img, reinterpret_cast<__bf16*>(out_bf16), qp, qmin, qmax, B, C, H, W, P);
+    k_img_patches<<<flat_grid(n8), 256, 0, st>>>(img, reinterpret_cast<__bf16*>(out_bf16), qp, qmin, qmax, B, C, H, W, P, reinterpret_cast<int8_t*>(out8),
+                                                 center);
     return 0;
 }
 
@@ -528,8 +556,9 @@ int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const
 }
 
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
-                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st) {
-    k_ln_apply_quant<<<flat_grid(M * (D / 4)), 256, 0, st>>>(x, mean, rstd, gamma, beta, qp, qmin, qmax, reinterpret_cast<__bf16*>(out_bf16), M, D);
+                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8, int center) {
+    k_ln_apply_quant<<<flat_grid(M * (D / 4)), 256, 0, st>>>(x, mean, rstd, gamma, beta, qp, qmin, qmax, reinterpret_cast<__bf16*>(out_bf16), M, D,
+                                                             reinterpret_cast<int8_t*>(out8), center);
     return 0;
 }
 
@@ -591,6 +620,14 @@ int launch_embed_bwd(const float* dx0, const float* Y0, const float* qp, int qmi
     return 0;
 }
 
+__global__ void k_zero_i32(int32_t* p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+// (a kernel, not hipMemsetAsync: the memset node of a captured hipGraph did not re-zero the buffer on replay)
+int launch_zero_i32(int32_t* p, int64_t n, hipStream_t st) {
+    k_zero_i32<<<(int)cdiv(n, 256) > 1024 ? 1024 : (int)cdiv(n, 256), 256, 0, st>>>(p, n);
+    return 0;
+}
 int launch_w_quant_all(WQuantTab& t, hipStream_t st) {
     int b = 0;
     for (int i = 0; i < t.n; ++i) {

@@ -68,6 +68,7 @@ struct Plan {
     int64_t blk_stride;
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
+    int64_t w8_off[64 * 4 + 8], wsum_off[64 * 4 + 8], wsum_base, wsum_bytes, imgq8, h1q8, h2q8;   // int8 operands of the forward grid x grid GEMMs
     int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo, tn_scratch;
     int64_t total, stats_words;
     int TP;
@@ -114,6 +115,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->Y1 = take(M * Hd * 4);
     p->G_hi = take(M * Hd * 2); p->G_lo = take(M * Hd * 2);
     p->Y2 = take(M * D * 4);
+    p->h1q8 = take(M * D); p->h2q8 = take(M * D);
     p->blk_stride = o - b0;
     o = b0 + p->blk_stride * d.depth;
     // x_in[depth] (input of the final norm) lives where block `depth` would start
@@ -123,7 +125,15 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
         int N, K; wshape(d, wi, &N, &K);
         p->w_off[wi] = take((int64_t)N * K * 2);
         p->wT_off[wi] = take((int64_t)N * K * 2);
+        p->w8_off[wi] = take((int64_t)N * K);
     }
+    p->imgq8 = take((int64_t)d.B * d.np * d.Kpe);
+    p->wsum_base = o;
+    for (int wi = 0; wi < d.n_w; ++wi) {
+        int N, K; wshape(d, wi, &N, &K);
+        p->wsum_off[wi] = take((int64_t)N * 4);
+    }
+    p->wsum_bytes = o - p->wsum_base;
     p->dxA = take(M * D * 4); p->dxB = take(M * D * 4);
     p->dYs_hi = take(M * D * 2); p->dYs_lo = take(M * D * 2);
     p->dG = take(M * Hd * 4);
@@ -183,6 +193,12 @@ static bool fc1_recompute() {
     return on != 0;
 }
 
+// QATVIT_I8=0: the grid x grid forward GEMMs (patch-embed, qkv, fc1) on bf16 MFMA instead of int8 MFMA (bit-identical results)
+static bool use_i8() {
+    static const int on = getenv("QATVIT_I8") ? atoi(getenv("QATVIT_I8")) : 1;
+    return on != 0;
+}
+
 struct Ctx {
     const qatvit_cfg& c;
     Dims d;
@@ -217,6 +233,19 @@ struct Ctx {
         ProfScope ps(A_lo ? 1 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);   // a statistics-only pass is issued, not algorithmic, work
         return launch_gemm_nt(A_hi, A_lo, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
                               c.w_per_channel ? f.scale : nullptr, bias, with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, nullptr, post);
+    }
+    int center() const { return (c.act_qmin + c.act_qmax + 1) / 2; }
+    // the same forward product with int8 operands: A8 = q - center written next to the bf16 grid by its producer, weight integers + row sums
+    // from k_w_quant_all.  Falls back to the bf16 form for shapes the int8 tile does not cover.
+    int linear_fwd_grid(const void* A16, const void* A8, int M, int wi, const float* a_qp, const float* bias, float* C, int ai_out,
+                        const NTPost* post = nullptr, bool with_stats = true) const {
+        int N, K; wshape(d, wi, &N, &K);
+        if (!use_i8() || N % 384 != 0 || K % 64 != 0) return linear_fwd(A16, nullptr, M, wi, a_qp, bias, C, ai_out, post, with_stats);
+        const qatvit_fq& f = wfq[wi];
+        ProfScope ps(2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);
+        return launch_gemm_nt_i8(A8, at<void>(p.w8_off[wi]), at<int32_t>(p.wsum_off[wi]), a_qp, center(), C, M, N, K, K, K, N, a_qp,
+                                 c.w_per_channel ? nullptr : f.scale, c.w_per_channel ? f.scale : nullptr, bias,
+                                 with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, post);
     }
     // the per-channel weight scale of layer wi, which its dY producer folds in (nullptr for per-tensor)
     const float* dy_colscale(int wi) const { return c.w_per_channel ? wfq[wi].scale : nullptr; }
@@ -267,7 +296,10 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
             tq.obs_on[wi] = f.observer_on; tq.fq_on[wi] = f.fake_quant_on;
             tq.qp[wi] = x.w_qp(wi); tw.qp[wi] = x.w_qp(wi);
             tw.wq[wi] = x.at<void>(p.w_off[wi]); tw.wqT[wi] = x.at<void>(p.wT_off[wi]);
+            tw.w8[wi] = use_i8() ? x.at<void>(p.w8_off[wi]) : nullptr;
+            tw.wsum[wi] = use_i8() ? x.at<int32_t>(p.wsum_off[wi]) : nullptr;
         }
+        if (use_i8()) launch_zero_i32(x.at<int32_t>(p.wsum_base), p.wsum_bytes / 4, st);   // row sums are accumulated with integer atomics
         launch_w_observe_all(to, st);
         launch_w_qparams_all(tq, st);
         launch_w_quant_all(tw, st);
@@ -286,8 +318,10 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
     // ---- input image FQ + patch rows
     launch_minmax(images, 1, (int64_t)d.B * d.chans * d.img * d.img, 0, x.act_stats(A_IN), kStatSlots, st);
     x.qparams_act(A_IN);
-    if (launch_img_patches(images, x.at<void>(p.imgq), x.act_qp(A_IN), qa, qb, d.B, d.chans, d.img, d.img, d.patch, st)) return 1;
-    if (x.linear_fwd(x.at<void>(p.imgq), nullptr, d.B * d.np, 0, x.act_qp(A_IN), x.prm(P_PE_B), x.at<float>(p.Y0), A_PE)) return 1;
+    if (launch_img_patches(images, x.at<void>(p.imgq), x.act_qp(A_IN), qa, qb, d.B, d.chans, d.img, d.img, d.patch, st,
+                           use_i8() ? x.at<void>(p.imgq8) : nullptr, x.center()))
+        return 1;
+    if (x.linear_fwd_grid(x.at<void>(p.imgq), x.at<void>(p.imgq8), d.B * d.np, 0, x.act_qp(A_IN), x.prm(P_PE_B), x.at<float>(p.Y0), A_PE)) return 1;
     x.qparams_act(A_PE);
     if (launch_resid_fq_lnstats(0, nullptr, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, x.prm(P_CLS), x.prm(P_POS), x.blk<float>(p.x_in, 0),
                                 x.blk<float>(p.mean1, 0), x.blk<float>(p.rstd1, 0), x.bprm(0, B_N1W), x.bprm(0, B_N1B), c.ln_eps,
@@ -300,9 +334,9 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         // norm1 -> qkv
         x.qparams_act(x.aidx(i, AB_N1));
         launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
-                              qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st);
-        if (x.linear_fwd(x.blk<void>(p.h1q, i), nullptr, M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), x.blk<float>(p.qkv, i),
-                         x.aidx(i, AB_QKV)))
+                              qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h1q8, i) : nullptr, x.center());
+        if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB),
+                              x.blk<float>(p.qkv, i), x.aidx(i, AB_QKV)))
             return 1;
         x.qparams_act(x.aidx(i, AB_QKV));
         if (launch_attn_fwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
@@ -318,24 +352,25 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         // norm2 -> fc1 -> gelu -> fc2
         x.qparams_act(x.aidx(i, AB_N2));
         launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
-                              x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st);
+                              x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h2q8, i) : nullptr,
+                              x.center());
         if (fc1_recompute()) {
             // fc1 is a K = D GEMM whose [M, 4D] fp32 output would be written once and read twice: run it TWICE instead.  Pass 1 only
             // feeds the observer (min/max, nothing stored); pass 2 - the same kernel on the same operands, so the same bits - quantises
             // with the fresh qparams and stores gelu(fq(.)) as the (hi, lo) pair fc2 reads plus a uint16 code (grid index | in-range
             // bit) for the backward.  The fp32 pre-FQ tensor and the separate fq+gelu pass (620 MB per block) disappear.
             const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
-            if (x.linear_fwd(x.blk<void>(p.h2q, i), nullptr, M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
+            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
                              x.aidx(i, AB_FC1), &p1))
                 return 1;
             x.qparams_act(x.aidx(i, AB_FC1));
             const NTPost p2{nullptr, x.act_qp(x.aidx(i, AB_FC1)), qa, qb, nullptr, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), 4,
                             x.blk<void>(p.Y1, i)};
-            if (x.linear_fwd(x.blk<void>(p.h2q, i), nullptr, M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
+            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
                              x.aidx(i, AB_FC1), &p2, false))
                 return 1;
         } else {
-            if (x.linear_fwd(x.blk<void>(p.h2q, i), nullptr, M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B),
+            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B),
                              x.blk<float>(p.Y1, i), x.aidx(i, AB_FC1)))
                 return 1;
             x.qparams_act(x.aidx(i, AB_FC1));

@@ -29,6 +29,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 // XCD-aware, bijective block-id remap: blocks b and b+8 share an XCD (and its L2), so give each
@@ -92,6 +93,10 @@ struct NTArgs {
     //   C * gelu'(fq(Y)) * mask(Y) * post_colscale[col],  Y = the pre-FQ fc1 output [M,ldc], post_qp = {scale, 1/scale, zp, enabled}
     int post_gelu_fwd;       // 1: store (hi, lo) of gelu(C) to out_hi / out_lo instead of C (no Y, no mask)
     int post_mode;           // NTPost::mode 3 / 4 / 5 (0 otherwise)
+    // int8 operands (template flag I8): A holds q - center, B the weight integers; the k extent / strides are then counted in 2-byte units
+    const int32_t* i8_wsum;  // [N] row sums of the int8 weight: C = (acc + (center - zp) * wsum[n]) * alpha + bias
+    const float* i8_aqp;     // qparams {s, 1/s, zp, on} of the A operand's quantizer (zp enters the correction)
+    int i8_center;
     int pm;                  // which epilogue the kernel instantiation contains (template parameter PM): 0 plain, 1 = postY, 2 = gelu fwd, 3 / 4 / 5
     uint16_t* post_code;     // mode 4: out, mode 5: in
     const float* postY;
@@ -105,8 +110,8 @@ struct NTArgs {
 // ---- shared epilogue of the NT kernels.  WM x WN waves, wave (wm, wn) holds a (16*TM) x (16*TNT) sub-tile in acc[][].
 // PM: the epilogue variant compiled into this instantiation (one per kernel: a monolithic epilogue with every mode selected at run time
 // needs 100 more registers than the accumulators leave and spills them)
-template <int WM, int WN, int TM, int TNT, int SLAB = 64, int PM = 0, int RING = 0>   // SLAB: rows staged through LDS at a time; RING: LDS bytes
-__device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char* smem, int m0, int n0, int tid, int lane, int wave, int wm, int wn,
+template <int WM, int WN, int TM, int TNT, int SLAB = 64, int PM = 0, int RING = 0, bool I8 = false>   // SLAB: rows staged through LDS at a time; RING: LDS bytes
+__device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4, f32x4> (&acc)[TM][TNT], char* smem, int m0, int n0, int tid, int lane, int wave, int wm, int wn,
                                    int r, int g) {
     constexpr int WR = 16 * TM, WC = 16 * TNT, BM = WR * WM, BN = WC * WN, NW = WN * WM;
     // ---- epilogue: C = acc * alpha[col] + bias[col]; min/max of what is stored.
@@ -146,6 +151,17 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
         ca[j] = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
         cb[j] = p.bias ? p.bias[n0 + cl] : 0.f;
     }
+    // int8 operands: the accumulators are exact int32 sums of (q - center) * w; adding (center - zp) * sum_k w restores sum (q - zp) * w,
+    // the integer the bf16 path accumulates (also exactly, it stays below 2^24) - so both paths store the same bits
+    int corr[TNT];
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) corr[j] = I8 ? (p.i8_center - (int)p.i8_aqp[2]) * p.i8_wsum[n0 + wn * WC + 16 * j + r] : 0;
+    auto accv = [&](int i, int j, int e) -> float {
+        // (the accumulators of the int8 form stay int vectors end to end: a whole-vector bit-cast to float4 followed by element reads is
+        //  miscompiled by hipcc 7.2 - every element reads element 0)
+        if constexpr (I8) return (float)(acc[i][j][e] + corr[j]);
+        else return acc[i][j][e];
+    };
     if constexpr (PM == 3) {   // statistics only: no staging, no stores
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -153,7 +169,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
             for (int j = 0; j < TNT; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = acc[i][j][e] * ca[j] + cb[j];
+                    const float v = accv(i, j, e) * ca[j] + cb[j];
                     if (m0 + wm * WR + 16 * i + 4 * g + e < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
                 }
     } else
@@ -178,7 +194,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int rl = rt - SLAB * h + 4 * g + e;
-                    const float v = acc[i][j][e] * ca[j] + cb[j];
+                    const float v = accv(i, j, e) * ca[j] + cb[j];
                     sC[rl * LDC + cl] = v;
                     if (m0 + SLAB * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
                 }
@@ -287,8 +303,8 @@ __device__ inline void nt_epilogue(const NTArgs& p, f32x4 (&acc)[TM][TNT], char*
 }
 
 // timing-only ablations: keep the accumulators alive without an epilogue
-template <int TM, int TNT>
-__device__ inline void nt_keep_alive(const NTArgs& p, f32x4 (&acc)[TM][TNT]) {
+template <int TM, int TNT, typename ACC>
+__device__ inline void nt_keep_alive(const NTArgs& p, ACC (&acc)[TM][TNT]) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -306,10 +322,11 @@ __device__ inline int nt_off32(int row, int chunk) {
 // ABL: timing-only ablations (tools/bench_gemm.py, tools/stamp_nt.py): 1 = no LDS reads / MFMA, 2 = no DMA, 3 = no epilogue,
 // 5 = s_memtime stamps of the k-loop into p.C (no epilogue)
 // NWD: number of waves (the first NWD, the older wave of each SIMD pair) that issue the LDS-DMA pieces; 0 = all of them
-template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0, int PM = 0>
+template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0, int PM = 0, bool I8 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {   // two waves per SIMD (one 8-wave or two 4-wave workgroups)
     // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
     static_assert(BK == 64 || BK == 32, "BK");
+    static_assert(!I8 || (TA == 1 && TB == 1 && TM > 4 && BK == 32), "int8 operands: tall single-image tiles only");
     constexpr int WR = 16 * TM, WC = 16 * TNT;      // rows / columns per wave
     constexpr int BM = WR * WM, BN = WC * WN, NW = WN * WM;
     constexpr int IMGA = BM * BK * 2;               // bytes of one [BM][BK] bf16 image
@@ -365,11 +382,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     };
     auto foff = [&](int row, int kk) { return BK == 64 ? nt_off(row, 4 * kk + g) : nt_off32(row, g); };
 
-    f32x4 acc[TM][TNT];
+    using acc_t = std::conditional_t<I8, i32x4, f32x4>;
+    acc_t acc[TM][TNT];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TNT; ++j) acc[i][j] = acc_t{};
 
     const int nk = p.K / BK;
 #pragma unroll
@@ -451,7 +469,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
 #pragma unroll
                     for (int t = 0; t < TA; ++t)
 #pragma unroll
-                        for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % PF][t], bfrag[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TNT; ++j) {
+                            if constexpr (I8) {   // one stage row (64 B) = 64 int8 k-values: v_mfma_i32_16x16x64_i8, same 16-B-per-lane fragments
+                                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[i % PF][t]), __builtin_bit_cast(i32x4, bfrag[j]),
+                                                                                  acc[i][j], 0, 0, 0);
+                            } else {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % PF][t], bfrag[j], acc[i][j], 0, 0, 0);
+                            }
+                        }
                     if constexpr (TB == 2) {
 #pragma unroll
                         for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % PF][0], blo[j], acc[i][j], 0, 0, 0);
@@ -467,7 +492,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     }
     constexpr int SLAB = NSTAGE * STAGE >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;   // the staging slab (+ LUT) must fit inside the ring
     static_assert(NSTAGE * STAGE >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
-    nt_epilogue<WM, WN, TM, TNT, SLAB, PM, NSTAGE * STAGE>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
+    nt_epilogue<WM, WN, TM, TNT, SLAB, PM, NSTAGE * STAGE, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
 
 template <typename K>
@@ -476,16 +501,22 @@ static void allow_lds(K kernel, size_t bytes) {
 }
 
 // one kernel instantiation per epilogue variant (NTArgs::pm); the timing-only ablations exist for the plain epilogue only
-template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD>
+template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD, bool I8 = false>
 static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
 #define QV_PM(PM_)                                                                                                  \
     do {                                                                                                            \
-        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_>, lds), true);       \
+        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8>, lds), true);   \
         (void)once;                                                                                                 \
-        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_><<<grid, WM * WN * 64, lds, st>>>(a);              \
+        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8><<<grid, WM * WN * 64, lds, st>>>(a);          \
     } while (0)
     if constexpr (ABL != 0) {
         QV_PM(0);
+    } else if constexpr (I8) {   // the grid x grid forward GEMMs only use these three epilogues
+        switch (a.pm) {
+            case 3: QV_PM(3); break;
+            case 4: QV_PM(4); break;
+            default: QV_PM(0); break;
+        }
     } else {
         switch (a.pm) {
             case 1: QV_PM(1); break;
@@ -509,7 +540,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
              reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
-             0, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
     if (post && post->mode >= 3) {
         a.post_mode = post->mode;
         a.pm = post->mode;
@@ -633,6 +664,37 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         else QV_NT_LAUNCH(1, 2, 2, 4);                  // (cfg 0) a, 2 stages (64 KiB, two workgroups per CU)
     }
 #undef QV_NT_LAUNCH
+    return 0;
+}
+
+// Grid x grid forward GEMM on int8 MFMA (v_mfma_i32_16x16x64_i8: twice the k per instruction and per LDS-DMA byte of the bf16 form).
+// A8 [M, lda] = q - center (int8), B8 [N, ldb] = weight integers (int8), wsum [N] = row sums of B8; the result equals the bf16 path's
+// bit for bit (both accumulate the same integers exactly).  Tall 208 x 384 tiles only: N % 384 == 0, K % 64 == 0.
+int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
+                      int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
+                      hipStream_t st, const NTPost* post) {
+    if (M < 1 || N % 384 != 0 || K % 64 != 0 || lda % 16 != 0 || ldb % 16 != 0 || ldc % 4 != 0 || !wsum || !a_qp) {
+        set_error("gemm_nt_i8: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d (need N%%384==0, K%%64==0, ld%%16==0)", M, N, K, lda, ldb);
+        return 1;
+    }
+    NTArgs a{reinterpret_cast<const __bf16*>(A8), nullptr, reinterpret_cast<const __bf16*>(B8), nullptr, C, M, N, K / 2, lda / 2, ldb / 2, ldc, s1, s2,
+             col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, 0, 0, wsum, a_qp, center, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+    if (post) {
+        if (post->mode != 3 && post->mode != 4) { set_error("gemm_nt_i8: epilogue mode %d not available", post->mode); return 1; }
+        a.post_mode = a.pm = post->mode;
+        a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax;
+        a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
+        a.post_code = reinterpret_cast<uint16_t*>(post->code);
+        if (post->mode == 4 && (!a.post_qp || !a.out_hi || !a.out_lo || !a.post_code || a.post_qmax - a.post_qmin >= 256)) {
+            set_error("gemm_nt_i8: incomplete arguments for epilogue mode 4");
+            return 1;
+        }
+    } else if (!C) {
+        set_error("gemm_nt_i8: null output");
+        return 1;
+    }
+    constexpr size_t lds = 3 * (208 + 384) * 64;
+    nt_launch<1, 3, 1, 13, 1, 0, 8, 3, 32, 0, true>(a, cdiv(M, 208) * (N / 384), lds, st);
     return 0;
 }
 

@@ -48,6 +48,9 @@ struct NTPost {
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
                    const void* B_lo = nullptr, const NTPost* post = nullptr);
+int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
+                      int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
+                      hipStream_t st, const NTPost* post = nullptr);
 // scratch that lets every wgrad shape take the two-phase (non-atomic, bit-reproducible) reduction: 256 workgroups x the largest tile
 constexpr int64_t kTnScratchBytes = 256ll * 128 * 384 * 4;
 // Optional: run the second phase (k_tn_reduce) on a side stream so the next GEMM does not wait for it.  The scratch is then used as two
@@ -65,12 +68,13 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
                    const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
                    float* dbias, const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0, TnAsync* async = nullptr);
 // ---- elt.hip
-int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st);
+int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st,
+                       void* out8 = nullptr, int center = 0);
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
                             float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
                             int64_t M, int D, int T, hipStream_t st);
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
-                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st);
+                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8 = nullptr, int center = 0);
 int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, void* G_hi, void* G_lo, int64_t n, hipStream_t st);
 int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, const float* col_scale, int ncols,
                     void* dst_hi, void* dst_lo, int64_t n, hipStream_t st);
@@ -93,10 +97,14 @@ struct WQpTab {
     uint32_t* ws[kMaxW]; float* rmin[kMaxW]; float* rmax[kMaxW]; float* scale[kMaxW]; int32_t* zp[kMaxW]; float* qp[kMaxW];
     const int64_t* obs_on[kMaxW]; const int64_t* fq_on[kMaxW]; int N[kMaxW], blk0[kMaxW + 1]; int n, per_channel, nslots, qmin, qmax; float c;
 };
-struct WQuantTab { const float* W[kMaxW]; const float* qp[kMaxW]; void* wq[kMaxW]; void* wqT[kMaxW]; int N[kMaxW], K[kMaxW], blk0[kMaxW + 1]; int n, per_channel, qmin, qmax; };
+struct WQuantTab {
+    const float* W[kMaxW]; const float* qp[kMaxW]; void* wq[kMaxW]; void* wqT[kMaxW]; void* w8[kMaxW]; int32_t* wsum[kMaxW];   // w8 / wsum optional (int8 copies + row sums)
+    int N[kMaxW], K[kMaxW], blk0[kMaxW + 1]; int n, per_channel, qmin, qmax;
+};
 int launch_w_observe_all(WObsTab& t, hipStream_t st);      // fills blk0
 int launch_w_qparams_all(WQpTab& t, hipStream_t st);       // fills blk0
 int launch_w_quant_all(WQuantTab& t, hipStream_t st);      // fills blk0
+int launch_zero_i32(int32_t* p, int64_t n, hipStream_t st);
 int launch_wquant(const float* W, const float* qp, int per_channel, int qmin, int qmax, void* wq, void* wqT, int N, int K, hipStream_t st);
 
 // ---- attn.hip

@@ -74,6 +74,38 @@ def test_gemm_nt_integer_exact(native_lib):
     assert torch.equal(C.double(), A.double() @ B.double().t())  # integers < 2^24: exact
 
 
+@pytest.mark.parametrize("M,N,K", [(1576, 1152, 384), (300, 384, 768), (50432, 1536, 384)])
+@pytest.mark.parametrize("zp,center", [(131, 128), (0, 128), (77, 64)])
+def test_gemm_nt_i8_equals_bf16_path(native_lib, M, N, K, zp, center):
+    """int8 MFMA forward GEMM == the bf16-integer GEMM, bit for bit (both accumulate the same integers exactly)."""
+    torch.manual_seed(M + N + K + zp)
+    dev = "cuda"
+    qmax = 2 * center - 1
+    q = torch.randint(0, qmax + 1, (M, K), device=dev)
+    W = torch.randint(-128, 128, (N, K), device=dev)
+    A16 = (q - zp).to(torch.bfloat16)
+    B16 = W.to(torch.bfloat16)
+    A8 = (q - center).to(torch.int8)
+    B8 = W.to(torch.int8)
+    wsum = W.sum(1).to(torch.int32)
+    aqp = torch.tensor([0.0173, 1 / 0.0173, float(zp), 1.0], device=dev)
+    s1 = torch.tensor([0.0173], device=dev)
+    s2 = torch.tensor([0.0041], device=dev)
+    bias = torch.randn(N, device=dev)
+    C16 = torch.empty(M, N, device=dev)
+    C8 = torch.empty(M, N, device=dev)
+    st16 = torch.tensor([0xFF800000 - (1 << 32), 0x007FFFFF], dtype=torch.int32, device=dev)
+    st8 = st16.clone()
+    assert native_lib.qatvit_gemm_nt(A16.data_ptr(), None, B16.data_ptr(), C16.data_ptr(), M, N, K, K, K, N, s1.data_ptr(), s2.data_ptr(), None,
+                                     bias.data_ptr(), st16.data_ptr(), _st()) == 0, native_lib.qatvit_last_error()
+    assert native_lib.qatvit_gemm_nt_i8(A8.data_ptr(), B8.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), center, C8.data_ptr(), M, N, K, K, K, N,
+                                        s1.data_ptr(), s2.data_ptr(), None, bias.data_ptr(), st8.data_ptr(), _st()) == 0, native_lib.qatvit_last_error()
+    assert torch.equal(C8, C16)
+    assert torch.equal(st8, st16)
+    ref = ((q - zp).double() @ W.double().t()) * (0.0173 * 0.0041) + bias.double()
+    assert rel_l2(C8.cpu(), ref.cpu()) < 1e-6
+
+
 def test_gemm_rejects_bad_shapes(native_lib):
     x = torch.zeros(128, 128, device="cuda")
     assert native_lib.qatvit_gemm_nt(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), 64, 64, 64, 64, 64, 64, None, None, None, None, None, None) != 0

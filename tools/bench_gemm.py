@@ -36,6 +36,16 @@ def nt(a_f32, N, K, stats=False, flags=0):
     passes = 2 if a_f32 else 1
     return t, 2.0 * M * N * K / t / 1e6, 2.0 * M * N * K * passes / t / 1e6
 
+def nt_i8(N, K):
+    q = torch.randint(0, 256, (M, K), device=dev); W = torch.randint(-128, 128, (N, K), device=dev)
+    A8 = (q - 128).to(torch.int8); B8 = W.to(torch.int8); wsum = W.sum(1).to(torch.int32)
+    aqp = torch.tensor([0.01, 100.0, 131.0, 1.0], device=dev)
+    C = torch.empty(M, N, device=dev); bias = torch.randn(N, device=dev); s1 = torch.tensor([0.01], device=dev)
+    t = timeit(lambda: L.qatvit_gemm_nt_i8(A8.data_ptr(), B8.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), 128, C.data_ptr(), M, N, K, K, K, N,
+                                           s1.data_ptr(), None, None, bias.data_ptr(), None, st))
+    return t, 2.0 * M * N * K / t / 1e6, 2.0 * M * N * K / t / 1e6
+
+
 def tn(q_f32, N, Kw):
     Ph, Pl = split(torch.randn(M, N, device=dev))
     if q_f32:
@@ -55,6 +65,9 @@ print("NT shapes (us, algorithmic TF/s, issued-MFMA TF/s)")
 for name, a, N, K in [("qkv fwd", 0, 1152, 384), ("fc1 fwd", 0, 1536, 384), ("proj fwd", 1, 384, 384), ("fc2 fwd", 1, 384, 1536),
                       ("qkv dgrad", 1, 384, 1152), ("fc1 dgrad", 1, 384, 1536), ("fc2 dgrad", 1, 1536, 384)]:
     print(f"  {name:10s} a_f32={a} N={N:5d} K={K:5d}: " + "  ".join(f"{v:9.1f}" for v in nt(a, N, K)))
+print("NT int8 (same products on v_mfma_i32_16x16x64_i8)")
+for name, N, K in [("qkv fwd", 1152, 384), ("fc1 fwd", 1536, 384)]:
+    print(f"  {name:10s} i8      N={N:5d} K={K:5d}: " + "  ".join(f"{v:9.1f}" for v in nt_i8(N, K)))
 if os.environ.get("SKIP_TN"): sys.exit(0)
 print("TN shapes")
 for name, q, N, Kw in [("qkv wgrad", 0, 1152, 384), ("fc1 wgrad", 0, 1536, 384), ("proj wgrad", 1, 384, 384), ("fc2 wgrad", 1, 384, 1536)]:
