@@ -595,7 +595,8 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     // groups.  M = B*197 rows over 256 CUs is 197 rows per CU: 243 tiles of 208 rows fill the chip in ONE round for N = 384
     // (128-row tiles: 394 tiles = 2 rounds at 77 %), and a 208-row tile moves 7.7 B into LDS per row and k against 10 B for 128 rows.
     static const int tall = getenv("QATVIT_NT_TALL") ? atoi(getenv("QATVIT_NT_TALL")) : 1;
-    if (tall == 4 && A_lo && N % 384 == 0 && K % 32 == 0) {   // experiment: 112 x 384 tiles, 4 waves, 2 stages (76 KiB): two workgroups per CU
+    static const int pm5_4w = getenv("QATVIT_NT_PM5_4W") ? atoi(getenv("QATVIT_NT_PM5_4W")) : 0;
+    if ((tall == 4 || (pm5_4w && a.pm == 5)) && A_lo && N % 384 == 0 && K % 32 == 0) {   // 112 x 384 tiles, 4 waves, 2 stages (76 KiB): two workgroups per CU
         constexpr size_t lds4 = 2 * (2 * 112 + 384) * 64;
         nt_launch<2, 2, 1, 7, 1, 0, 4, 6, 32, 0>(a, cdiv(M, 112) * (N / 384), lds4, st);
         return 0;
