@@ -925,9 +925,20 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, i
     const int wave = rem / per_wave, f = (rem % per_wave) / 64, lane = rem & 63;
     const int i = f / TNT, j = f % TNT, r = lane & 15, g = lane >> 4, wm = wave / WNK, wn = wave % WNK;
     const float4* src = reinterpret_cast<const float4*>(p.partial) + idx;
+    // four splits' loads in flight per thread; the additions stay in split order (bit-reproducible)
+    const int64_t sstride = (int64_t)p.tiles * per_tile;
     float4 a = src[0];
-    for (int s = 1; s < splits; ++s) {
-        const float4 b = src[(int64_t)s * p.tiles * per_tile];
+    int s = 1;
+    for (; s + 3 < splits; s += 4) {
+        const float4 b0 = src[(int64_t)s * sstride], b1 = src[(int64_t)(s + 1) * sstride], b2 = src[(int64_t)(s + 2) * sstride],
+                     b3 = src[(int64_t)(s + 3) * sstride];
+        a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+        a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+        a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+        a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+    }
+    for (; s < splits; ++s) {
+        const float4 b = src[(int64_t)s * sstride];
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     const int BKW = WNK * TNT * 16, tilesK = p.Kw / BKW;
