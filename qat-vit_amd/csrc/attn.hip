@@ -434,9 +434,16 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     char* sDl = smem + 2 * IMG;
     const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-    const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
+    const int T = p.T, D = p.D, ld = 3 * D;
     const float* base = p.qkv + (int64_t)b * T * ld + h * HD;
     const float* dObase = p.dO + (int64_t)b * T * D + h * HD;
+    // per-row softmax constants into LDS once: read from global inside the sweep they are a load-use chain per query-tile pair
+    float* sLse = reinterpret_cast<float*>(smem + 3 * IMG);
+    float* sDlt = sLse + NKT * 16;
+    for (int i = threadIdx.x; i < NKT * 16; i += NWV * 64) {
+        sLse[i] = p.lse[(int64_t)blockIdx.x * (NKT * 16) + min(i, p.T - 1)];
+        sDlt[i] = p.delta[(int64_t)blockIdx.x * (NKT * 16) + min(i, p.T - 1)];
+    }
     stage_tokens<HD, true, NKT, NWV>(sQt, base, T, ld, q);
     stage_split_tr<HD, NKT, NWV>(sDh, sDl, dObase, T, D);
     __syncthreads();
@@ -444,8 +451,6 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float c = q.s * q.s * p.softmax_scale;
     const int nkt = (T + 15) / 16;
-    const float* lse = p.lse + (int64_t)blockIdx.x * TP;
-    const float* delta = p.delta + (int64_t)blockIdx.x * TP;
     int jt[U];
     bool has[U];
 #pragma unroll
@@ -487,8 +492,8 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
             for (int e = 0; e < 4; ++e) {
                 const int qq = 16 * qt + 4 * g + e;
                 qval[v][e] = qq < T;
-                lse_r[v][e] = lse[min(qq, T - 1)];
-                dlt_r[v][e] = delta[min(qq, T - 1)];
+                lse_r[v][e] = sLse[qq];
+                dlt_r[v][e] = sDlt[qq];
             }
         }
         bf16x8 dth[ND], dtl[ND], qtf[ND];
@@ -594,16 +599,16 @@ static void launch3(int which, const AttnArgs& a, hipStream_t st) {
     const int grid = a.B * a.H;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 8 * (HD + 4) * 4)),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dq<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img + kAW * 8 * (HD + 4) * 4)),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img)), true);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img + NKT * 128)),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv<HD, NKT, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * img + NKT * 128)), true);
     (void)once;
     const size_t scratch = (size_t)kAW * 8 * (HD + 4) * sizeof(float);   // half-tile re-tiling scratch: 2 workgroups per CU (fwd, dQ)
     if (which == 0) k_attn_fwd<HD, NKT><<<grid, kAW * 64, 2 * img + scratch, st>>>(a);
     else if (which == 1) k_attn_bwd_dq<HD, NKT><<<grid, kAW * 64, 2 * img + scratch, st>>>(a);
     else {
         static const int dkv16 = getenv("QATVIT_ATTN_DKV16") ? atoi(getenv("QATVIT_ATTN_DKV16")) : 0;   // 16 waves x one key tile each (tuning)
-        if (dkv16 && NKT > 8) k_attn_bwd_dkv<HD, NKT, 16><<<grid, 16 * 64, 3 * img, st>>>(a);
-        else k_attn_bwd_dkv<HD, NKT, 8><<<grid, kAW * 64, 3 * img, st>>>(a);
+        if (dkv16 && NKT > 8) k_attn_bwd_dkv<HD, NKT, 16><<<grid, 16 * 64, 3 * img + NKT * 128, st>>>(a);
+        else k_attn_bwd_dkv<HD, NKT, 8><<<grid, kAW * 64, 3 * img + NKT * 128, st>>>(a);
     }
 }
 
