@@ -84,6 +84,36 @@ def _worker(rank, world, port, q):
                 if not torch.equal(a, b):
                     ok = False
                     msgs.append(f"it{it} buffer {n}")
+        # the reference's own wrapper, unchanged: DDP(prepared) (qat_trainer.py:311) around the native module.  torch's reducer then does
+        # the bucketing / all-reduce and broadcasts the fake-quant buffers from rank 0 before every forward, in place, into the very
+        # tensors the engine reads by pointer.
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        inner = make(11 + rank)
+        ddp = DDP(inner, device_ids=[0])                      # construction broadcasts rank 0's parameters and buffers
+        local2 = make(11)
+        for it in range(2):
+            src = [{k: v.cpu() for k, v in local2.state_dict().items() if "activation_post_process" in k or "weight_fake_quant" in k}]
+            dist.broadcast_object_list(src, src=0)
+            local2.load_state_dict({k: v.cuda() for k, v in src[0].items()}, strict=False)
+            step(local2, x, y)
+            want = []
+            for p in local2.parameters():
+                t = p.grad.detach().cpu().clone()
+                dist.all_reduce(t)
+                want.append(t / world)
+            step(ddp, x, y)
+            for (n, p), w in zip(inner.named_parameters(), want):
+                e = rel_l2(p.grad.cpu(), w)
+                if not e < 1e-5:
+                    ok = False
+                    msgs.append(f"stock-DDP it{it} grad {n} {e:.2e}")
+            for (n, a), (_, b) in zip(local2.named_buffers(), inner.named_buffers()):
+                if not torch.equal(a, b):
+                    ok = False
+                    msgs.append(f"stock-DDP it{it} buffer {n}")
+        if engine_of(inner) is None:
+            ok = False
+            msgs.append("stock-DDP: native engine not bound")
         # evaluation on rank 0 only (qat_trainer.py:370-371): must not issue a collective (would hang: rank 1 never joins)
         if rank == 0:
             dp.eval()
