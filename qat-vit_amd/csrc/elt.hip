@@ -93,19 +93,25 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
                                                           int qmin, int qmax, const float* __restrict__ cls, const float* __restrict__ pos,
                                                           float* __restrict__ x_new, float* __restrict__ mean, float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                          uint32_t* __restrict__ stats, int stat_slots, int64_t M, int D, int T) {
+                                                          uint32_t* __restrict__ stats, int stat_slots, int64_t M, int D, int T,
+                                                          unsigned long long* __restrict__ maskbits) {
+    // maskbits (MODE 1, optional): the STE mask of fq(Y), one bit per element, as wave ballots - word [(row * nv + j) * 4 + e] holds in
+    // bit `lane` the mask of column lane * 4 + 256 j + e.  k_ln_bwd_fq (same lane -> column mapping) reads it back with scalar loads,
+    // so the backward never touches the fp32 Y again.
     const QP q = load_qp(qpY);
     const int lane = threadIdx.x & 63;
     const int nv = (D + 255) / 256;
     float mn = INFINITY, mx = -INFINITY;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
         float4 v[kMaxV];
+        bool inb[kMaxV][4];
         float s = 0.f;
         const int t = (int)(row % T);
         const int64_t b = row / T;
 #pragma unroll
         for (int j = 0; j < kMaxV; ++j) {
             const int c = lane * 4 + 256 * j;
+            inb[j][0] = inb[j][1] = inb[j][2] = inb[j][3] = false;
             if (j < nv && c < D) {
                 float4 y = make_float4(0.f, 0.f, 0.f, 0.f), base;
                 bool in;
@@ -120,7 +126,9 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
                 } else {
                     base = *reinterpret_cast<const float4*>(x_prev + row * D + c);
                     const float4 r = *reinterpret_cast<const float4*>(Y + row * D + c);
-                    y = make_float4(fqv(r.x, q, qmin, qmax, in), fqv(r.y, q, qmin, qmax, in), fqv(r.z, q, qmin, qmax, in), fqv(r.w, q, qmin, qmax, in));
+                    bool i0, i1, i2, i3;
+                    y = make_float4(fqv(r.x, q, qmin, qmax, i0), fqv(r.y, q, qmin, qmax, i1), fqv(r.z, q, qmin, qmax, i2), fqv(r.w, q, qmin, qmax, i3));
+                    inb[j][0] = i0; inb[j][1] = i1; inb[j][2] = i2; inb[j][3] = i3;   // (balloted and stored after the row's loads: see below)
                 }
                 v[j] = make_float4(base.x + y.x, base.y + y.y, base.z + y.z, base.w + y.w);
                 *reinterpret_cast<float4*>(x_new + row * D + c) = v[j];
@@ -141,6 +149,14 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
         }
         const float rs = rsqrtf(wave_sum(qq) / (float)D + eps);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        if (MODE == 1 && maskbits) {   // ballots in uniform control flow (lane masks stay in scalar registers); lane e stores word e
+#pragma unroll
+            for (int j = 0; j < kMaxV; ++j)
+                if (j < nv) {
+                    const unsigned long long b0 = __ballot(inb[j][0]), b1 = __ballot(inb[j][1]), b2 = __ballot(inb[j][2]), b3 = __ballot(inb[j][3]);
+                    if (lane < 4) maskbits[(row * nv + j) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+                }
+        }
 #pragma unroll
         for (int j = 0; j < kMaxV; ++j) {
             const int c = lane * 4 + 256 * j;
@@ -266,28 +282,50 @@ __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ d, c
 // g_in = dH * mask(LN(x));  dx_out = (ACC ? dx_in : 0) + LNbwd(g_in);  dgamma/dbeta += column sums
 // rows_sel: if non-null only rows listed there carry a gradient (final norm: cls tokens); others get dx_out = dx_in/0.
 // NV = float4 column groups per lane (ceil(D / 256)): exact, so registers and the LDS column-sum staging scale with D
-template <int ACC, int NV, int WPB = 8>   // WPB waves per block: column sums meet in LDS, so more waves per block = same atomics, more rows in flight
+// FUSE: the residual-stream gradient this kernel produces is also the gradient of the NEXT (earlier) branch output; store it a second
+// time as the (hi, lo) bf16 pair that branch's dgrad / wgrad GEMMs read, multiplied by that output's STE mask (the ballot words
+// k_resid_fq_lnstats wrote in the forward) and the optional per-channel weight scale: what k_mask_bwd<0> would compute from a second
+// read of dx_out and of the fp32 pre-FQ tensor.
+template <int ACC, int NV, int WPB = 8, bool FUSE = false>   // WPB waves per block: column sums meet in LDS, so more waves per block = same atomics, more rows in flight
 __global__ __launch_bounds__(WPB * 64) void k_ln_bwd_fq(const float* __restrict__ dH, int64_t dH_row_stride_rows, const float* __restrict__ x,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ qp, int qmin, int qmax,
                                                    const float* __restrict__ dx_in, float* __restrict__ dx_out, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, int64_t M, int D, int T, int cls_only) {
+                                                   float* __restrict__ dbeta, int64_t M, int D, int T, int cls_only,
+                                                   const unsigned long long* __restrict__ nmask, const float* __restrict__ ncs,
+                                                   __bf16* __restrict__ nhi, __bf16* __restrict__ nlo) {
     const QP q = load_qp(qp);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long mk[NV][4];   // this row's mask words (wave-uniform: scalar loads, requested at the top of the row)
+    auto fuse_store = [&](int64_t row, int j, int c, const float4& o) {
+        const unsigned long long m0 = mk[j][0], m1 = mk[j][1], m2 = mk[j][2], m3 = mk[j][3];
+        float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (ncs) cs = *reinterpret_cast<const float4*>(ncs + c);
+        store_split4(nhi, nlo, row * D + c, (m0 >> lane) & 1 ? o.x * cs.x : 0.f, (m1 >> lane) & 1 ? o.y * cs.y : 0.f,
+                     (m2 >> lane) & 1 ? o.z * cs.z : 0.f, (m3 >> lane) & 1 ? o.w * cs.w : 0.f);
+    };
     constexpr int nv = NV;
     float4 ag[NV], ab[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t row = (int64_t)blockIdx.x * WPB + wave; row < M; row += (int64_t)gridDim.x * WPB) {
         const bool live = !cls_only || (row % T) == 0;
+        if (FUSE) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mk[j][e] = nmask[(row * NV + j) * 4 + e];
+        }
         if (!live) {
             // no gradient reaches this token through the (cls-pooled) head
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int c = lane * 4 + 256 * j;
-                if (j < nv && c < D)
-                    *reinterpret_cast<float4*>(dx_out + row * D + c) =
-                        ACC ? *reinterpret_cast<const float4*>(dx_in + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < nv && c < D) {
+                    const float4 o = ACC ? *reinterpret_cast<const float4*>(dx_in + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(dx_out + row * D + c) = o;
+                    if (FUSE) fuse_store(row, j, c, o);
+                }
             }
             continue;
         }
@@ -330,6 +368,7 @@ __global__ __launch_bounds__(WPB * 64) void k_ln_bwd_fq(const float* __restrict_
                     o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
                 }
                 *reinterpret_cast<float4*>(dx_out + row * D + c) = o;
+                if (FUSE) fuse_store(row, j, c, o);
             }
         }
     }
@@ -546,12 +585,13 @@ int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qm
 
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
                             float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
-                            int64_t M, int D, int T, hipStream_t st) {
+                            int64_t M, int D, int T, hipStream_t st, void* maskbits) {
     if (D % 4 != 0 || D > 256 * kMaxV) { set_error("resid_fq_lnstats: D=%d unsupported (need D%%4==0, D<=768)", D); return 1; }
     if (mode == 0)
-        k_resid_fq_lnstats<0><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T);
+        k_resid_fq_lnstats<0><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T, nullptr);
     else
-        k_resid_fq_lnstats<1><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T);
+        k_resid_fq_lnstats<1><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T,
+                                                            reinterpret_cast<unsigned long long*>(maskbits));
     return 0;
 }
 
@@ -578,13 +618,21 @@ int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* q
 
 int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                      const float* qp, int qmin, int qmax, const float* dx_in, float* dx_out, float* dgamma, float* dbeta, int64_t M, int D, int T,
-                     int cls_only, hipStream_t st) {
+                     int cls_only, hipStream_t st, const LnBwdNext* next) {
     if (D % 4 != 0 || D > 256 * kMaxV) { set_error("ln_bwd_fq: D=%d unsupported", D); return 1; }
     static const int rpw = getenv("QATVIT_LNB_ROWS") ? atoi(getenv("QATVIT_LNB_ROWS")) : 16;   // rows per wave (8 waves per block): fewer blocks = fewer same-address dgamma/dbeta atomics (12 ns each, serialised)
     int grid = (int)((M + 8 * rpw - 1) / (8 * rpw));
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-#define QV_LNB(ACC_, NV_) k_ln_bwd_fq<ACC_, NV_, 8><<<grid, 512, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only)
+    const unsigned long long* nm = next ? reinterpret_cast<const unsigned long long*>(next->maskbits) : nullptr;
+    const float* ncs = next ? next->colscale : nullptr;
+    __bf16* nh = next ? reinterpret_cast<__bf16*>(next->out_hi) : nullptr;
+    __bf16* nl = next ? reinterpret_cast<__bf16*>(next->out_lo) : nullptr;
+#define QV_LNB(ACC_, NV_)                                                                                                                          \
+    do {                                                                                                                                           \
+        if (next) k_ln_bwd_fq<ACC_, NV_, 8, true><<<grid, 512, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only, nm, ncs, nh, nl); \
+        else k_ln_bwd_fq<ACC_, NV_, 8, false><<<grid, 512, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only, nm, ncs, nh, nl); \
+    } while (0)
     const int nv = (D + 255) / 256;
     if (acc) { if (nv == 1) QV_LNB(1, 1); else if (nv == 2) QV_LNB(1, 2); else QV_LNB(1, 3); }
     else { if (nv == 1) QV_LNB(0, 1); else if (nv == 2) QV_LNB(0, 2); else QV_LNB(0, 3); }

@@ -64,7 +64,7 @@ static int wparam(const Dims& d, int wi) {  // index of the weight tensor in par
 struct Plan {
     // byte offsets into the workspace
     int64_t stats, qp_act, qp_w, imgq, Y0, meanF, rstdF, hq, logits_pre;
-    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2;  // per-block base, stride blk
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
     int64_t blk_stride;
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
@@ -116,6 +116,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->G_hi = take(M * Hd * 2); p->G_lo = take(M * Hd * 2);
     p->Y2 = take(M * D * 4);
     p->h1q8 = take(M * D); p->h2q8 = take(M * D);
+    p->mproj = take(ln_maskbits_bytes(M, (int)D)); p->m2 = take(ln_maskbits_bytes(M, (int)D));
     p->blk_stride = o - b0;
     o = b0 + p->blk_stride * d.depth;
     // x_in[depth] (input of the final norm) lives where block `depth` would start
@@ -348,7 +349,7 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         x.qparams_act(x.aidx(i, AB_PROJ));
         launch_resid_fq_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, nullptr, nullptr, xmid,
                                 x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B), c.ln_eps,
-                                x.act_stats(x.aidx(i, AB_N2)), kStatSlots, d.M, d.D, d.T, st);
+                                x.act_stats(x.aidx(i, AB_N2)), kStatSlots, d.M, d.D, d.T, st, x.blk<void>(p.mproj, i));
         // norm2 -> fc1 -> gelu -> fc2
         x.qparams_act(x.aidx(i, AB_N2));
         launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
@@ -387,7 +388,8 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
         float* mean = last ? x.at<float>(p.meanF) : x.blk<float>(p.mean1, i + 1);
         float* rstd = last ? x.at<float>(p.rstdF) : x.blk<float>(p.rstd1, i + 1);
         launch_resid_fq_lnstats(1, xmid, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, nullptr, nullptr, x.blk<float>(p.x_in, i + 1),
-                                mean, rstd, g, bt, c.ln_eps, x.act_stats(last ? x.a_norm() : x.aidx(i + 1, AB_N1)), kStatSlots, d.M, d.D, d.T, st);
+                                mean, rstd, g, bt, c.ln_eps, x.act_stats(last ? x.a_norm() : x.aidx(i + 1, AB_N1)), kStatSlots, d.M, d.D, d.T, st,
+                                x.blk<void>(p.m2, i));
     }
     // ---- final norm (observer saw all tokens), cls pooling, head
     x.qparams_act(x.a_norm());
@@ -415,6 +417,12 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
     // dxA always holds the gradient w.r.t. the current block's OUTPUT at stage entry.
     float* dxA = x.at<float>(p.dxA);
     float* dxB = x.at<float>(p.dxB);
+    // QATVIT_LN_FUSE (default on): every LayerNorm backward also emits the masked (hi, lo) gradient of the branch output that precedes
+    // it - from the mask bits of the forward - instead of a k_mask_bwd pass re-reading dx and the fp32 pre-FQ tensor.  Stages must then
+    // run in order within one backward (they already had to: dxA carries over).
+    static const bool ln_fuse = !(getenv("QATVIT_LN_FUSE") && atoi(getenv("QATVIT_LN_FUSE")) == 0);
+    void* const dYh_all = x.at<void>(p.dYs_hi);
+    void* const dYl_all = x.at<void>(p.dYs_lo);
     for (int s = stage_from; s <= stage_to; ++s) {
         if (s == 0) {
             const int base = P_BLOCK0 + B_COUNT * d.depth;
@@ -422,8 +430,10 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             launch_head_bwd(dlogits, x.at<float>(p.logits_pre), x.act_qp(x.a_head()), qa, qb, x.at<float>(p.hq), x.act_qp(x.a_norm()),
                             x.at<void>(p.w_off[wh]), x.prm(base + 2), x.wfq[wh].scale, x.wfq[wh].zero_point, c.w_per_channel, c.w_qmin, c.w_qmax,
                             G(base + 2), G(base + 3), x.at<float>(p.dh), d.B, d.D, d.C, st);
+            const LnBwdNext nx{x.blk<void>(p.m2, d.depth - 1), x.dy_colscale(x.widx(d.depth - 1, WB_FC2)), dYh_all, dYl_all};
             if (launch_ln_bwd_fq(0, x.at<float>(p.dh), x.blk<float>(p.x_in, d.depth), x.at<float>(p.meanF), x.at<float>(p.rstdF), x.prm(base),
-                                 x.prm(base + 1), x.act_qp(x.a_norm()), qa, qb, nullptr, dxA, G(base), G(base + 1), d.M, d.D, d.T, 1, st))
+                                 x.prm(base + 1), x.act_qp(x.a_norm()), qa, qb, nullptr, dxA, G(base), G(base + 1), d.M, d.D, d.T, 1, st,
+                                 ln_fuse ? &nx : nullptr))
                 return 1;
         } else if (s <= d.depth) {
             const int i = d.depth - s;
@@ -431,7 +441,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             void* dYl = x.at<void>(p.dYs_lo);
             const int w_fc2 = x.widx(i, WB_FC2), w_fc1 = x.widx(i, WB_FC1), w_proj = x.widx(i, WB_PROJ), w_qkv = x.widx(i, WB_QKV);
             // ---- MLP branch
-            launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
+            if (!ln_fuse) launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
             if (x.linear_wgrad(dYh, dYl, M, w_fc2, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
             {   // fc2 dgrad with the GELU backward + fc1's STE mask fused into its epilogue: dY1 = (dYs . W_fc2) * gelu'(fq(Y1)) * mask(Y1)
                 NTPost post{x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), x.at<void>(p.dY1_hi),
@@ -443,12 +453,13 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                                BG(i, B_FC1W), BG(i, B_FC1B)))
                 return 1;
             if (x.linear_dgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.at<float>(p.dH))) return 1;
+            const LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dYh, dYl};
             if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_mid, i), x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i),
                                  x.bprm(i, B_N2W), x.bprm(i, B_N2B), x.act_qp(x.aidx(i, AB_N2)), qa, qb, dxA, dxB, BG(i, B_N2W), BG(i, B_N2B), d.M,
-                                 d.D, d.T, 0, st))
+                                 d.D, d.T, 0, st, ln_fuse ? &nx_proj : nullptr))
                 return 1;
             // ---- attention branch (dxB = gradient w.r.t. x_mid)
-            launch_mask_bwd(0, dxB, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, x.dy_colscale(w_proj), d.D, dYh, dYl, d.M * d.D, st);
+            if (!ln_fuse) launch_mask_bwd(0, dxB, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, x.dy_colscale(w_proj), d.D, dYh, dYl, d.M * d.D, st);
             if (x.linear_wgrad(dYh, dYl, M, w_proj, x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), nullptr, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
             if (x.linear_dgrad(dYh, dYl, M, w_proj, x.at<float>(p.dO))) return 1;
             if (launch_attn_bwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
@@ -459,9 +470,11 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                                BG(i, B_QKVW), BG(i, B_QKVB)))
                 return 1;
             if (x.linear_dgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.at<float>(p.dH))) return 1;
+            const LnBwdNext nx_fc2{i > 0 ? x.blk<void>(p.m2, i - 1) : nullptr, i > 0 ? x.dy_colscale(x.widx(i - 1, WB_FC2)) : nullptr, dYh, dYl};
             if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_in, i), x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i),
                                  x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)), qa, qb, dxB, dxA, BG(i, B_N1W), BG(i, B_N1B), d.M,
-                                 d.D, d.T, 0, st))
+                                 d.D, d.T, 0, st,
+                                 (ln_fuse && i > 0) ? &nx_fc2 : nullptr))
                 return 1;
         } else {
             launch_embed_bwd(dxA, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, G(P_POS), G(P_CLS), x.at<void>(p.dY0_hi), x.at<void>(p.dY0_lo), d.B,

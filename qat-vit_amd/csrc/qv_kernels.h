@@ -72,7 +72,11 @@ int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qm
                        void* out8 = nullptr, int center = 0);
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
                             float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
-                            int64_t M, int D, int T, hipStream_t st);
+                            int64_t M, int D, int T, hipStream_t st, void* maskbits = nullptr);
+// STE mask of an [M, D] tensor as wave ballots: ceil(D / 256) * 4 64-bit words per row (written by launch_resid_fq_lnstats mode 1)
+inline int64_t ln_maskbits_bytes(int64_t M, int D) { return M * ((D + 255) / 256) * 32; }
+// optional second output of launch_ln_bwd_fq: split(dx_out * mask * colscale) for the next branch's GEMMs
+struct LnBwdNext { const void* maskbits; const float* colscale; void* out_hi; void* out_lo; };
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
                           int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8 = nullptr, int center = 0);
 int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, void* G_hi, void* G_lo, int64_t n, hipStream_t st);
@@ -80,7 +84,7 @@ int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* q
                     void* dst_hi, void* dst_lo, int64_t n, hipStream_t st);
 int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                      const float* qp, int qmin, int qmax, const float* dx_in, float* dx_out, float* dgamma, float* dbeta, int64_t M, int D, int T,
-                     int cls_only, hipStream_t st);
+                     int cls_only, hipStream_t st, const LnBwdNext* next = nullptr);
 int launch_head_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp_norm, int qmin,
                     int qmax, const void* wq, const float* w_scale, int w_per_channel, const float* bias, float* hq, float* logits_pre,
                     uint32_t* stats, int stat_slots, int B, int D, int T, int C, hipStream_t st);
