@@ -204,6 +204,94 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
         __syncthreads();
         constexpr int C4 = BN / 4;              // float4 per staged row
         const int rows_h = BM - SLAB * h < SLAB ? BM - SLAB * h : SLAB;
+#ifndef QV_EPI_U
+#define QV_EPI_U 4
+#endif
+        if constexpr ((PM == 0 || PM == 4 || PM == 5) && QV_EPI_U > 1) {
+            // Software-pipelined store loop: U iterations' LDS reads (staged values, codes), then their table lookups, then the stores.
+            // The rolled loop below is one LDS round trip (two with a table) per 16 B stored at two waves per SIMD; the row guard moves
+            // onto the stores so that no branch separates the reads.
+            constexpr int U = QV_EPI_U, NT_ = NW * 64;
+            const int limit = rows_h * C4;
+            for (int base = tid; base < limit; base += U * NT_) {
+                float4 v[U];
+                uint2 c2[U];
+                int64_t off[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = base + u * NT_;
+                    const int rl = idx / C4, c4 = idx % C4;
+                    const int row = m0 + SLAB * h + rl;
+                    ok[u] = idx < limit && row < p.M;
+                    off[u] = (int64_t)row * p.ldc + n0 + 4 * c4;
+                    const int rls = idx < limit ? rl : 0;      // (stay inside the staged slab)
+                    v[u] = *reinterpret_cast<const float4*>(sC + rls * LDC + 4 * c4);
+                    if constexpr (PM == 5) {
+                        if constexpr (CODE_LDS) c2[u] = *reinterpret_cast<const uint2*>(sCode + (rls * BN + 4 * c4) * 2);
+                        else c2[u] = ok[u] ? *reinterpret_cast<const uint2*>(p.post_code + off[u]) : make_uint2(0u, 0u);
+                    }
+                }
+                if constexpr (PM == 0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (ok[u]) *reinterpret_cast<float4*>(p.C + off[u]) = v[u];
+                } else if constexpr (PM == 4) {
+                    const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
+                    uint32_t w[U][4], cd[U][4];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float cv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = rintf(cv[e] * qinv) + qzp;
+                            const uint32_t ix = (uint32_t)(int)(fminf(fmaxf(t, fmin_), fmax_) - fmin_);
+                            w[u][e] = sLutF[ix];
+                            cd[u][e] = ix | ((t >= fmin_ && t <= fmax_) ? 0x8000u : 0u);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        uint2 hi2, lo2, cc;
+                        hi2.x = (w[u][0] & 0xffffu) | (w[u][1] << 16); hi2.y = (w[u][2] & 0xffffu) | (w[u][3] << 16);
+                        lo2.x = (w[u][0] >> 16) | (w[u][1] & 0xffff0000u); lo2.y = (w[u][2] >> 16) | (w[u][3] & 0xffff0000u);
+                        cc.x = cd[u][0] | (cd[u][1] << 16); cc.y = cd[u][2] | (cd[u][3] << 16);
+                        if (ok[u]) {
+                            *reinterpret_cast<uint2*>(p.out_hi + off[u]) = hi2;
+                            *reinterpret_cast<uint2*>(p.out_lo + off[u]) = lo2;
+                            *reinterpret_cast<uint2*>(p.post_code + off[u]) = cc;
+                        }
+                    }
+                } else {   // PM == 5
+                    float dg[U][4];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t cd[4] = {c2[u].x & 0xffffu, c2[u].x >> 16, c2[u].y & 0xffffu, c2[u].y >> 16};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dg[u][e] = sLut[cd[e] & 0xffu];   // (unconditional: no branch between the lookups)
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + (int)((base + u * NT_) % C4) * 4);
+                        const float cv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, sv[4] = {cs.x, cs.y, cs.z, cs.w};
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 oh, ol;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t cde = (e & 1) ? ((e & 2) ? c2[u].y : c2[u].x) >> 16 : ((e & 2) ? c2[u].y : c2[u].x);
+                            const float o = (cde & 0x8000u) ? cv[e] * dg[u][e] * sv[e] : 0.f;
+                            oh[e] = (__bf16)o;
+                            ol[e] = (__bf16)(o - (float)oh[e]);
+                        }
+                        if (ok[u]) {
+                            *reinterpret_cast<bf16x4*>(p.out_hi + off[u]) = oh;
+                            *reinterpret_cast<bf16x4*>(p.out_lo + off[u]) = ol;
+                        }
+                    }
+                }
+            }
+        } else
         for (int idx = tid; idx < rows_h * C4; idx += NW * 64) {
             const int rl = idx / C4, c4 = idx % C4;
             const int row = m0 + SLAB * h + rl;
