@@ -45,6 +45,9 @@ __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t byt
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: between epilogue slabs that is a wait for every
+// global store of the slab just written to be acknowledged (and for LDS-DMA that was deliberately started early).
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N> __device__ inline void wait_vmcnt() {
     static_assert(N >= 0 && N <= 20, "vmcnt immediate");
 #define QV_W(n) if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -137,7 +140,28 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     // per store-loop iteration is a load-use chain at 8 waves per CU: fc2 dgrad took 296 us against 160 us for the plain store)
     constexpr int CODE_BYTES = SLAB * BN * 2;
     constexpr bool CODE_LDS = PM == 5 && RING >= SLAB * LDC * 4 + 1024 + CODE_BYTES && CODE_BYTES % 1024 == 0;
+    // two code buffers when they fit: slab h + 1's codes are requested before slab h is staged and arrive under its store loop (one
+    // buffer exposes most of a 37-49 KB fetch per slab: a CU fills at ~20-30 GB/s)
+    constexpr bool CODE_DB = CODE_LDS && RING >= SLAB * LDC * 4 + 1024 + 2 * CODE_BYTES;
+    constexpr int NSLAB = (BM + SLAB - 1) / SLAB;
     char* sCode = smem + SLAB * LDC * 4 + 1024;
+    // mode 5: the per-column scale through LDS as well.  A conditional global load inside the store loop makes the compiler wait for
+    // vmcnt(0) at the merge point in EVERY iteration - which also drains the previous iteration's stores and the code DMA running ahead.
+    constexpr bool CS_LDS = PM == 5 && CODE_LDS && RING >= SLAB * LDC * 4 + 1024 + (CODE_DB ? 2 : 1) * CODE_BYTES + BN * 4;
+    float* sCs = reinterpret_cast<float*>(sCode + (CODE_DB ? 2 : 1) * CODE_BYTES);
+    if constexpr (CS_LDS) {
+        for (int c = tid; c < BN; c += NW * 64) sCs[c] = p.post_colscale ? p.post_colscale[n0 + c] : 1.f;   // (published by the barrier before the first store loop)
+    }
+    auto code_dma = [&](int h, char* dst) -> int {   // returns the number of DMA instructions this wave issued
+        const __amdgpu_buffer_rsrc_t rCode = make_rsrc(p.post_code, (int64_t)p.M * p.ldc * 2);
+        int n = 0;
+        for (int pc = wave; pc < CODE_BYTES / 1024; pc += NW, ++n) {
+            const int f = pc * 512 + lane * 8;          // flat code index inside the slab, 8 codes (16 B) per lane, never across a row
+            const uint32_t voff = (uint32_t)(((int64_t)(m0 + SLAB * h + f / BN) * p.ldc + n0 + f % BN) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rCode, (lds_void*)(dst + pc * 1024), 16, voff, 0, 0, 0);
+        }
+        return n;
+    };
     if (PM == 4 && tid <= p.post_qmax - p.post_qmin) {
         const float gv = gelu_fwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
         const __bf16 gh = (__bf16)gv;
@@ -175,15 +199,15 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     } else
 #pragma unroll
     for (int h = 0; h < (BM + SLAB - 1) / SLAB; ++h) {
-        if (h) __syncthreads();
-        if constexpr (CODE_LDS) {
-            const __amdgpu_buffer_rsrc_t rCode = make_rsrc(p.post_code, (int64_t)p.M * p.ldc * 2);
-            for (int pc = wave; pc < CODE_BYTES / 1024; pc += NW) {
-                const int f = pc * 512 + lane * 8;          // flat code index inside the slab, 8 codes (16 B) per lane, never across a row
-                const uint32_t voff = (uint32_t)(((int64_t)(m0 + SLAB * h + f / BN) * p.ldc + n0 + f % BN) * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rCode, (lds_void*)(sCode + pc * 1024), 16, voff, 0, 0, 0);
-            }
+        if (h) lds_barrier();   // every wave is done reading the staged slab (its global stores may still be in flight)
+        int code_ahead = 0;   // DMA instructions of this wave younger than the ones slab h waits for
+        if constexpr (CODE_DB) {
+            if (h == 0) code_dma(0, sCode);
+            if (h + 1 < NSLAB) code_ahead = code_dma(h + 1, sCode + ((h + 1) & 1) * CODE_BYTES);   // that buffer was last read in store loop h - 1
+        } else if constexpr (CODE_LDS) {
+            code_dma(h, sCode);
         }
+        const char* sCodeH = sCode + (CODE_DB ? (h & 1) * CODE_BYTES : 0);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int rt = wm * WR + 16 * i;    // first tile row of this 16-row fragment
@@ -200,8 +224,19 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                 }
             }
         }
-        if constexpr (CODE_LDS) wait_vmcnt<0>();
-        __syncthreads();
+        if constexpr (CODE_DB) {
+            // in-order completion: everything older than this wave's code_ahead youngest operations is done, slab h's codes included
+            constexpr int PMAX = (CODE_BYTES / 1024 + NW - 1) / NW;
+            static_assert(PMAX <= 6, "wait ladder below");
+            if (code_ahead == 0) wait_vmcnt<0>();
+            else if (code_ahead == 1) wait_vmcnt<1>();
+            else if (code_ahead == 2) wait_vmcnt<2>();
+            else if (code_ahead == 3) wait_vmcnt<3>();
+            else if (code_ahead == 4) wait_vmcnt<4>();
+            else if (code_ahead == 5) wait_vmcnt<5>();
+            else wait_vmcnt<6>();
+        } else if constexpr (CODE_LDS) wait_vmcnt<0>();
+        lds_barrier();
         constexpr int C4 = BN / 4;              // float4 per staged row
         const int rows_h = BM - SLAB * h < SLAB ? BM - SLAB * h : SLAB;
 #ifndef QV_EPI_U
@@ -228,7 +263,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     const int rls = idx < limit ? rl : 0;      // (stay inside the staged slab)
                     v[u] = *reinterpret_cast<const float4*>(sC + rls * LDC + 4 * c4);
                     if constexpr (PM == 5) {
-                        if constexpr (CODE_LDS) c2[u] = *reinterpret_cast<const uint2*>(sCode + (rls * BN + 4 * c4) * 2);
+                        if constexpr (CODE_LDS) c2[u] = *reinterpret_cast<const uint2*>(sCodeH + (rls * BN + 4 * c4) * 2);
                         else c2[u] = ok[u] ? *reinterpret_cast<const uint2*>(p.post_code + off[u]) : make_uint2(0u, 0u);
                     }
                 }
@@ -273,7 +308,8 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
-                        if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + (int)((base + u * NT_) % C4) * 4);
+                        if constexpr (CS_LDS) cs = *reinterpret_cast<const float4*>(sCs + (int)((base + u * NT_) % C4) * 4);
+                        else if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + (int)((base + u * NT_) % C4) * 4);
                         const float cv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, sv[4] = {cs.x, cs.y, cs.z, cs.w};
                         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                         bf16x4 oh, ol;
@@ -340,7 +376,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     *reinterpret_cast<uint2*>(p.post_code + off) = c2;
                 } else if constexpr (PM == 5) {
                     uint2 c2;
-                    if constexpr (CODE_LDS) c2 = *reinterpret_cast<const uint2*>(sCode + (rl * BN + 4 * c4) * 2);
+                    if constexpr (CODE_LDS) c2 = *reinterpret_cast<const uint2*>(sCodeH + (rl * BN + 4 * c4) * 2);
                     else c2 = *reinterpret_cast<const uint2*>(p.post_code + off);
                     float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + 4 * c4);
@@ -578,7 +614,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
         nt_keep_alive<TM, TNT>(p, acc);
         return;
     }
-    constexpr int SLAB = NSTAGE * STAGE >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;   // the staging slab (+ LUT) must fit inside the ring
+    // the staging slab (+ LUT, + the codes of mode 5) must fit inside the ring; mode 5 prefers 48 rows with two code buffers to 64 with one
+    constexpr int RING_ = NSTAGE * STAGE;
+    constexpr bool PM5_48 = PM == 5 && RING_ >= 48 * (BN + 4) * 4 + 1024 + 2 * 48 * BN * 2 && RING_ < 64 * (BN + 4) * 4 + 1024 + 2 * 64 * BN * 2;
+    constexpr int SLAB = PM5_48 ? 48 : RING_ >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;
     static_assert(NSTAGE * STAGE >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
     nt_epilogue<WM, WN, TM, TNT, SLAB, PM, NSTAGE * STAGE, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
