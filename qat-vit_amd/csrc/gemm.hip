@@ -413,11 +413,11 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     if (p.stats) {
         mn = wave_min(mn);
         mx = wave_max(mx);
-        __syncthreads();
+        lds_barrier();   // (LDS-only: the tile's global stores stay in flight)
         float* smn = reinterpret_cast<float*>(smem);
         float* smx = smn + NW;
         if (lane == 0) { smn[wave] = mn; smx[wave] = mx; }
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
 #pragma unroll
             for (int w = 1; w < NW; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); }
