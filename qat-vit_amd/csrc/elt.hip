@@ -88,81 +88,87 @@ __global__ __launch_bounds__(256) void k_img_patches(const float* __restrict__ i
 // MODE 1: x_new = x_prev + fq(Y)
 // then: mean/rstd of the x_new row and min/max of LN(x_new)*gamma+beta (the next aFQ's observer input).
 constexpr int kMaxV = 3;  // float4 per lane per row: D <= 768
-template <int MODE>
+__device__ inline void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// NV = column groups per lane (ceil(D / 256)).  All of a row's global loads are issued before anything is used, without branches
+// (a lane whose column is >= D loads column 0 and is masked out of the sums and stores): one `if (c < D)` region per column group made
+// the compiler serialise the groups, i.e. two or three dependent HBM round trips per row.  gamma / beta are loaded once per thread.
+template <int MODE, int NV>
 __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restrict__ x_prev, const float* __restrict__ Y, const float* __restrict__ qpY,
                                                           int qmin, int qmax, const float* __restrict__ cls, const float* __restrict__ pos,
                                                           float* __restrict__ x_new, float* __restrict__ mean, float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           uint32_t* __restrict__ stats, int stat_slots, int64_t M, int D, int T,
                                                           unsigned long long* __restrict__ maskbits) {
-    // maskbits (MODE 1, optional): the STE mask of fq(Y), one bit per element, as wave ballots - word [(row * nv + j) * 4 + e] holds in
+    // maskbits (MODE 1, optional): the STE mask of fq(Y), one bit per element, as wave ballots - word [(row * NV + j) * 4 + e] holds in
     // bit `lane` the mask of column lane * 4 + 256 j + e.  k_ln_bwd_fq (same lane -> column mapping) reads it back with scalar loads,
     // so the backward never touches the fp32 Y again.
     const QP q = load_qp(qpY);
     const int lane = threadIdx.x & 63;
-    const int nv = (D + 255) / 256;
+    bool act[NV];
+    int cc[NV];
+    float4 g[NV], bb[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        act[j] = c < D;
+        cc[j] = act[j] ? c : 0;
+        g[j] = *reinterpret_cast<const float4*>(gamma + cc[j]);
+        bb[j] = *reinterpret_cast<const float4*>(beta + cc[j]);
+    }
     float mn = INFINITY, mx = -INFINITY;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
-        float4 v[kMaxV];
-        bool inb[kMaxV][4];
-        float s = 0.f;
         const int t = (int)(row % T);
         const int64_t b = row / T;
+        const bool is_cls = MODE == 0 && t == 0;                  // wave-uniform: the class token is added as it is
+        const float* ysrc = MODE == 0 ? (is_cls ? cls : Y + (b * (T - 1) + (t - 1)) * D) : Y + row * D;
+        const float* bsrc = MODE == 0 ? pos + (int64_t)t * D : x_prev + row * D;
+        float4 yr[NV], base[NV], v[NV];
 #pragma unroll
-        for (int j = 0; j < kMaxV; ++j) {
-            const int c = lane * 4 + 256 * j;
-            inb[j][0] = inb[j][1] = inb[j][2] = inb[j][3] = false;
-            if (j < nv && c < D) {
-                float4 y = make_float4(0.f, 0.f, 0.f, 0.f), base;
-                bool in;
-                if (MODE == 0) {
-                    base = *reinterpret_cast<const float4*>(pos + (int64_t)t * D + c);
-                    if (t == 0) {
-                        y = *reinterpret_cast<const float4*>(cls + c);
-                    } else {
-                        const float4 r = *reinterpret_cast<const float4*>(Y + (b * (T - 1) + (t - 1)) * D + c);
-                        y = make_float4(fqv(r.x, q, qmin, qmax, in), fqv(r.y, q, qmin, qmax, in), fqv(r.z, q, qmin, qmax, in), fqv(r.w, q, qmin, qmax, in));
-                    }
-                } else {
-                    base = *reinterpret_cast<const float4*>(x_prev + row * D + c);
-                    const float4 r = *reinterpret_cast<const float4*>(Y + row * D + c);
-                    bool i0, i1, i2, i3;
-                    y = make_float4(fqv(r.x, q, qmin, qmax, i0), fqv(r.y, q, qmin, qmax, i1), fqv(r.z, q, qmin, qmax, i2), fqv(r.w, q, qmin, qmax, i3));
-                    inb[j][0] = i0; inb[j][1] = i1; inb[j][2] = i2; inb[j][3] = i3;   // (balloted and stored after the row's loads: see below)
-                }
-                v[j] = make_float4(base.x + y.x, base.y + y.y, base.z + y.z, base.w + y.w);
-                *reinterpret_cast<float4*>(x_new + row * D + c) = v[j];
-                s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-            } else {
-                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int j = 0; j < NV; ++j) {
+            base[j] = *reinterpret_cast<const float4*>(bsrc + cc[j]);
+            yr[j] = *reinterpret_cast<const float4*>(ysrc + cc[j]);
         }
+        // (pin the loaded values here: LLVM otherwise sinks each column group's loads down to its uses, one memory round trip per group)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { pin4(base[j]); pin4(yr[j]); }
+        float s = 0.f;
+        unsigned long long mb[NV][4];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            bool i0, i1, i2, i3;
+            float4 y = make_float4(fqv(yr[j].x, q, qmin, qmax, i0), fqv(yr[j].y, q, qmin, qmax, i1), fqv(yr[j].z, q, qmin, qmax, i2),
+                                   fqv(yr[j].w, q, qmin, qmax, i3));
+            if (is_cls) y = yr[j];
+            if (MODE == 1) {   // uniform control flow: the ballots stay in scalar registers
+                mb[j][0] = __ballot(act[j] && i0); mb[j][1] = __ballot(act[j] && i1);
+                mb[j][2] = __ballot(act[j] && i2); mb[j][3] = __ballot(act[j] && i3);
+            }
+            v[j] = make_float4(base[j].x + y.x, base[j].y + y.y, base[j].z + y.z, base[j].w + y.w);
+            if (act[j]) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        // (stores after every load of the row has been consumed: vmcnt is in issue order, a store between two loads' uses is waited for)
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (act[j]) *reinterpret_cast<float4*>(x_new + row * D + cc[j]) = v[j];
         const float mu = wave_sum(s) / (float)D;
         float qq = 0.f;
 #pragma unroll
-        for (int j = 0; j < kMaxV; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (j < nv && c < D) {
-                v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
-                qq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
-            }
+        for (int j = 0; j < NV; ++j) {
+            v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+            if (act[j]) qq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
         }
         const float rs = rsqrtf(wave_sum(qq) / (float)D + eps);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-        if (MODE == 1 && maskbits) {   // ballots in uniform control flow (lane masks stay in scalar registers); lane e stores word e
+        if (MODE == 1 && maskbits && lane < 4) {   // lane e stores word e of every column group
 #pragma unroll
-            for (int j = 0; j < kMaxV; ++j)
-                if (j < nv) {
-                    const unsigned long long b0 = __ballot(inb[j][0]), b1 = __ballot(inb[j][1]), b2 = __ballot(inb[j][2]), b3 = __ballot(inb[j][3]);
-                    if (lane < 4) maskbits[(row * nv + j) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-                }
+            for (int j = 0; j < NV; ++j)
+                maskbits[(row * NV + j) * 4 + lane] = lane == 0 ? mb[j][0] : lane == 1 ? mb[j][1] : lane == 2 ? mb[j][2] : mb[j][3];
         }
 #pragma unroll
-        for (int j = 0; j < kMaxV; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (j < nv && c < D) {
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c), bb = *reinterpret_cast<const float4*>(beta + c);
-                const float o0 = v[j].x * rs * g.x + bb.x, o1 = v[j].y * rs * g.y + bb.y, o2 = v[j].z * rs * g.z + bb.z, o3 = v[j].w * rs * g.w + bb.w;
+        for (int j = 0; j < NV; ++j) {
+            if (act[j]) {
+                const float o0 = v[j].x * rs * g[j].x + bb[j].x, o1 = v[j].y * rs * g[j].y + bb[j].y, o2 = v[j].z * rs * g[j].z + bb[j].z,
+                            o3 = v[j].w * rs * g[j].w + bb[j].w;
                 mn = fminf(fminf(mn, o0), fminf(o1, fminf(o2, o3)));
                 mx = fmaxf(fmaxf(mx, o0), fmaxf(o1, fmaxf(o2, o3)));
             }
@@ -297,10 +303,21 @@ __global__ __launch_bounds__(WPB * 64) void k_ln_bwd_fq(const float* __restrict_
     const QP q = load_qp(qp);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long mk[NV][4];   // this row's mask words (wave-uniform: scalar loads, requested at the top of the row)
+    bool act[NV];
+    int cc[NV];
+    float4 gm[NV], bt[NV], csn[NV];   // gamma, beta, the next branch's per-column scale: once per thread
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        act[j] = c < D;
+        cc[j] = act[j] ? c : 0;
+        gm[j] = *reinterpret_cast<const float4*>(gamma + cc[j]);
+        bt[j] = *reinterpret_cast<const float4*>(beta + cc[j]);
+        csn[j] = FUSE && ncs ? *reinterpret_cast<const float4*>(ncs + cc[j]) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
     auto fuse_store = [&](int64_t row, int j, int c, const float4& o) {
         const unsigned long long m0 = mk[j][0], m1 = mk[j][1], m2 = mk[j][2], m3 = mk[j][3];
-        float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (ncs) cs = *reinterpret_cast<const float4*>(ncs + c);
+        const float4 cs = csn[j];
         store_split4(nhi, nlo, row * D + c, (m0 >> lane) & 1 ? o.x * cs.x : 0.f, (m1 >> lane) & 1 ? o.y * cs.y : 0.f,
                      (m2 >> lane) & 1 ? o.z * cs.z : 0.f, (m3 >> lane) & 1 ? o.w * cs.w : 0.f);
     };
@@ -320,55 +337,61 @@ __global__ __launch_bounds__(WPB * 64) void k_ln_bwd_fq(const float* __restrict_
             // no gradient reaches this token through the (cls-pooled) head
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const int c = lane * 4 + 256 * j;
-                if (j < nv && c < D) {
-                    const float4 o = ACC ? *reinterpret_cast<const float4*>(dx_in + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(dx_out + row * D + c) = o;
-                    if (FUSE) fuse_store(row, j, c, o);
+                if (act[j]) {
+                    const float4 o = ACC ? *reinterpret_cast<const float4*>(dx_in + row * D + cc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(dx_out + row * D + cc[j]) = o;
+                    if (FUSE) fuse_store(row, j, cc[j], o);
                 }
             }
             continue;
         }
         const float mu = mean[row], rs = rstd[row];
         const int64_t drow = cls_only ? row / T : row;  // dH is [B, D] for the cls-only case
+        // every global load of the row first, branch-free (lanes past D read column 0 and are masked below), and pinned: see
+        // k_resid_fq_lnstats - one `if (c < D)` region per column group serialised the groups' memory round trips
+        float4 xv[NV], dvv[NV], pv[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            xv[j] = *reinterpret_cast<const float4*>(x + row * D + cc[j]);
+            dvv[j] = *reinterpret_cast<const float4*>(dH + drow * D + cc[j]);
+            if (ACC) pv[j] = *reinterpret_cast<const float4*>(dx_in + row * D + cc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            pin4(xv[j]);
+            pin4(dvv[j]);
+            if (ACC) pin4(pv[j]);
+        }
         float4 xh[NV], gy[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (j < nv && c < D) {
-                const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c);
-                float4 dv = *reinterpret_cast<const float4*>(dH + drow * D + c);
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
-                xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                bool i0, i1, i2, i3;
-                fqv(xh[j].x * g.x + b.x, q, qmin, qmax, i0);
-                fqv(xh[j].y * g.y + b.y, q, qmin, qmax, i1);
-                fqv(xh[j].z * g.z + b.z, q, qmin, qmax, i2);
-                fqv(xh[j].w * g.w + b.w, q, qmin, qmax, i3);
-                dv.x = i0 ? dv.x : 0.f; dv.y = i1 ? dv.y : 0.f; dv.z = i2 ? dv.z : 0.f; dv.w = i3 ? dv.w : 0.f;
-                gy[j] = make_float4(dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w);
+            const float4 g = gm[j], b = bt[j];
+            float4 dv = dvv[j];
+            xh[j] = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
+            bool i0, i1, i2, i3;
+            fqv(xh[j].x * g.x + b.x, q, qmin, qmax, i0);
+            fqv(xh[j].y * g.y + b.y, q, qmin, qmax, i1);
+            fqv(xh[j].z * g.z + b.z, q, qmin, qmax, i2);
+            fqv(xh[j].w * g.w + b.w, q, qmin, qmax, i3);
+            dv.x = i0 ? dv.x : 0.f; dv.y = i1 ? dv.y : 0.f; dv.z = i2 ? dv.z : 0.f; dv.w = i3 ? dv.w : 0.f;
+            gy[j] = make_float4(dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w);
+            if (act[j]) {
                 ag[j].x += dv.x * xh[j].x; ag[j].y += dv.y * xh[j].y; ag[j].z += dv.z * xh[j].z; ag[j].w += dv.w * xh[j].w;
                 ab[j].x += dv.x; ab[j].y += dv.y; ab[j].z += dv.z; ab[j].w += dv.w;
                 s1 += (gy[j].x + gy[j].y) + (gy[j].z + gy[j].w);
                 s2 += (gy[j].x * xh[j].x + gy[j].y * xh[j].y) + (gy[j].z * xh[j].z + gy[j].w * xh[j].w);
-            } else {
-                xh[j] = gy[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (j < nv && c < D) {
-                float4 o = make_float4((gy[j].x - m1 - xh[j].x * m2) * rs, (gy[j].y - m1 - xh[j].y * m2) * rs,
-                                       (gy[j].z - m1 - xh[j].z * m2) * rs, (gy[j].w - m1 - xh[j].w * m2) * rs);
-                if (ACC) {
-                    const float4 p = *reinterpret_cast<const float4*>(dx_in + row * D + c);
-                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-                }
-                *reinterpret_cast<float4*>(dx_out + row * D + c) = o;
-                if (FUSE) fuse_store(row, j, c, o);
+            float4 o = make_float4((gy[j].x - m1 - xh[j].x * m2) * rs, (gy[j].y - m1 - xh[j].y * m2) * rs,
+                                   (gy[j].z - m1 - xh[j].z * m2) * rs, (gy[j].w - m1 - xh[j].w * m2) * rs);
+            if (ACC) { o.x += pv[j].x; o.y += pv[j].y; o.z += pv[j].z; o.w += pv[j].w; }
+            if (act[j]) {
+                *reinterpret_cast<float4*>(dx_out + row * D + cc[j]) = o;
+                if (FUSE) fuse_store(row, j, cc[j], o);
             }
         }
     }
@@ -587,11 +610,12 @@ int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const
                             float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
                             int64_t M, int D, int T, hipStream_t st, void* maskbits) {
     if (D % 4 != 0 || D > 256 * kMaxV) { set_error("resid_fq_lnstats: D=%d unsupported (need D%%4==0, D<=768)", D); return 1; }
-    if (mode == 0)
-        k_resid_fq_lnstats<0><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T, nullptr);
-    else
-        k_resid_fq_lnstats<1><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T,
-                                                            reinterpret_cast<unsigned long long*>(maskbits));
+    unsigned long long* mbits = mode == 0 ? nullptr : reinterpret_cast<unsigned long long*>(maskbits);
+#define QV_RESID(MODE_, NV_) k_resid_fq_lnstats<MODE_, NV_><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T, mbits)
+    const int nv = (D + 255) / 256;
+    if (mode == 0) { if (nv == 1) QV_RESID(0, 1); else if (nv == 2) QV_RESID(0, 2); else QV_RESID(0, 3); }
+    else { if (nv == 1) QV_RESID(1, 1); else if (nv == 2) QV_RESID(1, 2); else QV_RESID(1, 3); }
+#undef QV_RESID
     return 0;
 }
 
