@@ -176,6 +176,9 @@ __device__ inline bf16x8 quant8(const float4& a, const float4& b, const AQP& q) 
     f[4] = (__bf16)qint(b.x, q); f[5] = (__bf16)qint(b.y, q); f[6] = (__bf16)qint(b.z, q); f[7] = (__bf16)qint(b.w, q);
     return f;
 }
+// (pins: an empty asm that "uses" the loaded values right after the load loop - left alone, LLVM sinks half of the loads below the first
+//  half's conversions, two memory round trips per image instead of one)
+__device__ inline void pin4(const float4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
 template <int HD, bool TR, int NKT, int NWV = kAW>
 __device__ inline void stage_tokens(char* img, const float* base, int T, int ld, const AQP& q) {
     constexpr int CH = HD / 8;  // 16-B chunks per token row
@@ -184,13 +187,13 @@ __device__ inline void stage_tokens(char* img, const float* base, int T, int ld,
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
-        if (i < TOTAL && tok < T) {
-            const float4* p = reinterpret_cast<const float4*>(base + (int64_t)tok * ld + ch * 8);
-            a[it] = p[0]; b[it] = p[1];
-        } else {
-            a[it] = b[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        // branch-free (a padded token reads the last real one and is zeroed at conversion): a conditional load has to be merged with
+        // its zero alternative right away, i.e. waited for inside this loop
+        const float4* p = reinterpret_cast<const float4*>(base + (int64_t)min(tok, T - 1) * ld + ch * 8);
+        a[it] = p[0]; b[it] = p[1];
     }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) { pin4(a[it]); pin4(b[it]); }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
@@ -212,13 +215,13 @@ __device__ inline void stage_split_tr(char* img_hi, char* img_lo, const float* b
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
-        if (i < TOTAL && tok < T) {
-            const float4* p = reinterpret_cast<const float4*>(base + (int64_t)tok * ld + ch * 8);
-            a[it] = p[0]; b[it] = p[1];
-        } else {
-            a[it] = b[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        // branch-free (a padded token reads the last real one and is zeroed at conversion): a conditional load has to be merged with
+        // its zero alternative right away, i.e. waited for inside this loop
+        const float4* p = reinterpret_cast<const float4*>(base + (int64_t)min(tok, T - 1) * ld + ch * 8);
+        a[it] = p[0]; b[it] = p[1];
     }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) { pin4(a[it]); pin4(b[it]); }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
@@ -227,8 +230,8 @@ __device__ inline void stage_split_tr(char* img_hi, char* img_lo, const float* b
             bf16x8 hi, lo;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                hi[j] = (__bf16)v[j];
-                lo[j] = (__bf16)(v[j] - (float)hi[j]);
+                hi[j] = (__bf16)(tok < T ? v[j] : 0.f);
+                lo[j] = (__bf16)(tok < T ? v[j] - (float)hi[j] : 0.f);
             }
             *reinterpret_cast<bf16x8*>(img_hi + tr_off<HD>(tok, ch)) = hi;
             *reinterpret_cast<bf16x8*>(img_lo + tr_off<HD>(tok, ch)) = lo;

@@ -49,58 +49,70 @@ __global__ __launch_bounds__(256) void k_patches_split(const float* __restrict__
 // MODE 0: x[b,0,:] = cls + pos[0]; x[b,1+p,:] = Y[b*np+p,:] + pos[1+p,:]     MODE 1: x = x_prev + Y
 // then h = LayerNorm(x) written as a (hi, lo) pair (one wave per row, row kept in registers: single pass over HBM)
 constexpr int kTV = 3;  // float4 per lane per row: D <= 768
-template <int MODE>
+__device__ inline void t_pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// NV = ceil(D / 256) column groups per lane.  All loads of the row are issued first, branch-free and pinned (a lane past D reads column 0
+// and is masked out): one `if (c < D)` region per group let LLVM sink each group's loads to its uses - three dependent HBM round trips
+// per row at D = 768.  gamma / beta once per thread.
+template <int MODE, int NV>
 __global__ __launch_bounds__(256) void k_resid_ln_split(const float* __restrict__ x_prev, const float* __restrict__ Y, const float* __restrict__ cls,
                                                         const float* __restrict__ pos, float* __restrict__ x_new, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, __bf16* __restrict__ h_hi,
                                                         __bf16* __restrict__ h_lo, int64_t M, int D, int T) {
     const int lane = threadIdx.x & 63;
-    const int nv = (D + 255) / 256;
+    bool act[NV];
+    int cc[NV];
+    float4 g[NV], bb[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        act[j] = c < D;
+        cc[j] = act[j] ? c : 0;
+        g[j] = *reinterpret_cast<const float4*>(gamma + cc[j]);
+        bb[j] = *reinterpret_cast<const float4*>(beta + cc[j]);
+    }
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
-        float4 v[kTV];
-        float s = 0.f;
         const int t = (int)(row % T);
         const int64_t b = row / T;
+        const float* ysrc = MODE == 0 ? (t == 0 ? cls : Y + (b * (T - 1) + (t - 1)) * D) : Y + row * D;   // (wave-uniform select)
+        const float* bsrc = MODE == 0 ? pos + (int64_t)t * D : x_prev + row * D;
+        float4 v[NV], y[NV];
 #pragma unroll
-        for (int j = 0; j < kTV; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (j < nv && c < D) {
-                float4 y, base;
-                if (MODE == 0) {
-                    base = *reinterpret_cast<const float4*>(pos + (int64_t)t * D + c);
-                    y = t == 0 ? *reinterpret_cast<const float4*>(cls + c) : *reinterpret_cast<const float4*>(Y + (b * (T - 1) + (t - 1)) * D + c);
-                } else {
-                    base = *reinterpret_cast<const float4*>(x_prev + row * D + c);
-                    y = *reinterpret_cast<const float4*>(Y + row * D + c);
-                }
-                v[j] = make_float4(base.x + y.x, base.y + y.y, base.z + y.z, base.w + y.w);
-                *reinterpret_cast<float4*>(x_new + row * D + c) = v[j];
-                s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-            } else {
-                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int j = 0; j < NV; ++j) {
+            v[j] = *reinterpret_cast<const float4*>(bsrc + cc[j]);
+            y[j] = *reinterpret_cast<const float4*>(ysrc + cc[j]);
         }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { t_pin4(v[j]); t_pin4(y[j]); }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = make_float4(v[j].x + y[j].x, v[j].y + y[j].y, v[j].z + y[j].z, v[j].w + y[j].w);
+            if (act[j]) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (act[j]) *reinterpret_cast<float4*>(x_new + row * D + cc[j]) = v[j];
         const float mu = wave_sum(s) / (float)D;
         float qq = 0.f;
 #pragma unroll
-        for (int j = 0; j < kTV; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (j < nv && c < D) {
-                v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
-                qq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
-            }
+        for (int j = 0; j < NV; ++j) {
+            v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+            if (act[j]) qq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
         }
         const float rs = rsqrtf(wave_sum(qq) / (float)D + eps);
 #pragma unroll
-        for (int j = 0; j < kTV; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (j < nv && c < D) {
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c), bb = *reinterpret_cast<const float4*>(beta + c);
-                st_split4(h_hi, h_lo, row * D + c, v[j].x * rs * g.x + bb.x, v[j].y * rs * g.y + bb.y, v[j].z * rs * g.z + bb.z,
-                          v[j].w * rs * g.w + bb.w);
-            }
-        }
+        for (int j = 0; j < NV; ++j)
+            if (act[j])
+                st_split4(h_hi, h_lo, row * D + cc[j], v[j].x * rs * g[j].x + bb[j].x, v[j].y * rs * g[j].y + bb[j].y, v[j].z * rs * g[j].z + bb[j].z,
+                          v[j].w * rs * g[j].w + bb[j].w);
     }
+}
+template <int MODE, typename... A>
+static void launch_resid_ln_split(int grid, hipStream_t st, int D, A... a) {
+    const int nv = (D + 255) / 256;
+    if (nv == 1) k_resid_ln_split<MODE, 1><<<grid, 256, 0, st>>>(a...);
+    else if (nv == 2) k_resid_ln_split<MODE, 2><<<grid, 256, 0, st>>>(a...);
+    else k_resid_ln_split<MODE, 3><<<grid, 256, 0, st>>>(a...);
 }
 
 __device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -396,14 +408,14 @@ int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* con
     if (gemm(V(p.p_hi), V(p.p_lo), 0, prm(1), F(p.Y0), c.batch * np, D, Kpe)) return 1;
     float* x = F(p.xA);
     float* x2 = F(p.xB);
-    k_resid_ln_split<0><<<rows_grid_t(M), 256, 0, st>>>(nullptr, F(p.Y0), prm(2), prm(3), x, bprm(0, 0), bprm(0, 1), c.ln_eps, H16(p.h_hi),
+    launch_resid_ln_split<0>(rows_grid_t(M), st, D, (const float*)nullptr, F(p.Y0), prm(2), prm(3), x, bprm(0, 0), bprm(0, 1), c.ln_eps, H16(p.h_hi),
                                                         H16(p.h_lo), M, D, T);
     for (int i = 0; i < c.depth; ++i) {
         const int w0 = 1 + 4 * i;
         if (gemm(V(p.h_hi), V(p.h_lo), w0 + 0, bprm(i, 3), F(p.qkv), (int)M, 3 * D, D)) return 1;
         if (launch_attn_fwd_float(F(p.qkv), c.batch, T, c.num_heads, D, V(p.O_hi), V(p.O_lo), st)) return 1;
         if (gemm(V(p.O_hi), V(p.O_lo), w0 + 1, bprm(i, 5), F(p.Y), (int)M, D, D)) return 1;
-        k_resid_ln_split<1><<<rows_grid_t(M), 256, 0, st>>>(x, F(p.Y), nullptr, nullptr, x2, bprm(i, 6), bprm(i, 7), c.ln_eps, H16(p.h_hi),
+        launch_resid_ln_split<1>(rows_grid_t(M), st, D, (const float*)x, (const float*)F(p.Y), (const float*)nullptr, (const float*)nullptr, x2, bprm(i, 6), bprm(i, 7), c.ln_eps, H16(p.h_hi),
                                                             H16(p.h_lo), M, D, T);
         {   // fc1 with GELU + hi/lo split in the GEMM epilogue (the fp32 [M, Hd] tensor never exists)
             NTPost post{nullptr, nullptr, 0, 0, nullptr, V(p.G_hi), V(p.G_lo)};
@@ -416,7 +428,7 @@ int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* con
         // the next block's norm1 (for the last block the pair is unused: the head normalises the cls rows itself)
         const float* g = last ? prm(4 + 12 * c.depth) : bprm(i + 1, 0);
         const float* bt = last ? prm(4 + 12 * c.depth + 1) : bprm(i + 1, 1);
-        k_resid_ln_split<1><<<rows_grid_t(M), 256, 0, st>>>(x2, F(p.Y), nullptr, nullptr, x, g, bt, c.ln_eps, H16(p.h_hi), H16(p.h_lo), M, D, T);
+        launch_resid_ln_split<1>(rows_grid_t(M), st, D, (const float*)x2, (const float*)F(p.Y), (const float*)nullptr, (const float*)nullptr, x, g, bt, c.ln_eps, H16(p.h_hi), H16(p.h_lo), M, D, T);
     }
     const int base = 4 + 12 * c.depth;
     k_teacher_head<<<c.batch, 256, (D + 8) * sizeof(float), st>>>(x, prm(base), prm(base + 1), c.ln_eps, prm(base + 2), prm(base + 3), logits, D, T,
