@@ -398,6 +398,25 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
                 dq[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl, kt, dq[jd], 0, 0, 0);
             }
         }
+        // the pre-FQ q values of both half tiles (STE mask) and the per-column scales are requested together, before either half is
+        // stored: loads and stores share one in-order counter, so a load issued after a store is also a wait for that store, and a
+        // conditional load inside the loop costs a vmcnt(0) at its merge point whether it is taken or not
+        const int erow = lane / (HD / 8), ec8 = lane % (HD / 8);   // (the row / 8-column group wave_retile8 hands this lane)
+        float4 xq[2][2], csq[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int qq = min(qt * 16 + 8 * half + (erow & 7), T - 1);
+            const float* px = p.qkv + ((int64_t)b * T + qq) * ld + h * HD + 8 * ec8;
+            xq[half][0] = *reinterpret_cast<const float4*>(px);
+            xq[half][1] = *reinterpret_cast<const float4*>(px + 4);
+        }
+        csq[0] = csq[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.col_scale) {
+            csq[0] = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 8 * ec8);
+            csq[1] = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 8 * ec8 + 4);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) { pin4(xq[half][0]); pin4(xq[half][1]); }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             float gv[8];
@@ -408,13 +427,11 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
                 const int64_t off = ((int64_t)b * T + qq) * ld + h * HD + 8 * oc;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {  // STE mask of the qkv fake-quant (+ optional per-channel weight scale), 8 contiguous features
-                    const float4 xq = *reinterpret_cast<const float4*>(p.qkv + off + 4 * k);
-                    float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (p.col_scale) cs = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 8 * oc + 4 * k);
-                    gv[4 * k] = qin(xq.x, q) ? gv[4 * k] * cs.x : 0.f;
-                    gv[4 * k + 1] = qin(xq.y, q) ? gv[4 * k + 1] * cs.y : 0.f;
-                    gv[4 * k + 2] = qin(xq.z, q) ? gv[4 * k + 2] * cs.z : 0.f;
-                    gv[4 * k + 3] = qin(xq.w, q) ? gv[4 * k + 3] * cs.w : 0.f;
+                    const float4 x4 = xq[half][k], cs = csq[k];
+                    gv[4 * k] = qin(x4.x, q) ? gv[4 * k] * cs.x : 0.f;
+                    gv[4 * k + 1] = qin(x4.y, q) ? gv[4 * k + 1] * cs.y : 0.f;
+                    gv[4 * k + 2] = qin(x4.z, q) ? gv[4 * k + 2] * cs.z : 0.f;
+                    gv[4 * k + 3] = qin(x4.w, q) ? gv[4 * k + 3] * cs.w : 0.f;
                 }
                 store_split8(p.dqkv_hi, p.dqkv_lo, off, gv);
             }
@@ -443,11 +460,13 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     // per-row softmax constants into LDS once: read from global inside the sweep they are a load-use chain per query-tile pair
     float* sLse = reinterpret_cast<float*>(smem + 3 * IMG);
     float* sDlt = sLse + NKT * 16;
-    for (int i = threadIdx.x; i < NKT * 16; i += NWV * 64) {
-        sLse[i] = p.lse[(int64_t)blockIdx.x * (NKT * 16) + min(i, p.T - 1)];
-        sDlt[i] = p.delta[(int64_t)blockIdx.x * (NKT * 16) + min(i, p.T - 1)];
-    }
+    static_assert(NKT * 16 <= NWV * 64, "one softmax constant per thread");
+    // (requested first, written to LDS after the first image: a load -> ds_write right here would be a round trip of its own)
+    const int ci = min((int)threadIdx.x, NKT * 16 - 1);
+    const float lse_i = p.lse[(int64_t)blockIdx.x * (NKT * 16) + min(ci, p.T - 1)];
+    const float dlt_i = p.delta[(int64_t)blockIdx.x * (NKT * 16) + min(ci, p.T - 1)];
     stage_tokens<HD, true, NKT, NWV>(sQt, base, T, ld, q);
+    if (threadIdx.x < NKT * 16) { sLse[threadIdx.x] = lse_i; sDlt[threadIdx.x] = dlt_i; }
     stage_split_tr<HD, NKT, NWV>(sDh, sDl, dObase, T, D);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -462,18 +481,37 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     bf16x8 kf[U][KK], vf[U][KK];
     bool kvalid[U];
     f32x4 dk[U][ND], dv[U][ND];
+    {   // the owned K / V row fragments: every raw load first, pinned (left alone they come in dribs as registers free up, five or six
+        // dependent round trips before the sweep can start)
+        float4 kr[U][KK][2], vr[U][KK][2];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int krow = min(16 * jt[u] + r, T - 1);
-        kvalid[u] = has[u] && 16 * jt[u] + r < T;
+        for (int u = 0; u < U; ++u) {
+            const int krow = min(16 * jt[u] + r, T - 1);
+            kvalid[u] = has[u] && 16 * jt[u] + r < T;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            kf[u][kk] = load_q8(base + D + (int64_t)krow * ld + 32 * kk + 8 * g, q);
-            vf[u][kk] = load_q8(base + 2 * D + (int64_t)krow * ld + 32 * kk + 8 * g, q);
+            for (int kk = 0; kk < KK; ++kk) {
+                const float4* pk = reinterpret_cast<const float4*>(base + D + (int64_t)krow * ld + 32 * kk + 8 * g);
+                const float4* pv = reinterpret_cast<const float4*>(base + 2 * D + (int64_t)krow * ld + 32 * kk + 8 * g);
+                kr[u][kk][0] = pk[0]; kr[u][kk][1] = pk[1];
+                vr[u][kk][0] = pv[0]; vr[u][kk][1] = pv[1];
+            }
         }
 #pragma unroll
-        for (int id = 0; id < ND; ++id) dk[u][id] = dv[u][id] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) { pin4(kr[u][kk][0]); pin4(kr[u][kk][1]); pin4(vr[u][kk][0]); pin4(vr[u][kk][1]); }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                kf[u][kk] = quant8(kr[u][kk][0], kr[u][kk][1], q);
+                vf[u][kk] = quant8(vr[u][kk][0], vr[u][kk][1], q);
+            }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int id = 0; id < ND; ++id) dk[u][id] = dv[u][id] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int qs = 0; qs < NKT / 2; ++qs) {
         // this pair's query-row fragments (A operands of S and dP), and per-row softmax constants
@@ -544,17 +582,29 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     const float a = q.s * p.softmax_scale;
     // the STE mask needs the pre-FQ k / v values: all of them are requested before any is used (one memory round trip for the
     // epilogue instead of one per fragment; the sweep's operand registers are dead here)
-    float4 xk[U][ND], xv[U][ND];
+    float4 xk[U][ND], xv[U][ND], ckc[ND], cvc[ND];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int id = 0; id < ND; ++id) {
-            if (kvalid[u]) {
-                const int64_t offk = ((int64_t)b * T + 16 * jt[u] + r) * ld + D + h * HD + 16 * id + 4 * g;
-                xk[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk);
-                xv[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk + D);
-            }
+            const int64_t offk = ((int64_t)b * T + min(16 * jt[u] + r, T - 1)) * ld + D + h * HD + 16 * id + 4 * g;   // (branch-free; invalid keys are skipped below)
+            xk[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk);
+            xv[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk + D);
         }
+    // the per-column scales here too: an `if (col_scale)` load inside the store loop costs a vmcnt(0) at its merge point in every
+    // iteration, taken or not - i.e. a wait for the previous iteration's stores
+#pragma unroll
+    for (int id = 0; id < ND; ++id) {
+        ckc[id] = cvc[id] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.col_scale) {
+            ckc[id] = *reinterpret_cast<const float4*>(p.col_scale + D + h * HD + 16 * id + 4 * g);
+            cvc[id] = *reinterpret_cast<const float4*>(p.col_scale + 2 * D + h * HD + 16 * id + 4 * g);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int id = 0; id < ND; ++id) { pin4(xk[u][id]); pin4(xv[u][id]); }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (!kvalid[u]) continue;
@@ -563,11 +613,7 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
             const int64_t offk = ((int64_t)b * T + 16 * jt[u] + r) * ld + D + h * HD + 16 * id + 4 * g;
             const int64_t offv = offk + D;
             const float4 k4 = xk[u][id], v4 = xv[u][id];
-            float4 ck = make_float4(1.f, 1.f, 1.f, 1.f), cv = ck;
-            if (p.col_scale) {
-                ck = *reinterpret_cast<const float4*>(p.col_scale + D + h * HD + 16 * id + 4 * g);
-                cv = *reinterpret_cast<const float4*>(p.col_scale + 2 * D + h * HD + 16 * id + 4 * g);
-            }
+            const float4 ck = ckc[id], cv = cvc[id];
             const float vk[4] = {qin(k4.x, q) ? dk[u][id][0] * a * ck.x : 0.f, qin(k4.y, q) ? dk[u][id][1] * a * ck.y : 0.f,
                                  qin(k4.z, q) ? dk[u][id][2] * a * ck.z : 0.f, qin(k4.w, q) ? dk[u][id][3] * a * ck.w : 0.f};
             const float vv[4] = {qin(v4.x, q) ? dv[u][id][0] * cv.x : 0.f, qin(v4.y, q) ? dv[u][id][1] * cv.y : 0.f,

@@ -215,20 +215,39 @@ __global__ __launch_bounds__(kTW * 64) void k_attn_fwd_float(const float* __rest
     float* sO = reinterpret_cast<float*>(smem + 4 * IMG) + (threadIdx.x >> 6) * (8 * (HD + 4));   // per-wave output re-tiling scratch
     const int b = blockIdx.x / H, h = blockIdx.x % H, ld = 3 * D;
     const float* base = qkv + (int64_t)b * T * ld + h * HD;
-    for (int i = threadIdx.x; i < NKT * 16 * CH; i += kTW * 64) {
-        const int tok = i / CH, ch = i % CH;
-        bf16x8 kh, kl, vh, vl;
-        if (tok < T) {
-            t_load_split8(base + D + (int64_t)tok * ld + ch * 8, kh, kl);
-            t_load_split8(base + 2 * D + (int64_t)tok * ld + ch * 8, vh, vl);
-        } else {
+    {   // staging: every load of the K and V slices first (branch-free: a padded token reads the last real one and is zeroed below),
+        // pinned, then the splits and LDS stores - the rolled load -> split -> store loop was four dependent memory round trips
+        constexpr int TOTAL = NKT * 16 * CH, ITERS = (TOTAL + kTW * 64 - 1) / (kTW * 64);
+        float4 ka[ITERS], kb[ITERS], va[ITERS], vb[ITERS];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kh[j] = kl[j] = vh[j] = vl[j] = (__bf16)0.f;
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = threadIdx.x + it * kTW * 64, tok = min(i / CH, T - 1), ch = i % CH;
+            const float4* pk = reinterpret_cast<const float4*>(base + D + (int64_t)tok * ld + ch * 8);
+            const float4* pv = reinterpret_cast<const float4*>(base + 2 * D + (int64_t)tok * ld + ch * 8);
+            ka[it] = pk[0]; kb[it] = pk[1]; va[it] = pv[0]; vb[it] = pv[1];
         }
-        *reinterpret_cast<bf16x8*>(sKh + t_row_off<HD>(tok, ch)) = kh;
-        *reinterpret_cast<bf16x8*>(sKl + t_row_off<HD>(tok, ch)) = kl;
-        *reinterpret_cast<bf16x8*>(sVh + t_tr_off<HD>(tok, ch)) = vh;
-        *reinterpret_cast<bf16x8*>(sVl + t_tr_off<HD>(tok, ch)) = vl;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) { t_pin4(ka[it]); t_pin4(kb[it]); t_pin4(va[it]); t_pin4(vb[it]); }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = threadIdx.x + it * kTW * 64, tok = i / CH, ch = i % CH;
+            if (i < TOTAL) {
+                const bool real = tok < T;
+                const float kv[8] = {ka[it].x, ka[it].y, ka[it].z, ka[it].w, kb[it].x, kb[it].y, kb[it].z, kb[it].w};
+                const float vv[8] = {va[it].x, va[it].y, va[it].z, va[it].w, vb[it].x, vb[it].y, vb[it].z, vb[it].w};
+                bf16x8 kh, kl, vh, vl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float k1 = real ? kv[j] : 0.f, v1 = real ? vv[j] : 0.f;
+                    kh[j] = (__bf16)k1; kl[j] = (__bf16)(k1 - (float)kh[j]);
+                    vh[j] = (__bf16)v1; vl[j] = (__bf16)(v1 - (float)vh[j]);
+                }
+                *reinterpret_cast<bf16x8*>(sKh + t_row_off<HD>(tok, ch)) = kh;
+                *reinterpret_cast<bf16x8*>(sKl + t_row_off<HD>(tok, ch)) = kl;
+                *reinterpret_cast<bf16x8*>(sVh + t_tr_off<HD>(tok, ch)) = vh;
+                *reinterpret_cast<bf16x8*>(sVl + t_tr_off<HD>(tok, ch)) = vl;
+            }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
