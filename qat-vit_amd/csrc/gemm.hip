@@ -110,6 +110,12 @@ struct NTArgs {
     __bf16* out_lo;
 };
 
+constexpr int kStandIn = 512;
+struct OnesTab { float v[kStandIn]; constexpr OnesTab() : v() { for (int i = 0; i < kStandIn; ++i) v[i] = 1.f; } };
+struct ZerosTab { float v[kStandIn]; constexpr ZerosTab() : v() {} };
+__device__ const OnesTab kOnes{};
+__device__ const ZerosTab kZeros{};
+
 // ---- shared epilogue of the NT kernels.  WM x WN waves, wave (wm, wn) holds a (16*TM) x (16*TNT) sub-tile in acc[][].
 // PM: the epilogue variant compiled into this instantiation (one per kernel: a monolithic epilogue with every mode selected at run time
 // needs 100 more registers than the accumulators leave and spills them)
@@ -121,9 +127,12 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     // The accumulator layout (16 consecutive columns per 16 lanes, rows on registers) would give 64-B store
     // segments; stage 64-row halves of the tile through LDS instead and store whole 16-B-per-lane row runs
     // (512 contiguous bytes per row).
-    float alpha = 1.f;
-    if (p.s1) alpha *= *p.s1;
-    if (p.s2) alpha *= *p.s2;
+    // optional operands are read through stand-in tables of ones / zeros instead of `ptr ? *ptr : default`: a conditional load has to be
+    // merged with its default at once, so every one of them was a memory round trip of its own (six to nine in a row per tile)
+    static_assert(BN <= kStandIn, "stand-in tables too small");
+    const float alpha = *(p.s1 ? p.s1 : kOnes.v) * *(p.s2 ? p.s2 : kOnes.v);
+    const float* csp = p.col_scale ? p.col_scale + n0 : kOnes.v;
+    const float* bsp = p.bias ? p.bias + n0 : kZeros.v;
     float mn = INFINITY, mx = -INFINITY;
     constexpr int LDC = BN + 4;                 // fp32 words per staged row (pad: conflict-free b32 writes)
     float* sC = reinterpret_cast<float*>(smem); // [SLAB][LDC]
@@ -172,8 +181,8 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
 #pragma unroll
     for (int j = 0; j < TNT; ++j) {
         const int cl = wn * WC + 16 * j + r;
-        ca[j] = p.col_scale ? alpha * p.col_scale[n0 + cl] : alpha;
-        cb[j] = p.bias ? p.bias[n0 + cl] : 0.f;
+        ca[j] = alpha * csp[cl];
+        cb[j] = bsp[cl];
     }
     // int8 operands: the accumulators are exact int32 sums of (q - center) * w; adding (center - zp) * sum_k w restores sum (q - zp) * w,
     // the integer the bf16 path accumulates (also exactly, it stays below 2^24) - so both paths store the same bits
