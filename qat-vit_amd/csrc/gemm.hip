@@ -1061,6 +1061,30 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, i
     const int wave = rem / per_wave, f = (rem % per_wave) / 64, lane = rem & 63;
     const int i = f / TNT, j = f % TNT, r = lane & 15, g = lane >> 4, wm = wave / WNK, wn = wave % WNK;
     const float4* src = reinterpret_cast<const float4*>(p.partial) + idx;
+    // the tail's operands (weights for the STE mask, their scale / zero point, the dW values to accumulate into) are requested up front,
+    // branch-free, together with the first partial tile: as `if (p.W)` loads inside the element loop they were eight dependent round
+    // trips after the sum
+    const int BKW = WNK * TNT * 16, tilesK = p.Kw / BKW;
+    const int n0 = (tile / tilesK) * 128, k0 = (tile % tilesK) * BKW;
+    const int kw = k0 + wn * (16 * TNT) + 16 * j + r;
+    const int nbase = n0 + wm * (16 * TM) + 16 * i + 4 * g;
+    float wv[4], cv[4], wsc[4], rdv[4];
+    int wzp[4];
+    const float* Wp = p.W ? p.W : p.C;                                    // stand-ins instead of conditional loads
+    const float* wsp = p.W ? p.w_scale : kOnes.v;
+    const int32_t* wzpp = p.W ? p.w_zp : reinterpret_cast<const int32_t*>(kZeros.v);
+    const float* rdp = p.row_div ? p.row_div : kOnes.v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = min(nbase + e, p.N - 1);
+        const int ci = (p.W && p.w_per_channel) ? n : 0;
+        cv[e] = p.C[(int64_t)n * p.ldc + kw];
+        wv[e] = Wp[(int64_t)n * p.ldc + kw];
+        wsc[e] = wsp[ci];
+        wzp[e] = wzpp[ci];
+        rdv[e] = rdp[p.row_div ? n : 0];
+    }
+    const float alpha = p.s1 ? *p.s1 : 1.f;
     // four splits' loads in flight per thread; the additions stay in split order (bit-reproducible)
     const int64_t sstride = (int64_t)p.tiles * per_tile;
     float4 a = src[0];
@@ -1077,24 +1101,21 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, i
         const float4 b = src[(int64_t)s * sstride];
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    const int BKW = WNK * TNT * 16, tilesK = p.Kw / BKW;
-    const int n0 = (tile / tilesK) * 128, k0 = (tile % tilesK) * BKW;
-    const int kw = k0 + wn * (16 * TNT) + 16 * j + r;
-    const float alpha = p.s1 ? *p.s1 : 1.f;
     const float av[4] = {a.x, a.y, a.z, a.w};
+    // (values first, branch-free; the guarded blocks below hold nothing but a store - a block that uses a loaded value gets a
+    //  conservative vmcnt(0) at its entry, which after the first store is a wait for that store)
+    float outv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int n = n0 + wm * (16 * TM) + 16 * i + 4 * g + e;
-        if (n >= p.N) continue;
-        const float rdiv = p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f;
-        float v = av[e] * (alpha * rdiv);
-        if (p.W) {
-            const int ci = p.w_per_channel ? n : 0;
-            const float q = rintf(p.W[(int64_t)n * p.ldc + kw] * __fdiv_rn(1.0f, p.w_scale[ci])) + (float)p.w_zp[ci];
-            if (!(q >= (float)p.w_qmin && q <= (float)p.w_qmax)) v = 0.f;
-        }
-        p.C[(int64_t)n * p.ldc + kw] += v;
+        const float rdiv = __fdiv_rn(1.0f, rdv[e]);                       // (stand-in 1.0 without row_div: exactly 1)
+        const float v = av[e] * (alpha * rdiv);
+        const float q = rintf(wv[e] * __fdiv_rn(1.0f, wsc[e])) + (float)wzp[e];
+        const bool clipped = p.W != nullptr && !(q >= (float)p.w_qmin && q <= (float)p.w_qmax);
+        outv[e] = cv[e] + (clipped ? 0.f : v);
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (nbase + e < p.N) p.C[(int64_t)(nbase + e) * p.ldc + kw] = outv[e];
 }
 
 int tn_async_init(TnAsync* a) {
