@@ -160,6 +160,14 @@ __device__ inline void qparams_body(uint32_t* ws, float* running_min, float* run
     // round of loads instead of a dependent chain - this kernel sits on the critical path between a producer and its consumer).
     // Per-channel: one thread per channel, a single pair each.
     const int64_t i = nslots > 1 ? 0 : blk * (int64_t)blockDim.x + threadIdx.x;
+    // every input is requested here, in one batch with the accumulator pairs (all lanes, clamped index): read where they are used -
+    // behind the early return and inside the observer / fake-quant branches - they were four more dependent round trips, and this
+    // kernel runs 135 times per step between a producer and its consumer
+    const int64_t il = i < channels ? i : channels - 1;
+    float mn = running_min[il], mx = running_max[il];
+    float s = scale[il];
+    int32_t z = zero_point[il];
+    const bool obs_on = *observer_on != 0, fq_on = *fake_quant_on != 0;
     uint32_t omn, omx;
     if (nslots > 1) {
         const int l = threadIdx.x;
@@ -184,18 +192,15 @@ __device__ inline void qparams_body(uint32_t* ws, float* running_min, float* run
             ws[2 * i + 1] = kOrdNegInf;
         }
     }
-    float mn = running_min[i], mx = running_max[i];
-    if (*observer_on != 0) {
+    if (obs_on) {
         mn = ema(mn, ord2f(omn), c);
         mx = ema(mx, ord2f(omx), c);
         running_min[i] = mn;
         running_max[i] = mx;
     }
-    float s = scale[i];
-    int32_t z = zero_point[i];
     // (the reference raises when fake-quant runs with an unobserved min > max; a device
     //  kernel cannot raise, so the previous scale/zero_point are kept in that case)
-    if (*fake_quant_on != 0 && mn <= mx) {
+    if (fq_on && mn <= mx) {
         choose_qparams(mn, mx, qmin, qmax, symmetric != 0, &s, &z);
         scale[i] = s;
         zero_point[i] = z;
@@ -204,7 +209,7 @@ __device__ inline void qparams_body(uint32_t* ws, float* running_min, float* run
         qp_out[4 * i + 0] = s;
         qp_out[4 * i + 1] = __fdiv_rn(1.0f, s);
         qp_out[4 * i + 2] = (float)z;
-        qp_out[4 * i + 3] = (*fake_quant_on != 0) ? 1.f : 0.f;
+        qp_out[4 * i + 3] = fq_on ? 1.f : 0.f;
     }
 }
 __global__ void k_qparams(uint32_t* ws, float* running_min, float* running_max, float* scale, int32_t* zero_point,
