@@ -407,7 +407,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     bf16x4 oh, ol;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float o = gelu_fwd(cv[e]);
+                        const float o = gelu_fwd_fast(cv[e]);
                         oh[e] = (__bf16)o;
                         ol[e] = (__bf16)(o - (float)oh[e]);
                     }

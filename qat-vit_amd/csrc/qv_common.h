@@ -84,6 +84,19 @@ __device__ inline float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.
 
 // exact-erf GELU (nn.GELU() default) and its derivative
 __device__ inline float gelu_fwd(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU for the frozen teacher's fused fc1 epilogue (no quantisation grid there, so no table): erfc by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute, the size of erff's own rounding), one exp2 + one rcp + five FMAs instead of libm's erff.
+// 0.5 x (1 + erf(x / sqrt 2)) is evaluated through erfc on the side that would cancel: x < 0 -> 0.5 x E, x >= 0 -> x (1 - 0.5 E).
+__device__ inline float gelu_fwd_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float E = pl * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erfc(z)
+    return x < 0.f ? 0.5f * x * E : x * (1.0f - 0.5f * E);
+}
 __device__ inline float gelu_bwd(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
