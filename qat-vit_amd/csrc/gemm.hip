@@ -1007,11 +1007,8 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     if (p.partial) {
         // raw accumulators in their register layout, one float4 per lane per fragment: 1-KiB coalesced stores, no atomics;
         // scale / mask / accumulate happen once per element in k_tn_reduce (fixed summation order: bit-reproducible)
-        float4* dst = reinterpret_cast<float4*>(p.partial) + ((int64_t)vb * NW + wave) * (TM * TNT * 64);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TNT; ++j) dst[(i * TNT + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        // (bias first: its row_div loads issued after the tile stores would wait for every one of them to be acknowledged - loads and
+        //  stores share one in-order counter - at the very end of a single-round kernel)
         if (do_bias && r == 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -1021,6 +1018,11 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
                     if (n < p.N) atomicAdd(&p.dbias[n], accb[i][e] * (p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f));
                 }
         }
+        float4* dst = reinterpret_cast<float4*>(p.partial) + ((int64_t)vb * NW + wave) * (TM * TNT * 64);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) dst[(i * TNT + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         return;
     }
 #pragma unroll
