@@ -518,9 +518,10 @@ __global__ __launch_bounds__(64) void k_embed_bwd(const float* __restrict__ dx0,
     const QP q = load_qp(qp);
     const int d4 = D / 4;
     const int64_t n4 = (int64_t)T * d4;
-    constexpr int UNR = 8;
+    constexpr int UNR = 16;   // (about one wave per CU exists, so the kernel is UNR-deep round trips over the batch: 8 -> 16 halves them)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(i / d4), c = (int)(i % d4) * 4;
+        const int ty = t > 0 ? t - 1 : 0;     // (branch-free: the class-token row reads patch 0 and ignores it)
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int b0 = 0; b0 < B; b0 += UNR) {
             float4 g[UNR], y[UNR];
@@ -528,8 +529,10 @@ __global__ __launch_bounds__(64) void k_embed_bwd(const float* __restrict__ dx0,
             for (int u = 0; u < UNR; ++u) {
                 const int b = b0 + u < B ? b0 + u : B - 1;
                 g[u] = *reinterpret_cast<const float4*>(dx0 + ((int64_t)b * T + t) * D + c);
-                y[u] = t > 0 ? *reinterpret_cast<const float4*>(Y0 + ((int64_t)b * (T - 1) + (t - 1)) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                y[u] = *reinterpret_cast<const float4*>(Y0 + ((int64_t)b * (T - 1) + ty) * D + c);
             }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) { pin4(g[u]); pin4(y[u]); }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 if (b0 + u < B) {
