@@ -9,6 +9,13 @@ A "step" = student forward + label-smoothed CE + backward (+ bucketed RCCL gradi
 overlapped with backward and the rank-0 fake-quant-state broadcast when N>1); optimizer/clip are
 outside the metric.  `--backend x86 --teacher` gives config C3/C4
 (per-channel weights, [0,127] activations, KD against a frozen ViT-B teacher: native 3-pass split-bf16 forward).
+
+Started directly with ``--gpus N`` (N > 1, no WORLD_SIZE in the environment) it launches its own N workers - the reference starts
+its workers itself too (scripts/train_final.sh:13, torchrun --standalone) - BEFORE any GPU call; the parent never touches the GPU,
+relays rank 0's JSON line and exits non-zero if any worker fails.
+
+The headline steps run with NO profiling hooks; per-kernel HIP-event timing (roofline / mfma_gemms) and the extra configurations
+(C3 with its teacher share, C5) run afterwards in separate, untimed-for-the-headline steps.
 """
 from __future__ import annotations
 
@@ -30,6 +37,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+I8_PEAK_TOPS = 5000.0      # dense int8 MFMA (v_mfma_i32_16x16x64_i8: twice the bf16 rate)
 
 
 def prepare(wrapper, backend):
@@ -99,7 +107,7 @@ def hbm_kernel_rates(batch, iters=20):
     return out
 
 
-def cpu_baseline(seconds=15.0):
+def cpu_baseline(seconds=12.0):
     """The oracle (CPU restatement of the reference step over torch.ao eager QAT) on this box's
     host cores, BASELINE config C1 shapes (ViT-S, batch 8, qnnpack)."""
     from oracle import step_ref
@@ -120,6 +128,72 @@ def cpu_baseline(seconds=15.0):
             "sample": f"{n} steps of ViT-S student QAT fwd+bwd at batch 8 (config C1), qnnpack, fp32, torch {torch.__version__} CPU eager"}
 
 
+def spawn_workers(n, argv):
+    """``bench.py --gpus N`` started directly: run N workers (one per GPU, RCCL rendezvous on 127.0.0.1), relay rank 0's stdout.
+    Nothing in this process has touched the GPU (importing torch does not)."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, rc = "", 0
+    try:
+        out0, _ = procs[0].communicate()
+        for q in procs:
+            q.wait()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    for r, q in enumerate(procs):
+        if q.returncode != 0:
+            print(f"bench.py: worker rank {r} exited with {q.returncode}", file=sys.stderr)
+            rc = 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if rc == 0 and '"metric"' not in out0:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    raise SystemExit(rc)
+
+
+def build_model(qat_vit_amd, student, backend, dev):
+    if student == "vit_small":
+        stu = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True).to(dev)
+    else:
+        stu = qat_vit_amd.create_model("vit_base_patch16_224_teacher", pretrained=False, num_classes=10, qat_wrapper=True).to(dev)
+    return prepare(stu, backend).to(dev)
+
+
+def timed_steps(step, steps, warmup, world, dev):
+    """W untimed steps, then exactly K timed ones bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    return dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,13 +206,16 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (launch-bound small batches; N=1, no teacher)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rates", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C3 / C5 legs that follow the headline measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_workers(args.gpus, sys.argv[1:])          # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # rehearsal knobs for a ONE-GPU box (tests the N>1 code path, not its speed): all ranks on device 0, gloo as the transport
     if os.environ.get("BENCH_ONE_DEVICE"):
         local = 0
@@ -159,42 +236,43 @@ def main():
 
     L = native.lib()  # fail loudly before any timing if the HIP library is missing
     torch.manual_seed(0)
-    if args.student == "vit_small":
-        student = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True).to(dev)
-    else:
-        student = qat_vit_amd.create_model("vit_base_patch16_224_teacher", pretrained=False, num_classes=10, qat_wrapper=True).to(dev)
-    model = prepare(student, args.backend).to(dev)
-    teacher = None
-    if args.teacher:
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            teacher = qat_vit_amd.create_teacher("vit", num_classes=10).to(dev).eval()
-        for p in teacher.parameters():
-            p.requires_grad = False
 
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(args.batch, 3, 224, 224, device=dev, generator=g)
-    y = torch.randint(0, 10, (args.batch,), device=dev, generator=g)
+    def make_config(student, qbackend, with_teacher, batch):
+        """(step function, engine) for one configuration; synthetic N(0,1) images generated on the device once, seed 1234 + rank."""
+        model = build_model(qat_vit_amd, student, qbackend, dev)
+        teacher = None
+        if with_teacher:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                teacher = qat_vit_amd.create_teacher("vit", num_classes=10).to(dev).eval()
+            for p in teacher.parameters():
+                p.requires_grad = False
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        x = torch.randn(batch, 3, 224, 224, device=dev, generator=g)
+        y = torch.randint(0, 10, (batch,), device=dev, generator=g)
+        with torch.no_grad():
+            model(x)  # builds the native engine (workspace, FQ arena)
+        eng = engine_of(model)
+        if world > 1:
+            eng.enable_data_parallel()
 
-    with torch.no_grad():
-        model(x)  # builds the native engine (workspace, FQ arenas)
-    eng = engine_of(model)
-    if world > 1:
-        eng.enable_data_parallel()
-
-    def step():
-        for p in eng.params:
-            p.grad = None
-        t_out = None
-        if teacher is not None:
+        def teacher_only():
             with torch.no_grad():
-                t_out = teacher(x)   # eval + no_grad + CUDA -> qatvit_teacher_forward
-        out = model(x)
-        loss, _ = F.kd_ce_loss(out, t_out, y, 4.0, 0.5, 0.1)
-        loss.backward()
+                return teacher(x)   # eval + no_grad + CUDA -> qatvit_teacher_forward
 
+        def step():
+            for p in eng.params:
+                p.grad = None
+            t_out = teacher_only() if teacher is not None else None
+            out = model(x)
+            loss, _ = F.kd_ce_loss(out, t_out, y, 4.0, 0.5, 0.1)
+            loss.backward()
+
+        return step, eng, model, x, y, (teacher_only if teacher is not None else None)
+
+    step, eng, model, x, y, _ = make_config(args.student, args.backend, args.teacher, args.batch)
     if args.graph:
-        if world > 1 or teacher is not None:
+        if world > 1 or args.teacher:
             raise SystemExit("--graph: single GPU, no teacher")
         from qat_vit_amd.graph import GraphedStudentStep
 
@@ -203,76 +281,110 @@ def main():
         def step():  # noqa: F811
             gstep(x, y)
 
-    for _ in range(args.warmup):
-        step()
-    n_nt2 = 6 * eng.cfg.depth  # proj fwd, fc2 fwd + 4 dgrads per block
-    if rank == 0:
-        native.check(L.qatvit_profile_start(1, n_nt2 * args.steps + 8), "profile_start")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = timed_steps(step, args.steps, args.warmup, world, dev)     # the headline: no profiling hooks are active
 
-    if rank == 0:
+    ws = eng.workspace.data_ptr()
+
+    def profile_kind(kind, nsteps):
+        """HIP events around every launch of one GEMM class, on the stream it is launched on, in `nsteps` extra steps (outside the headline)."""
         ms, cnt, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-        native.check(L.qatvit_profile_stop(ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl)), "profile_stop")
+        native.check(L.qatvit_profile_start(ws, kind, (8 * eng.cfg.depth + 16) * nsteps), "profile_start")
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        native.check(L.qatvit_profile_stop(ws, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl)), "profile_stop")
+        return ms.value, cnt.value, fl.value
+
+    res = None
+    if rank == 0:
         imgs = args.batch * world * args.steps
         res = {
             "metric": "images/sec QAT student step (fwd+bwd+allreduce)",
             "value": round(imgs / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 semantics (int8 MFMA for grid x grid products, bf16 MFMA on exact grid / hi+lo split operands, exact or fp32 accumulate)", "data": "synthetic",
+            "dtype": "f32 (emulated: int8 MFMA for grid x grid products, 16-bit MFMA on exact-grid / hi+lo split operands; exact-integer or fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"{args.student}_patch16_224 student + QATWrapper, {args.backend} qconfig, "
                                    f"{'vit_base teacher KD (native teacher forward inside the timed step)' if args.teacher else 'no teacher'}, "
                                    f"batch {args.batch}/GPU, 224x224x3 (BASELINE configs[{2 if args.teacher else 1}])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(args.graph)},
         }
-        tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    # ---- per-kernel legs: every rank runs the same extra steps (collectives stay matched), rank 0 times its own launches
+    prof = {}
+    nprof = 0 if args.graph else 3
+    for kind in (1, 2, 3):
+        if nprof == 0:
+            break
+        if rank == 0:
+            prof[kind] = profile_kind(kind, nprof)
+        else:
+            for _ in range(nprof):
+                step()
+    if rank == 0 and prof:
+        ms, cnt, fl = prof[1]
+        tflops = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic, traffic_note = None, None
-        try:   # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh, B=256 shapes)
-            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_gemm_pmc_traffic_tall.json")))
+        try:   # HBM-side bytes per launch of that kernel: NOT measured by this run - an offline rocprofv3 --pmc collection at B=256 shapes
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_gemm_pmc_traffic_tall.json")))
             per = [v for k, v in pm.items() if "k_gemm_nt<2, 3, 1, 13" in k][0]       # proj, fc2 fwd, qkv dgrad, fc1 dgrad, fc2 dgrad
             mix = [per[0], per[1], per[2], per[0], per[3], per[4]]                      # + proj dgrad (= proj forward's shape)
             if args.batch == 256 and args.student == "vit_small":
-                traffic = round(sum(x["fetch_MB"] + x["write_MB"] for x in mix) / len(mix) * 1e6)
-                traffic_note = "mean FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch over the kernel's six uses, separate --pmc passes: profiles/round1_gemm_pmc_traffic_tall.json"
+                traffic = round(sum(v["fetch_MB"] + v["write_MB"] for v in mix) / len(mix) * 1e6)
+                traffic_note = ("STATIC, not measured in this run: mean FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch over the kernel's six uses, "
+                                "offline rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/round1_gemm_pmc_traffic_tall.json")
         except Exception:  # noqa: BLE001
             pass
         res["roofline"] = {
-            "bound": "mfma", "kernel": "qv::k_gemm_nt<2,3,1,13,1,0,8,3,32>, split-bf16 A operand (proj/fc2 forward + all dgrads; 208x384 tiles; "
+            "bound": "mfma", "kernel": "qv::k_gemm_nt split-A (float A operand as a 16-bit hi+lo pair; proj/fc2 forward + all dgrads; 208x384 tiles; "
                                        "the largest single kernel of the step)",
-            "achieved": round(tflops, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-            "launches": cnt.value, "avg_us_per_launch": round(1e3 * ms.value / max(1, cnt.value), 1),
-            "note": "algorithmic FLOPs 2*M*N*K per launch / HIP-event time of that launch inside the timed steps; every launch issues two "
-                    "bf16 MFMA passes (hi and lo), so issued MFMA work is 2x this figure",
+            "achieved": round(tflops, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / BF16_PEAK_TFLOPS, 4),
+            "traffic": traffic, "traffic_note": traffic_note, "launches": cnt, "avg_us_per_launch": round(1e3 * ms / max(1, cnt), 1),
+            "note": f"algorithmic FLOPs 2*M*N*K per launch / HIP-event time of that launch on its launch stream, {nprof} steps run right after the timed "
+                    "region (no event is recorded inside the timed region); every launch issues two 16-bit MFMA passes (hi and lo), so issued MFMA work is 2x this figure",
         }
-        # MFMA utilisation of the other two GEMM kernels (fused-QKV / MLP GEMMs), two extra untimed steps each
         other = {}
-        for kind, name in ((2, "k_gemm_nt grid A (patch-embed, qkv, fc1 forward; one bf16 pass)"),
-                           (3, "k_gemm_tn (all weight gradients; split dY, grid or split X)")):
-            native.check(L.qatvit_profile_start(kind, 8 * eng.cfg.depth + 16), "profile_start")
-            if world == 1:
-                step(); step()
-                torch.cuda.synchronize()
-            native.check(L.qatvit_profile_stop(ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl)), "profile_stop")
-            if ms.value > 0:
-                tf = fl.value / (ms.value * 1e-3) / 1e12
-                other[name] = {"algorithmic_TFLOPs": round(tf, 1), "frac_of_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4),
-                               "launches": cnt.value, "avg_us_per_launch": round(1e3 * ms.value / max(1, cnt.value), 1)}
-        if other:
-            res["mfma_gemms"] = other
-        if not args.no_kernel_rates:
-            res["hbm_kernels"] = hbm_kernel_rates(args.batch)
+        ms2, cnt2, fl2 = prof[2]
+        if ms2 > 0:
+            tf = fl2 / (ms2 * 1e-3) / 1e12
+            other["k_gemm_nt grid A on int8 MFMA (patch-embed, qkv, fc1 forward)"] = {
+                "algorithmic_TOPs": round(tf, 1), "peak_TOPs_int8": I8_PEAK_TOPS, "frac_of_int8_peak": round(tf / I8_PEAK_TOPS, 4), "launches": cnt2,
+                "avg_us_per_launch": round(1e3 * ms2 / max(1, cnt2), 1),
+                "note": "fc1 runs twice (statistics-only pass + storing pass): both launches are timed, only one counts as algorithmic work"}
+        ms3, cnt3, fl3 = prof[3]
+        if ms3 > 0:
+            tf = fl3 / (ms3 * 1e-3) / 1e12
+            other["k_gemm_tn (all weight gradients; split dY, grid or split X; 2-3 bf16 passes issued)"] = {
+                "algorithmic_TFLOPs": round(tf, 1), "frac_of_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4), "launches": cnt3,
+                "avg_us_per_launch": round(1e3 * ms3 / max(1, cnt3), 1)}
+        res["mfma_gemms"] = other
+    if rank == 0 and not args.no_kernel_rates:
+        res["hbm_kernels"] = hbm_kernel_rates(args.batch)
+    # ---- the other single-GPU-sized configurations of BASELINE.json, on the same clock discipline (fewer steps): every rank runs them
+    if not args.no_extras and not args.graph and not args.teacher and args.student == "vit_small" and args.batch == 256:
+        del step, model, x, y
+        eng.workspace = None
+        del eng
+        torch.cuda.empty_cache()
+        extras = {}
+        for tag, cfgs in (("C3" if world == 1 else "C4", ("vit_small", "x86", True, 256)), ("C5", ("vit_base", "x86", False, 128))):
+            st2, eng2, _m, _x, _y, t_only = make_config(*cfgs)
+            k = max(5, args.steps // 4)
+            d2 = timed_steps(st2, k, 3, world, dev)
+            e = {"value": round(cfgs[3] * world * k / d2, 2), "unit": "images/sec", "ms_per_step": round(1e3 * d2 / k, 3), "steps": k, "warmup": 3,
+                 "n_gpus": world, "workload": f"{cfgs[0]}_patch16_224 student, {cfgs[1]} qconfig (per-channel weight fake-quant, [0,127] activations), "
+                                              f"{'vit_base teacher KD inside the step' if cfgs[2] else 'no teacher'}, batch {cfgs[3]}/GPU"}
+            if t_only is not None:
+                d3 = timed_steps(t_only, k, 2, 1, dev)
+                e["teacher_forward_ms"] = round(1e3 * d3 / k, 3)
+                e["student_step_ms"] = round(1e3 * (d2 - d3) / k, 3)
+            extras[tag] = e
+            del st2, _m, _x, _y, t_only
+            eng2.workspace = None
+            del eng2
+            torch.cuda.empty_cache()
+        if rank == 0:
+            res["extra_configs"] = extras
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QATVIT_ABI_VERSION 1
+#define QATVIT_ABI_VERSION 2
 
 int qatvit_abi_version(void);
 const char* qatvit_last_error(void);
@@ -180,6 +180,23 @@ int qatvit_student_forward(const qatvit_cfg* cfg, void* const* params, const qat
 int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
                             const float* dlogits, void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to,
                             void* stream);
+/* The same two calls over a range of stages, for stage-level (teacher-forced) parity tests and for callers that interleave other work.
+ * Forward stages: 0 = weight fake-quant + input fake-quant + patch embedding (leaves the residual stream x_in[0] in the workspace);
+ * s = 1..depth = transformer block s-1 (reads x_in[s-1], leaves x_in[s]); depth+1 = final norm, cls pooling, head, logits fake-quant.
+ * Backward stages are those of qatvit_student_backward.  A full step is forward [0, depth+1] then backward [0, depth+1].
+ * flags & QATVIT_STAGE_INJECT (stage_from >= 1): the tensor ENTERING stage_from was written into the workspace by the caller instead of
+ * by the preceding stage - forward: x_in[stage_from-1] (qatvit_student_tensor_offset "x_in"); backward: the residual-stream gradient
+ * "dxA" (d loss / d x_in[depth - stage_from + 1]; for stage depth+1 d loss / d x_in[0]).  The library then recomputes what the
+ * preceding stage would have left beside that tensor (LayerNorm row statistics and the next observer's min/max; the masked (hi, lo)
+ * copy of the gradient) before running the stages.  images may be NULL when stage_from > 0, logits when stage_to <= depth, dlogits when
+ * stage_from > 0.  Replaces, per stage, the corresponding slice of `ddp_model(images)` / `loss.backward()` (qat_trainer.py:341,359). */
+#define QATVIT_STAGE_INJECT 1
+int qatvit_student_forward_stages(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
+                                  const float* images, float* logits, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags,
+                                  void* stream);
+int qatvit_student_backward_stages(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
+                                   const float* dlogits, void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags,
+                                   void* stream);
 /* ---------------------------------------------------------------------------
  * Frozen KD teacher forward (no fake-quant, no gradient).
  * Replaces: `with torch.no_grad(): teacher_out = teacher(images)` (qat_trainer.py:337-338).
@@ -212,12 +229,13 @@ int qatvit_optim_adamw(const void* param_ptrs, const void* grad_ptrs, const void
                        int64_t chunk_elems, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                        const float* clip_out2, void* stream);
 
-/* Measurement hooks (bench.py): bracket every launch of one GEMM class inside the step with HIP events on the
- * launch stream.  kind: 1 = NT with split (hi+lo) A operand, 2 = NT with grid A operand, 3 = TN (wgrad).
+/* Measurement hooks (bench.py): bracket every launch of one GEMM class inside the steps of ONE engine - identified by its workspace
+ * pointer, so engines in the same process do not see each other's sessions - with HIP events on the launch stream.
+ * kind: 1 = NT with split (hi+lo) A operand, 2 = NT with grid A operand, 3 = TN (wgrad).
  * stop() synchronises on the recorded events and returns the summed kernel time, launch count and the summed
  * algorithmic FLOPs (2*M*N*K per launch, one pass). */
-int qatvit_profile_start(int32_t kind, int32_t max_launches);
-int qatvit_profile_stop(double* total_ms, int64_t* launches, double* flops);
+int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launches);
+int qatvit_profile_stop(const void* workspace, double* total_ms, int64_t* launches, double* flops);
 /* byte offset of a named intermediate tensor inside the workspace (tests); -1 if unknown */
 int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, int32_t block);
 

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_img_patches(const float* __restrict__ i
 // ---------------------------------------------------------------- residual + FQ + LN statistics
 // MODE 0: x_new[b,0,:] = cls + pos[0];  x_new[b,1+p,:] = fq(Y[b*np+p,:]) + pos[1+p,:]
 // MODE 1: x_new = x_prev + fq(Y)
+// MODE 2: x_new = x_prev, nothing is stored (statistics of a residual-stream tensor the caller wrote: stage-level parity tests)
 // then: mean/rstd of the x_new row and min/max of LN(x_new)*gamma+beta (the next aFQ's observer input).
 constexpr int kMaxV = 3;  // float4 per lane per row: D <= 768
 __device__ inline void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
         const int t = (int)(row % T);
         const int64_t b = row / T;
         const bool is_cls = MODE == 0 && t == 0;                  // wave-uniform: the class token is added as it is
-        const float* ysrc = MODE == 0 ? (is_cls ? cls : Y + (b * (T - 1) + (t - 1)) * D) : Y + row * D;
         const float* bsrc = MODE == 0 ? pos + (int64_t)t * D : x_prev + row * D;
+        const float* ysrc = MODE == 0 ? (is_cls ? cls : Y + (b * (T - 1) + (t - 1)) * D) : MODE == 1 ? Y + row * D : bsrc;
         float4 yr[NV], base[NV], v[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
             float4 y = make_float4(fqv(yr[j].x, q, qmin, qmax, i0), fqv(yr[j].y, q, qmin, qmax, i1), fqv(yr[j].z, q, qmin, qmax, i2),
                                    fqv(yr[j].w, q, qmin, qmax, i3));
             if (is_cls) y = yr[j];
+            if (MODE == 2) y = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == 1) {   // uniform control flow: the ballots stay in scalar registers
                 mb[j][0] = __ballot(act[j] && i0); mb[j][1] = __ballot(act[j] && i1);
                 mb[j][2] = __ballot(act[j] && i2); mb[j][3] = __ballot(act[j] && i3);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
         // (stores after every load of the row has been consumed: vmcnt is in issue order, a store between two loads' uses is waited for)
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-            if (act[j]) *reinterpret_cast<float4*>(x_new + row * D + cc[j]) = v[j];
+            if (MODE != 2 && act[j]) *reinterpret_cast<float4*>(x_new + row * D + cc[j]) = v[j];
         const float mu = wave_sum(s) / (float)D;
         float qq = 0.f;
 #pragma unroll
@@ -613,11 +615,12 @@ int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const
                             float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
                             int64_t M, int D, int T, hipStream_t st, void* maskbits) {
     if (D % 4 != 0 || D > 256 * kMaxV) { set_error("resid_fq_lnstats: D=%d unsupported (need D%%4==0, D<=768)", D); return 1; }
-    unsigned long long* mbits = mode == 0 ? nullptr : reinterpret_cast<unsigned long long*>(maskbits);
+    unsigned long long* mbits = mode != 1 ? nullptr : reinterpret_cast<unsigned long long*>(maskbits);
 #define QV_RESID(MODE_, NV_) k_resid_fq_lnstats<MODE_, NV_><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T, mbits)
     const int nv = (D + 255) / 256;
     if (mode == 0) { if (nv == 1) QV_RESID(0, 1); else if (nv == 2) QV_RESID(0, 2); else QV_RESID(0, 3); }
-    else { if (nv == 1) QV_RESID(1, 1); else if (nv == 2) QV_RESID(1, 2); else QV_RESID(1, 3); }
+    else if (mode == 1) { if (nv == 1) QV_RESID(1, 1); else if (nv == 2) QV_RESID(1, 2); else QV_RESID(1, 3); }
+    else { if (nv == 1) QV_RESID(2, 1); else if (nv == 2) QV_RESID(2, 2); else QV_RESID(2, 3); }
 #undef QV_RESID
     return 0;
 }

@@ -8,6 +8,8 @@
 // device state (backward runs on autograd's worker thread).
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/qatvit.h"
@@ -144,7 +146,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->delta = take((int64_t)d.B * d.H * p->TP * 4);
     p->dh = take((int64_t)d.B * D * 4);
     p->dY0_hi = take((int64_t)d.B * d.np * D * 2); p->dY0_lo = take((int64_t)d.B * d.np * D * 2);
-    p->tn_scratch = take(2 * kTnScratchBytes);   // split partials of the weight-gradient GEMMs (two-phase, non-atomic reduction), two halves
+    p->tn_scratch = take(kTnScratchBytes);   // split partials of the weight-gradient GEMMs (two-phase, non-atomic reduction)
     p->total = o;
     return 0;
 }
@@ -159,34 +161,33 @@ static int check_cfg(const qatvit_cfg& c) {
     return 0;
 }
 
-// ---- optional in-situ timing of one GEMM class with HIP events on the launch stream (bench.py only)
+// ---- optional in-situ timing of one GEMM class with HIP events on the launch stream (bench.py only).  The state belongs to ONE engine:
+// it is keyed by that engine's workspace pointer, so two engines in one process (student + a second model, two threads) never see each
+// other's events; an engine without an active profile pays one map lookup per forward / backward call.
 struct Prof {
     int kind = 0;  // 0 off, 1 NT split-A (k_gemm_nt<2,3>), 2 NT grid-A (k_gemm_nt<1,2>), 3 TN
     std::vector<hipEvent_t> ev;
     size_t used = 0;
     double flops = 0.0;
 };
-static Prof g_prof;
+static std::mutex g_prof_mu;
+static std::unordered_map<const void*, Prof*> g_profs;
+static Prof* prof_of(const void* workspace) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto it = g_profs.find(workspace);
+    return it == g_profs.end() ? nullptr : it->second;
+}
 struct ProfScope {
+    Prof* pr;
     hipStream_t st;
     bool on;
-    ProfScope(int kind, double flops, hipStream_t s) : st(s), on(g_prof.kind == kind && g_prof.used + 2 <= g_prof.ev.size()) {
-        if (on) { (void)hipEventRecord(g_prof.ev[g_prof.used], st); g_prof.flops += flops; }
+    ProfScope(Prof* p, int kind, double flops, hipStream_t s) : pr(p), st(s), on(p && p->kind == kind && p->used + 2 <= p->ev.size()) {
+        if (on) { (void)hipEventRecord(pr->ev[pr->used], st); pr->flops += flops; }
     }
     ~ProfScope() {
-        if (on) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st); g_prof.used += 2; }
+        if (on) { (void)hipEventRecord(pr->ev[pr->used + 1], st); pr->used += 2; }
     }
 };
-
-// second phase of the split weight gradients on a side stream: QATVIT_TN_ASYNC=1.  Off by default: measured 28.4 vs 28.5 ms per step
-// (the reduction hardly overlaps the next GEMM although 13 CUs and 100 VGPRs per SIMD are free), not worth a second stream
-static TnAsync g_tn_async{};
-static TnAsync* tn_async() {
-    static const int on = getenv("QATVIT_TN_ASYNC") ? atoi(getenv("QATVIT_TN_ASYNC")) : 0;
-    if (!on) return nullptr;
-    if (!g_tn_async.ready && tn_async_init(&g_tn_async)) return nullptr;
-    return &g_tn_async;
-}
 
 // QATVIT_FC1_RECOMPUTE=0: fc1 once, fp32 output, separate fq+gelu pass (the pre-recompute path; keeps Y1 as fp32 for diagnostics)
 static bool fc1_recompute() {
@@ -209,6 +210,7 @@ struct Ctx {
     const qatvit_fq* act;
     const qatvit_fq* wfq;
     hipStream_t st;
+    Prof* prof;
     template <typename T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
     template <typename T> T* blk(int64_t off, int i) const { return reinterpret_cast<T*>(ws + off + p.blk_stride * i); }
     const float* prm(int i) const { return reinterpret_cast<const float*>(params[i]); }
@@ -231,7 +233,7 @@ struct Ctx {
                    const NTPost* post = nullptr, bool with_stats = true) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(A_lo ? 1 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);   // a statistics-only pass is issued, not algorithmic, work
+        ProfScope ps(prof, A_lo ? 1 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);   // a statistics-only pass is issued, not algorithmic, work
         return launch_gemm_nt(A_hi, A_lo, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
                               c.w_per_channel ? f.scale : nullptr, bias, with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, nullptr, post);
     }
@@ -243,7 +245,7 @@ struct Ctx {
         int N, K; wshape(d, wi, &N, &K);
         if (!use_i8() || N % 384 != 0 || K % 64 != 0) return linear_fwd(A16, nullptr, M, wi, a_qp, bias, C, ai_out, post, with_stats);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);
+        ProfScope ps(prof, 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);
         return launch_gemm_nt_i8(A8, at<void>(p.w8_off[wi]), at<int32_t>(p.wsum_off[wi]), a_qp, center(), C, M, N, K, K, K, N, a_qp,
                                  c.w_per_channel ? nullptr : f.scale, c.w_per_channel ? f.scale : nullptr, bias,
                                  with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, post);
@@ -254,7 +256,7 @@ struct Ctx {
     int linear_dgrad(const void* dY_hi, const void* dY_lo, int M, int wi, float* dX, const NTPost* post = nullptr) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(1, 2.0 * M * N * K, st);
+        ProfScope ps(prof, 1, 2.0 * M * N * K, st);
         return launch_gemm_nt(dY_hi, dY_lo, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr,
                               nullptr, nullptr, 1, st, nullptr, post);
     }
@@ -263,18 +265,39 @@ struct Ctx {
                      bool dy_scaled = true) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(3, 2.0 * M * N * K, st);
+        ProfScope ps(prof, 3, 2.0 * M * N * K, st);
         return launch_gemm_tn(dY_hi, dY_lo, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
-                              c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), 2 * kTnScratchBytes, tn_async());
+                              c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
     }
 };
 
-static int fwd(const Ctx& x, const float* images, float* logits) {
+// x_in[i] (the input of block i, or of the final norm for i == depth) was written into the workspace by the caller (teacher forcing in
+// the stage-level parity tests): compute what the producer of that tensor would have left behind for its consumer - the row mean / rstd
+// and the min/max of the LayerNorm output that the consumer's first fake-quant observes.
+static int inject_ln_stats(const Ctx& x, int i) {
+    const Dims& d = x.d;
+    const Plan& p = x.p;
+    const bool last = (i == d.depth);
+    const float* g = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth) : x.bprm(i, B_N1W);
+    const float* bt = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth + 1) : x.bprm(i, B_N1B);
+    float* mean = last ? x.at<float>(p.meanF) : x.blk<float>(p.mean1, i);
+    float* rstd = last ? x.at<float>(p.rstdF) : x.blk<float>(p.rstd1, i);
+    const int ai = last ? x.a_norm() : x.aidx(i, AB_N1);
+    launch_ws_init(x.act_stats(ai), kStatSlots * kStatStride / 2, x.st);   // whatever an earlier, unconsumed producer accumulated is stale
+    return launch_resid_fq_lnstats(2, x.blk<float>(p.x_in, i), nullptr, x.act_qp(0), x.c.act_qmin, x.c.act_qmax, nullptr, nullptr, nullptr, mean, rstd, g, bt,
+                                   x.c.ln_eps, x.act_stats(ai), kStatSlots, d.M, d.D, d.T, x.st);
+}
+
+// forward stages: 0 = weight preparation + input fake-quant + patch embedding (leaves x_in[0]); s in 1..depth = block s-1 (leaves
+// x_in[s]); depth+1 = final norm + cls pooling + head + logits fake-quant.  `inject`: x_in[s_from - 1] was written by the caller.
+static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int s_to, bool inject) {
     const Dims& d = x.d;
     const Plan& p = x.p;
     const qatvit_cfg& c = x.c;
     hipStream_t st = x.st;
     const int qa = c.act_qmin, qb = c.act_qmax;
+    if (inject && s_from >= 1 && inject_ln_stats(x, s_from - 1)) return 1;
+    if (s_from == 0) {
     // ---- weights: observe, qparams, integer operands (row-major and transposed) - all 50 tensors in three launches
     static const int wbatch = getenv("QATVIT_WBATCH") ? atoi(getenv("QATVIT_WBATCH")) : 1;   // 0: one launch triple per weight (tuning)
     if (wbatch && d.n_w <= kMaxW) {
@@ -328,8 +351,9 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
                                 x.blk<float>(p.mean1, 0), x.blk<float>(p.rstd1, 0), x.bprm(0, B_N1W), x.bprm(0, B_N1B), c.ln_eps,
                                 x.act_stats(x.aidx(0, AB_N1)), kStatSlots, d.M, d.D, d.T, st))
         return 1;
+    }   // stage 0
     const int M = (int)d.M;
-    for (int i = 0; i < d.depth; ++i) {
+    for (int i = (s_from < 1 ? 0 : s_from - 1); i < d.depth && i + 1 <= s_to; ++i) {
         float* xin = x.blk<float>(p.x_in, i);
         float* xmid = x.blk<float>(p.x_mid, i);
         // norm1 -> qkv
@@ -391,6 +415,7 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
                                 mean, rstd, g, bt, c.ln_eps, x.act_stats(last ? x.a_norm() : x.aidx(i + 1, AB_N1)), kStatSlots, d.M, d.D, d.T, st,
                                 x.blk<void>(p.m2, i));
     }
+    if (s_to < d.depth + 1) return 0;
     // ---- final norm (observer saw all tokens), cls pooling, head
     x.qparams_act(x.a_norm());
     const int base = P_BLOCK0 + B_COUNT * d.depth;
@@ -404,7 +429,10 @@ static int fwd(const Ctx& x, const float* images, float* logits) {
 }
 
 // stages: 0 = head + final norm; 1..depth = blocks depth-1..0; depth+1 = embedding
-static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage_from, int stage_to) {
+// `inject`: the gradient entering stage_from (dxA = d loss / d x_in[depth - stage_from + 1] for a block stage, / d x_in[0] for the embedding
+// stage) was written by the caller; a block stage then rebuilds the masked (hi, lo) copy of it that the previous stage's fused
+// LayerNorm backward would have left for the fc2 weight / data gradient GEMMs.
+static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage_from, int stage_to, bool inject) {
     const Dims& d = x.d;
     const Plan& p = x.p;
     const qatvit_cfg& c = x.c;
@@ -441,7 +469,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             void* dYl = x.at<void>(p.dYs_lo);
             const int w_fc2 = x.widx(i, WB_FC2), w_fc1 = x.widx(i, WB_FC1), w_proj = x.widx(i, WB_PROJ), w_qkv = x.widx(i, WB_QKV);
             // ---- MLP branch
-            if (!ln_fuse) launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
+            if (!ln_fuse || (inject && s == stage_from)) launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
             if (x.linear_wgrad(dYh, dYl, M, w_fc2, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
             {   // fc2 dgrad with the GELU backward + fc1's STE mask fused into its epilogue: dY1 = (dYs . W_fc2) * gelu'(fq(Y1)) * mask(Y1)
                 NTPost post{x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), x.at<void>(p.dY1_hi),
@@ -515,61 +543,103 @@ int qatvit_student_init(const qatvit_cfg* cfg, void* workspace, void* stream) {
     return 0;
 }
 
+static int run_forward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, const float* images,
+                       float* logits, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags, void* stream, const char* who) {
+    QV_CHECK_ARG(cfg && params && act_fq && weight_fq && workspace, "%s: null argument", who);
+    if (check_cfg(*cfg)) return 1;
+    QV_CHECK_ARG(stage_from >= 0 && stage_to <= cfg->depth + 1 && stage_from <= stage_to, "%s: bad stage range [%d,%d]", who, stage_from, stage_to);
+    QV_CHECK_ARG(stage_from > 0 || images, "%s: stage 0 needs the images", who);
+    QV_CHECK_ARG(stage_to <= cfg->depth || logits, "%s: the last stage needs the logits buffer", who);
+    QV_CHECK_ARG((flags & ~QATVIT_STAGE_INJECT) == 0 && !((flags & QATVIT_STAGE_INJECT) && stage_from == 0), "%s: bad flags %d", who, flags);
+    Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream, prof_of(workspace)};
+    if (make_plan(*cfg, &x.p)) return 1;
+    if (fwd(x, images, logits, stage_from, stage_to, (flags & QATVIT_STAGE_INJECT) != 0)) return 1;
+    QV_CHECK_LAUNCH(who);
+    return 0;
+}
+
 int qatvit_student_forward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, const float* images,
                            float* logits, void* workspace, void* stream) {
-    QV_CHECK_ARG(cfg && params && act_fq && weight_fq && images && logits && workspace, "qatvit_student_forward: null argument");
+    QV_CHECK_ARG(cfg && images && logits, "qatvit_student_forward: null argument");
+    return run_forward(cfg, params, act_fq, weight_fq, images, logits, workspace, 0, cfg->depth + 1, 0, stream, "qatvit_student_forward");
+}
+
+int qatvit_student_forward_stages(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
+                                  const float* images, float* logits, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags,
+                                  void* stream) {
+    return run_forward(cfg, params, act_fq, weight_fq, images, logits, workspace, stage_from, stage_to, flags, stream, "qatvit_student_forward_stages");
+}
+
+static int run_backward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, const float* dlogits,
+                        void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags, void* stream, const char* who) {
+    QV_CHECK_ARG(cfg && params && act_fq && weight_fq && grads && workspace, "%s: null argument", who);
     if (check_cfg(*cfg)) return 1;
-    Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream};
+    QV_CHECK_ARG(stage_from >= 0 && stage_to <= cfg->depth + 1 && stage_from <= stage_to, "%s: bad stage range [%d,%d]", who, stage_from, stage_to);
+    QV_CHECK_ARG(stage_from > 0 || dlogits, "%s: stage 0 needs dlogits", who);
+    QV_CHECK_ARG((flags & ~QATVIT_STAGE_INJECT) == 0 && !((flags & QATVIT_STAGE_INJECT) && stage_from == 0), "%s: bad flags %d", who, flags);
+    Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream, prof_of(workspace)};
     if (make_plan(*cfg, &x.p)) return 1;
-    if (fwd(x, images, logits)) return 1;
-    QV_CHECK_LAUNCH("qatvit_student_forward");
+    if (bwd(x, dlogits, grads, stage_from, stage_to, (flags & QATVIT_STAGE_INJECT) != 0)) return 1;
+    QV_CHECK_LAUNCH(who);
     return 0;
 }
 
 int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, const float* dlogits,
                             void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to, void* stream) {
-    QV_CHECK_ARG(cfg && params && act_fq && weight_fq && dlogits && grads && workspace, "qatvit_student_backward: null argument");
-    if (check_cfg(*cfg)) return 1;
-    QV_CHECK_ARG(stage_from >= 0 && stage_to <= cfg->depth + 1 && stage_from <= stage_to, "qatvit_student_backward: bad stage range [%d,%d]",
-                 stage_from, stage_to);
-    Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream};
-    if (make_plan(*cfg, &x.p)) return 1;
-    const int rc = bwd(x, dlogits, grads, stage_from, stage_to);
-    tn_async_join(&g_tn_async, x.st);   // the caller's stream sees every dW complete (all-reduce / optimizer come next)
-    if (rc) return 1;
-    QV_CHECK_LAUNCH("qatvit_student_backward");
+    return run_backward(cfg, params, act_fq, weight_fq, dlogits, grads, workspace, stage_from, stage_to, 0, stream, "qatvit_student_backward");
+}
+
+int qatvit_student_backward_stages(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
+                                   const float* dlogits, void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags,
+                                   void* stream) {
+    return run_backward(cfg, params, act_fq, weight_fq, dlogits, grads, workspace, stage_from, stage_to, flags, stream, "qatvit_student_backward_stages");
+}
+
+// bench.py: time every launch of one GEMM class of ONE engine (identified by its workspace) with HIP events on the stream it is launched on
+int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launches) {
+    QV_CHECK_ARG(workspace && kind >= 1 && kind <= 3 && max_launches > 0, "qatvit_profile_start: bad arguments");
+    Prof* pr = new Prof();
+    pr->ev.assign((size_t)max_launches * 2, nullptr);
+    for (auto& e : pr->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            for (hipEvent_t d : pr->ev) if (d) (void)hipEventDestroy(d);
+            delete pr;
+            set_error("qatvit_profile_start: hipEventCreate failed");
+            return 2;
+        }
+    pr->kind = kind;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto it = g_profs.find(workspace);
+    if (it != g_profs.end()) {   // restart: drop the previous session of this engine
+        for (hipEvent_t e : it->second->ev) (void)hipEventDestroy(e);
+        delete it->second;
+        g_profs.erase(it);
+    }
+    g_profs[workspace] = pr;
     return 0;
 }
 
-// bench.py: time every launch of one GEMM class with HIP events on the stream it is launched on
-int qatvit_profile_start(int32_t kind, int32_t max_launches) {
-    QV_CHECK_ARG(kind >= 1 && kind <= 3 && max_launches > 0, "qatvit_profile_start: bad arguments");
-    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
-    g_prof.ev.assign((size_t)max_launches * 2, nullptr);
-    for (auto& e : g_prof.ev)
-        if (hipEventCreate(&e) != hipSuccess) { set_error("qatvit_profile_start: hipEventCreate failed"); return 2; }
-    g_prof.used = 0;
-    g_prof.flops = 0.0;
-    g_prof.kind = kind;
-    return 0;
-}
-
-int qatvit_profile_stop(double* total_ms, int64_t* launches, double* flops) {
-    QV_CHECK_ARG(total_ms && launches && flops, "qatvit_profile_stop: null argument");
+int qatvit_profile_stop(const void* workspace, double* total_ms, int64_t* launches, double* flops) {
+    QV_CHECK_ARG(workspace && total_ms && launches && flops, "qatvit_profile_stop: null argument");
+    Prof* pr = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        auto it = g_profs.find(workspace);
+        if (it != g_profs.end()) { pr = it->second; g_profs.erase(it); }   // no forward / backward of this engine records from here on
+    }
+    QV_CHECK_ARG(pr, "qatvit_profile_stop: no profile is active for this workspace");
     double ms = 0.0;
-    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-        (void)hipEventSynchronize(g_prof.ev[i + 1]);
+    for (size_t i = 0; i + 1 < pr->used; i += 2) {
+        (void)hipEventSynchronize(pr->ev[i + 1]);
         float t = 0.f;
-        (void)hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+        (void)hipEventElapsedTime(&t, pr->ev[i], pr->ev[i + 1]);
         ms += t;
     }
     *total_ms = ms;
-    *launches = (int64_t)(g_prof.used / 2);
-    *flops = g_prof.flops;
-    g_prof.kind = 0;
-    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
-    g_prof.ev.clear();
-    g_prof.used = 0;
+    *launches = (int64_t)(pr->used / 2);
+    *flops = pr->flops;
+    for (hipEvent_t e : pr->ev) (void)hipEventDestroy(e);
+    delete pr;
     return 0;
 }
 

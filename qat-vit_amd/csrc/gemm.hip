@@ -1120,33 +1120,9 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, i
         if (nbase + e < p.N) p.C[(int64_t)(nbase + e) * p.ldc + kw] = outv[e];
 }
 
-int tn_async_init(TnAsync* a) {
-    if (a->ready) return 0;
-    if (hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess) { set_error("tn_async_init: hipStreamCreate failed"); return 1; }
-    for (int i = 0; i < 2; ++i) {
-        if (hipEventCreateWithFlags(&a->tn_done[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a->red_done[i], hipEventDisableTiming) != hipSuccess) {
-            set_error("tn_async_init: hipEventCreate failed");
-            return 1;
-        }
-        a->pending[i] = false;
-    }
-    a->next = 0;
-    a->ready = true;
-    return 0;
-}
-void tn_async_join(TnAsync* a, hipStream_t st) {
-    if (!a || !a->ready) return;
-    for (int i = 0; i < 2; ++i)
-        if (a->pending[i]) {
-            (void)hipStreamWaitEvent(st, a->red_done[i], 0);
-            a->pending[i] = false;
-        }
-}
-
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                    const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
-                   float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes, TnAsync* async) {
+                   float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
     if (M < 1 || N % 128 != 0 || Kw % 128 != 0 || ldp % 8 != 0 || ldq % 8 != 0) {
         set_error("gemm_tn: unsupported shape M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%128==0, ld%%8==0)", M, N, Kw, ldp, ldq);
         return 1;
@@ -1183,16 +1159,8 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
         constexpr size_t lds = (size_t)NS_ * (2 * BK_ * 256 + TQ_ * BK_ * (WNK_ * TNT_ * 32));                      \
         constexpr int tm = 128 / WM_ / 16;                                                                         \
         const int64_t tile_f4 = (int64_t)WM_ * WNK_ * tm * TNT_ * 64;                                              \
-        const bool use_async = async && async->ready;                                                              \
-        const int hh = use_async ? async->next : 0;                                                                \
-        const int64_t part_bytes = use_async ? partial_bytes / 2 : partial_bytes;                                   \
-        float* part = partial ? partial + (use_async ? hh * (part_bytes / 4) : 0) : nullptr;                        \
-        const bool two_phase = part && splits > 1 && tn_atomic == 0 && (int64_t)grid * tile_f4 * 16 <= part_bytes;  \
-        a.partial = two_phase ? part : nullptr;                                                                    \
-        if (two_phase && use_async && async->pending[hh]) {  /* the reduce that last read this half must be done */ \
-            (void)hipStreamWaitEvent(st, async->red_done[hh], 0);                                                  \
-            async->pending[hh] = false;                                                                            \
-        }                                                                                                          \
+        const bool two_phase = partial && splits > 1 && tn_atomic == 0 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;  \
+        a.partial = two_phase ? partial : nullptr;                                                                 \
         if (tn_spread) {                                                                                           \
             static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, true>, lds), true);            \
             (void)once;                                                                                            \
@@ -1202,20 +1170,7 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
             (void)once;                                                                                            \
             k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, false><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);               \
         }                                                                                                          \
-        if (two_phase) {                                                                                           \
-            hipStream_t rs = st;                                                                                   \
-            if (use_async) {                                                                                       \
-                (void)hipEventRecord(async->tn_done[hh], st);                                                      \
-                (void)hipStreamWaitEvent(async->side, async->tn_done[hh], 0);                                      \
-                rs = async->side;                                                                                  \
-            }                                                                                                      \
-            k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, rs>>>(a, splits, WM_, WNK_, tm, TNT_);  \
-            if (use_async) {                                                                                       \
-                (void)hipEventRecord(async->red_done[hh], async->side);                                            \
-                async->pending[hh] = true;                                                                         \
-                async->next ^= 1;                                                                                  \
-            }                                                                                                      \
-        }                                                                                                          \
+        if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, WM_, WNK_, tm, TNT_); \
     } while (0)
     if (wide) {
         if (Q_lo) QV_TN_LAUNCH(2, 2, 2, 4, 6, 32);   // 2 x (16 + 48) KiB = 128 KiB

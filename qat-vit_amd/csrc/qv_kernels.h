@@ -53,20 +53,9 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
                       hipStream_t st, const NTPost* post = nullptr);
 // scratch that lets every wgrad shape take the two-phase (non-atomic, bit-reproducible) reduction: 256 workgroups x the largest tile
 constexpr int64_t kTnScratchBytes = 256ll * 128 * 384 * 4;
-// Optional: run the second phase (k_tn_reduce) on a side stream so the next GEMM does not wait for it.  The scratch is then used as two
-// halves in turn; events order (wgrad kernel -> its reduce) and (reduce -> the next wgrad kernel that reuses that half).
-struct TnAsync {
-    hipStream_t side;
-    hipEvent_t tn_done[2], red_done[2];
-    bool pending[2];
-    int next;
-    bool ready;
-};
-int tn_async_init(TnAsync* a);                      // creates the stream and the events once
-void tn_async_join(TnAsync* a, hipStream_t st);     // st waits for every outstanding reduction
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                    const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
-                   float* dbias, const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0, TnAsync* async = nullptr);
+                   float* dbias, const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st,
                        void* out8 = nullptr, int center = 0);

@@ -1,21 +1,25 @@
 """Host side of the native student step: binds a prepare_qat()-ed QATWrapper(ViT) to
 ``qatvit_student_forward`` / ``qatvit_student_backward`` (include/qatvit.h).
 
-torch is plumbing here: it owns the parameters, the fake-quant buffers (re-homed into two flat
-arenas so that the data-parallel buffer broadcast is one collective per dtype), the workspace and
-the streams.  All arithmetic of the step runs in libqatvit.so.
+torch is plumbing here: it owns the parameters, the fake-quant buffers (re-homed into one flat
+arena so that the data-parallel buffer broadcast is one collective), the workspace and the
+streams.  All arithmetic of the step runs in libqatvit.so.
 
 Call order mirrored from the reference loop (/root/reference/src/training/qat_trainer.py:337-361):
 ``out = model(images)`` -> loss -> ``loss.backward()``; with ``torch.distributed`` initialised and
 ``enable_data_parallel()`` called, backward issues the bucketed gradient all-reduce (RCCL) while
 earlier layers are still being differentiated, and forward starts with the rank-0 broadcast of the
 fake-quant state (what DDP does for the reference, torch/nn/parallel/distributed.py:1554-1559).
+
+The batch size is a run-time argument: the workspace is sized for the largest batch seen so far and a
+smaller batch (the last partial batch of an epoch, the evaluation loader - the reference's loaders have
+no ``drop_last``, qat_trainer.py:228-254) runs inside it without any allocation or collective.
 """
 from __future__ import annotations
 
 import ctypes
 import weakref
-from typing import List, Optional
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -23,6 +27,79 @@ from torch.ao.quantization.fake_quantize import FusedMovingAvgObsFakeQuantize
 
 from . import native
 
+STAGE_INJECT = 1  # QATVIT_STAGE_INJECT
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Data-parallel schedule: pure host logic (no native library, no GPU) so that the 2-rank gloo test on CPU drives exactly
+# the code the engine runs over RCCL.
+
+class FlatGradLayout:
+    """Where each parameter's gradient lives inside ONE flat fp32 buffer laid out in backward-stage order
+    (stage 0 = final norm + head, stages 1..depth = blocks depth-1..0, stage depth+1 = embedding), so that the
+    gradients finished by a prefix of the stages are a contiguous slice - the unit of the bucketed all-reduce.
+
+    ``numels``: parameter sizes in the C-ABI order of include/qatvit.h (4 embedding tensors, 12 per block, 4 tail)."""
+
+    ALIGN = 64  # elements: every tensor starts on a 256-byte boundary
+
+    def __init__(self, numels: Sequence[int], depth: int):
+        n_par = len(numels)
+        if n_par != 8 + 12 * depth:
+            raise ValueError(f"expected {8 + 12 * depth} parameters for depth {depth}, got {n_par}")
+        order = [n_par - 4 + k for k in range(4)]                       # stage 0: norm, head
+        for i in reversed(range(depth)):
+            order += [4 + 12 * i + k for k in range(12)]                # stages 1..depth
+        order += [0, 1, 2, 3]                                           # stage depth+1: embedding
+        stage_of_slot = [0] * 4 + sum(([s] * 12 for s in range(1, depth + 1)), []) + [depth + 1] * 4
+        self.order = order
+        self.offset: Dict[int, int] = {}
+        self.stage_end: List[int] = [0] * (depth + 2)
+        n = 0
+        for slot, pi in enumerate(order):
+            self.offset[pi] = n
+            n += (numels[pi] + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.stage_end[stage_of_slot[slot]] = n
+        self.numel = n
+        self.numels = list(numels)
+        self.last_stage = depth + 1
+
+    def views(self, flat: torch.Tensor, shapes: Sequence[torch.Size]) -> List[torch.Tensor]:
+        return [flat[self.offset[pi]:self.offset[pi] + self.numels[pi]].view(shapes[pi]) for pi in range(len(self.numels))]
+
+    def buckets(self, bucket_bytes: int) -> List[Tuple[int, int, int, int]]:
+        """[(stage_from, stage_to, elem_start, elem_end)]: a bucket closes once it holds >= bucket_bytes of gradients
+        (or at the last stage).  Multi-MB buckets: xGMI is point-to-point, a few large transfers keep every link busy."""
+        out, start, s0 = [], 0, 0
+        for s in range(self.last_stage + 1):
+            end = self.stage_end[s]
+            if (end - start) * 4 >= bucket_bytes or s == self.last_stage:
+                out.append((s0, s, start, end))
+                start, s0 = end, s + 1
+        return out
+
+
+def staged_backward_allreduce(flat: torch.Tensor, layout: FlatGradLayout, bucket_bytes: int, pg,
+                              run_stages: Callable[[int, int], None]) -> None:
+    """Run the backward stage by stage; as soon as a bucket's stages have been enqueued, start its all-reduce
+    (async: RCCL / gloo run it on their own stream / thread) and go on differentiating earlier layers.  Returns
+    with every slice averaged over the group (the caller's stream waits on the collectives).
+
+    Replaces the Reducer of ``DDP(prepared)`` (qat_trainer.py:311; bucketing of torch/nn/parallel/distributed.py:828-834)."""
+    world = dist.get_world_size(pg)
+    avg = dist.get_backend(pg) == "nccl"          # gloo has no AVG: sum, then divide
+    works = []
+    for s0, s1, a, b in layout.buckets(bucket_bytes):
+        run_stages(s0, s1)
+        seg = flat[a:b]
+        works.append((dist.all_reduce(seg, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=pg, async_op=True), seg))
+    for w, seg in works:
+        w.wait()
+        if not avg:
+            seg.div_(world)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 
 def _fq_of(mod, attr):
     fq = getattr(mod, attr, None)
@@ -32,6 +109,76 @@ def _fq_of(mod, attr):
             "fake-quant that get_default_qat_qconfig('qnnpack'|'x86'|'fbgemm') installs"
         )
     return fq
+
+
+def collect_student(wrapper: torch.nn.Module):
+    """(parameters, activation fake-quant modules, weight fake-quant modules) of a prepared QATWrapper(ViT), each in
+    the order include/qatvit.h documents.  Pure module-tree walking: works on any device."""
+    m = wrapper.model
+    blocks = list(m.blocks)
+    pe = m.patch_embed.proj
+    ps = [pe.weight, pe.bias, m.cls_token, m.pos_embed]
+    for b in blocks:
+        ps += [b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.qkv.bias, b.attn.proj.weight, b.attn.proj.bias,
+               b.norm2.weight, b.norm2.bias, b.mlp.fc1.weight, b.mlp.fc1.bias, b.mlp.fc2.weight, b.mlp.fc2.bias]
+    ps += [m.norm.weight, m.norm.bias, m.head.weight, m.head.bias]
+    act = [_fq_of(wrapper.quant, "activation_post_process"), _fq_of(pe, "activation_post_process")]
+    wfq = [_fq_of(pe, "weight_fake_quant")]
+    for b in blocks:
+        act += [_fq_of(x, "activation_post_process") for x in (b.norm1, b.attn.qkv, b.attn.proj, b.norm2, b.mlp.fc1, b.mlp.fc2)]
+        wfq += [_fq_of(x, "weight_fake_quant") for x in (b.attn.qkv, b.attn.proj, b.mlp.fc1, b.mlp.fc2)]
+    act += [_fq_of(m.norm, "activation_post_process"), _fq_of(m.head, "activation_post_process")]
+    wfq += [_fq_of(m.head, "weight_fake_quant")]
+    return ps, act, wfq
+
+
+def weight_param_indices(n_params: int) -> List[int]:
+    """Index (in the parameter order above) of the weight tensor behind each weight fake-quant module."""
+    depth = (n_params - 8) // 12
+    idx = [0]
+    for i in range(depth):
+        idx += [4 + 12 * i + 2, 4 + 12 * i + 4, 4 + 12 * i + 8, 4 + 12 * i + 10]
+    return idx + [n_params - 2]
+
+
+def rehome_fq_state(params, act_fq, w_fq, device):
+    """Move min/max/scale (fp32) and zero_point (int32) of all fake-quant modules into ONE flat byte arena; the module
+    buffers become views (state_dict() is unchanged), so the data-parallel state broadcast is a single collective.
+    Per-channel state gets its [C] shape here, as the fused op would do on its first call.
+    Returns (f32 view, i32 view, arena, total channels).  Replaces the per-buffer broadcast of DDP._sync_buffers
+    (torch/nn/parallel/distributed.py:2178-2221) for the reference's ``DDP(prepared)`` (qat_trainer.py:311)."""
+    sizes = []
+    for f, w in [(f, None) for f in act_fq] + list(zip(w_fq, [params[i] for i in weight_param_indices(len(params))])):
+        sizes.append(w.shape[0] if (w is not None and f.is_per_channel) else 1)
+    tot = sum(sizes)
+    arena = torch.empty(16 * tot, dtype=torch.uint8, device=device)
+    f32 = arena[:12 * tot].view(torch.float32)
+    i32 = arena[12 * tot:].view(torch.int32)
+    o = 0
+    for f, c in zip(list(act_fq) + list(w_fq), sizes):
+        obs = f.activation_post_process
+        per_ch = f.is_per_channel
+        mn, mx, sc, zp = f32[o:o + c], f32[tot + o:tot + o + c], f32[2 * tot + o:2 * tot + o + c], i32[o:o + c]
+        if obs.min_val.numel() == c:
+            mn.copy_(obs.min_val.reshape(-1)); mx.copy_(obs.max_val.reshape(-1))
+        else:
+            mn.fill_(float("inf")); mx.fill_(float("-inf"))
+        if f.scale.numel() == c:
+            sc.copy_(f.scale.reshape(-1)); zp.copy_(f.zero_point.reshape(-1))
+        else:
+            sc.fill_(1.0); zp.fill_(0)
+        obs._buffers["min_val"] = mn if per_ch else mn.view(())
+        obs._buffers["max_val"] = mx if per_ch else mx.view(())
+        f._buffers["scale"] = sc
+        f._buffers["zero_point"] = zp
+        o += c
+    return f32, i32, arena, tot
+
+
+@torch.no_grad()
+def broadcast_fq_state(arena: torch.Tensor, pg) -> None:
+    """Rank 0's fake-quant state becomes every rank's: ONE collective for all 126 modules."""
+    dist.broadcast(arena, src=0, group=pg)
 
 
 class StudentEngine:
@@ -46,24 +193,11 @@ class StudentEngine:
         self.lib = native.lib()
         blocks = list(m.blocks)
         pe = m.patch_embed.proj
-        # ---- parameters, in the order include/qatvit.h documents
-        ps = [pe.weight, pe.bias, m.cls_token, m.pos_embed]
-        for b in blocks:
-            ps += [b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.qkv.bias, b.attn.proj.weight, b.attn.proj.bias,
-                   b.norm2.weight, b.norm2.bias, b.mlp.fc1.weight, b.mlp.fc1.bias, b.mlp.fc2.weight, b.mlp.fc2.bias]
-        ps += [m.norm.weight, m.norm.bias, m.head.weight, m.head.bias]
+        ps, act, wfq = collect_student(wrapper)
         for p in ps:
             if p is None or p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("every student parameter must be a contiguous fp32 tensor (bias=True everywhere)")
         self.params: List[torch.nn.Parameter] = ps
-        # ---- fake-quant modules
-        act = [_fq_of(wrapper.quant, "activation_post_process"), _fq_of(pe, "activation_post_process")]
-        wfq = [_fq_of(pe, "weight_fake_quant")]
-        for b in blocks:
-            act += [_fq_of(x, "activation_post_process") for x in (b.norm1, b.attn.qkv, b.attn.proj, b.norm2, b.mlp.fc1, b.mlp.fc2)]
-            wfq += [_fq_of(x, "weight_fake_quant") for x in (b.attn.qkv, b.attn.proj, b.mlp.fc1, b.mlp.fc2)]
-        act += [_fq_of(m.norm, "activation_post_process"), _fq_of(m.head, "activation_post_process")]
-        wfq += [_fq_of(m.head, "weight_fake_quant")]
         self.act_fq, self.w_fq = act, wfq
         a0, w0 = act[0], wfq[0]
         for f in act:
@@ -79,83 +213,61 @@ class StudentEngine:
         if not bool((flags == 1).all().item()):  # one-time host read
             raise RuntimeError("the native step needs fake_quant_enabled = 1 on every fake-quant module")
         hd = blocks[0].attn.head_dim
-        self.cfg = native.Cfg(
-            batch=batch, img_size=m.patch_embed.img_size, patch_size=m.patch_embed.patch_size, in_chans=pe.weight.shape[1],
+        self._cfg_kw = dict(
+            img_size=m.patch_embed.img_size, patch_size=m.patch_embed.patch_size, in_chans=pe.weight.shape[1],
             embed_dim=m.embed_dim, depth=len(blocks), num_heads=blocks[0].attn.num_heads, mlp_hidden=blocks[0].mlp.fc1.weight.shape[0],
             num_classes=m.head.weight.shape[0], act_qmin=a0.activation_post_process.quant_min, act_qmax=a0.activation_post_process.quant_max,
             w_qmin=w0.activation_post_process.quant_min, w_qmax=w0.activation_post_process.quant_max, w_per_channel=int(w0.is_per_channel),
             averaging_const=float(a0.activation_post_process.averaging_constant), ln_eps=float(blocks[0].norm1.eps),
         )
+        self._cfgs: Dict[int, native.Cfg] = {}
+        self.cfg = self.cfg_for(batch)           # the configuration of the most recent forward (tests read .cfg of the last step)
         if hd * self.cfg.num_heads != self.cfg.embed_dim:
             raise RuntimeError("embed_dim must equal num_heads * head_dim")
         L, cp = self.lib, ctypes.byref(self.cfg)
         assert L.qatvit_student_num_params(cp) == len(ps) and L.qatvit_student_num_act_fq(cp) == len(act) and L.qatvit_student_num_weight_fq(cp) == len(wfq)
         self._rehome_fq_state()
-        nbytes = L.qatvit_student_workspace_bytes(cp)
-        if nbytes <= 0:
-            raise RuntimeError("qatvit_student_workspace_bytes: " + L.qatvit_last_error().decode())
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        native.check(L.qatvit_student_init(cp, self.workspace.data_ptr(), native.stream_ptr()), "qatvit_student_init")
+        self.capacity = 0
+        self.workspace: Optional[torch.Tensor] = None
+        self.frozen = False                      # set by a captured hipGraph: the workspace address must not change under it
+        self._reserve(batch)
         # ---- flat gradient buffer, laid out in backward-stage order so that finished buckets are contiguous
-        depth = self.cfg.depth
-        order = [len(ps) - 4 + k for k in range(4)]                      # stage 0: norm, head
-        for i in reversed(range(depth)):
-            order += [4 + 12 * i + k for k in range(12)]                 # stages 1..depth
-        order += [0, 1, 2, 3]                                            # stage depth+1: embedding
-        self.stage_of_slot = [0] * 4 + sum(([s] * 12 for s in range(1, depth + 1)), []) + [depth + 1] * 4
-        offs, n = {}, 0
-        for slot, pi in enumerate(order):
-            offs[pi] = n
-            n += (ps[pi].numel() + 63) // 64 * 64
-        self.grad_numel = n
-        self.grad_offset = offs
-        self.order = order
+        self.layout = FlatGradLayout([p.numel() for p in ps], self.cfg.depth)
+        self.grad_numel = self.layout.numel
         self._ptr_params = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
         self._param_ptrs_key = tuple(p.data_ptr() for p in ps)
         self.pg = None
         self.sync_state = True      # set per call by student_forward: grad mode of the caller (False under no_grad)
         self.bucket_bytes = 16 << 20
+        self.generation = 0         # bumped by every forward: the workspace holds the activations of exactly one forward
         self._build_fq_structs()
 
-    # ------------------------------------------------------------------ FQ state arenas
-    def _rehome_fq_state(self):
-        """Move min/max/scale (fp32) and zero_point (int32) of all 126 modules into two flat tensors; the module
-        buffers become views (state_dict() is unchanged).  Per-channel state gets its [C] shape here, as the fused
-        op would do on its first call."""
-        dev = self.device
-        sizes = []
-        for f, w in [(f, None) for f in self.act_fq] + list(zip(self.w_fq, [self.params[i] for i in self._weight_param_indices()])):
-            sizes.append(w.shape[0] if (w is not None and f.is_per_channel) else 1)
-        tot = sum(sizes)
-        arena = torch.empty(16 * tot, dtype=torch.uint8, device=dev)     # one buffer: a single broadcast carries the whole state
-        f32 = arena[:12 * tot].view(torch.float32)
-        i32 = arena[12 * tot:].view(torch.int32)
-        o = 0
-        for f, c in zip(self.act_fq + self.w_fq, sizes):
-            obs = f.activation_post_process
-            per_ch = f.is_per_channel
-            mn, mx, sc, zp = f32[o:o + c], f32[tot + o:tot + o + c], f32[2 * tot + o:2 * tot + o + c], i32[o:o + c]
-            if obs.min_val.numel() == c:
-                mn.copy_(obs.min_val.reshape(-1)); mx.copy_(obs.max_val.reshape(-1))
-            else:
-                mn.fill_(float("inf")); mx.fill_(float("-inf"))
-            if f.scale.numel() == c:
-                sc.copy_(f.scale.reshape(-1)); zp.copy_(f.zero_point.reshape(-1))
-            else:
-                sc.fill_(1.0); zp.fill_(0)
-            obs._buffers["min_val"] = mn if per_ch else mn.view(())
-            obs._buffers["max_val"] = mx if per_ch else mx.view(())
-            f._buffers["scale"] = sc
-            f._buffers["zero_point"] = zp
-            o += c
-        self.fq_f32, self.fq_i32, self.fq_arena = f32, i32, arena
+    # ------------------------------------------------------------------ configuration / workspace
+    def cfg_for(self, batch: int) -> native.Cfg:
+        c = self._cfgs.get(batch)
+        if c is None:
+            c = self._cfgs[batch] = native.Cfg(batch=batch, **self._cfg_kw)
+        return c
 
-    def _weight_param_indices(self):
-        depth = (len(self.params) - 8) // 12
-        idx = [0]
-        for i in range(depth):
-            idx += [4 + 12 * i + 2, 4 + 12 * i + 4, 4 + 12 * i + 8, 4 + 12 * i + 10]
-        return idx + [len(self.params) - 2]
+    def _reserve(self, batch: int) -> None:
+        """Make the workspace large enough for `batch` images.  Offsets inside it depend on the batch of the call, the
+        observer accumulators at its start do not, so a smaller batch simply runs in the front part of the same buffer."""
+        if batch <= self.capacity:
+            return
+        if self.frozen:
+            raise RuntimeError(f"batch {batch} exceeds the workspace ({self.capacity}) a captured hipGraph is bound to")
+        L, cp = self.lib, ctypes.byref(self.cfg_for(batch))
+        nbytes = L.qatvit_student_workspace_bytes(cp)
+        if nbytes <= 0:
+            raise RuntimeError("qatvit_student_workspace_bytes: " + L.qatvit_last_error().decode())
+        self.workspace = None                    # release the smaller one first
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        native.check(L.qatvit_student_init(cp, self.workspace.data_ptr(), native.stream_ptr()), "qatvit_student_init")
+        self.capacity = batch
+
+    # ------------------------------------------------------------------ FQ state arena
+    def _rehome_fq_state(self):
+        self.fq_f32, self.fq_i32, self.fq_arena, self.fq_total = rehome_fq_state(self.params, self.act_fq, self.w_fq, self.device)
 
     def _build_fq_structs(self):
         def arr(fqs):
@@ -176,68 +288,90 @@ class StudentEngine:
         for p in self.params:  # replicas start identical (DDP's constructor broadcast)
             dist.broadcast(p.data, src=0, group=self.pg)
 
-    @torch.no_grad()
     def _broadcast_fq_state(self):
-        dist.broadcast(self.fq_arena, src=0, group=self.pg)
+        broadcast_fq_state(self.fq_arena, self.pg)
 
     # ------------------------------------------------------------------ step
     def _check_ptrs(self):
         if tuple(p.data_ptr() for p in self.params) != self._param_ptrs_key:
             raise RuntimeError("student parameters were re-allocated after the native engine was built (e.g. .to()); rebuild the wrapper")
 
-    def forward(self, images: torch.Tensor) -> torch.Tensor:
-        c = self.cfg
-        if images.shape != (c.batch, c.in_chans, c.img_size, c.img_size) or images.dtype != torch.float32:
-            raise RuntimeError(f"expected fp32 images of shape {(c.batch, c.in_chans, c.img_size, c.img_size)}, got {tuple(images.shape)} {images.dtype}")
+    def _check_images(self, images: torch.Tensor) -> native.Cfg:
+        c0 = self.cfg
+        if images.dim() != 4 or images.shape[0] < 1 or tuple(images.shape[1:]) != (c0.in_chans, c0.img_size, c0.img_size) or images.dtype != torch.float32:
+            raise RuntimeError(f"expected fp32 images of shape (B, {c0.in_chans}, {c0.img_size}, {c0.img_size}), got {tuple(images.shape)} {images.dtype}")
         self._check_ptrs()
+        self._reserve(images.shape[0])
+        return self.cfg_for(images.shape[0])
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        c = self._check_images(images)
+        self.cfg = c
         # Rank 0's fake-quant state is authoritative at the start of every TRAINING forward (what DDP's buffer broadcast does
         # for the reference).  A forward under no_grad - the reference's evaluate_fp32 runs on rank 0 only
-        # (qat_trainer.py:370-371) - issues no collective, so a one-rank evaluation cannot dead-lock the group.
+        # (qat_trainer.py:370-371) - issues no collective, whatever its batch size, so a one-rank evaluation cannot dead-lock the group.
         if self.pg is not None and self.sync_state:
             self._broadcast_fq_state()
         images = images.contiguous()
         logits = torch.empty(c.batch, c.num_classes, dtype=torch.float32, device=self.device)
+        self.generation += 1
         native.check(self.lib.qatvit_student_forward(ctypes.byref(c), self._ptr_params, self._act_structs, self._w_structs, images.data_ptr(),
                                                      logits.data_ptr(), self.workspace.data_ptr(), native.stream_ptr()), "qatvit_student_forward")
         return logits
 
-    def backward(self, dlogits: torch.Tensor):
-        c = self.cfg
-        dlogits = dlogits.contiguous()
+    def _grad_buffers(self):
         flat = torch.zeros(self.grad_numel, dtype=torch.float32, device=self.device)
-        views = [None] * len(self.params)
-        for pi, p in enumerate(self.params):
-            o = self.grad_offset[pi]
-            views[pi] = flat[o:o + p.numel()].view_as(p)
+        views = self.layout.views(flat, [p.shape for p in self.params])
         gptr = (ctypes.c_void_p * len(views))(*[v.data_ptr() for v in views])
+        return flat, views, gptr
+
+    def backward(self, dlogits: torch.Tensor, cfg: Optional[native.Cfg] = None):
+        c = cfg if cfg is not None else self.cfg
+        dlogits = dlogits.contiguous()
+        flat, views, gptr = self._grad_buffers()
         L, cp, st = self.lib, ctypes.byref(c), native.stream_ptr()
 
         def run(s0, s1):
             native.check(L.qatvit_student_backward(cp, self._ptr_params, self._act_structs, self._w_structs, dlogits.data_ptr(), gptr,
                                                    self.workspace.data_ptr(), s0, s1, st), "qatvit_student_backward")
 
-        last = c.depth + 1
         if self.pg is None:
-            run(0, last)
-            return views
-        # bucketed all-reduce overlapped with the remaining stages: stage boundaries are contiguous in `flat`
-        world = dist.get_world_size(self.pg)
-        avg = dist.get_backend(self.pg) == "nccl"
-        works, start, s0 = [], 0, 0
-        stage_end = {}
-        for slot, pi in enumerate(self.order):
-            stage_end[self.stage_of_slot[slot]] = self.grad_offset[pi] + (self.params[pi].numel() + 63) // 64 * 64
-        for s in range(last + 1):
-            end = stage_end[s]
-            if (end - start) * 4 >= self.bucket_bytes or s == last:
-                run(s0, s)
-                seg = flat[start:end]
-                works.append((dist.all_reduce(seg, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.pg, async_op=True), seg))
-                start, s0 = end, s + 1
-        for w, seg in works:
-            w.wait()
-            if not avg:
-                seg.div_(world)
+            run(0, self.layout.last_stage)
+        else:
+            staged_backward_allreduce(flat, self.layout, self.bucket_bytes, self.pg, run)
+        return views
+
+    # ------------------------------------------------------------------ stage-level access (parity tests, include/qatvit.h "stages")
+    def tensor(self, name: str, block: int, shape, dtype=torch.float32, cfg: Optional[native.Cfg] = None) -> torch.Tensor:
+        """View of a named intermediate tensor inside the workspace (layout of the given / most recent batch size)."""
+        c = cfg if cfg is not None else self.cfg
+        off = self.lib.qatvit_student_tensor_offset(ctypes.byref(c), name.encode(), block)
+        if off < 0:
+            raise KeyError(name)
+        n = 1
+        for s in shape:
+            n *= s
+        return self.workspace[off:off + n * torch.empty((), dtype=dtype).element_size()].view(dtype).view(*shape)
+
+    def forward_stages(self, images: Optional[torch.Tensor], stage_from: int, stage_to: int, inject: bool = False,
+                       logits: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        c = self.cfg
+        if stage_to == c.depth + 1 and logits is None:
+            logits = torch.empty(c.batch, c.num_classes, dtype=torch.float32, device=self.device)
+        self.generation += 1
+        native.check(self.lib.qatvit_student_forward_stages(
+            ctypes.byref(c), self._ptr_params, self._act_structs, self._w_structs, images.data_ptr() if images is not None else None,
+            logits.data_ptr() if logits is not None else None, self.workspace.data_ptr(), stage_from, stage_to, STAGE_INJECT if inject else 0,
+            native.stream_ptr()), "qatvit_student_forward_stages")
+        return logits
+
+    def backward_stages(self, dlogits: Optional[torch.Tensor], stage_from: int, stage_to: int, inject: bool = False):
+        """Returns per-parameter gradient views (zero for the stages that did not run)."""
+        c = self.cfg
+        flat, views, gptr = self._grad_buffers()
+        native.check(self.lib.qatvit_student_backward_stages(
+            ctypes.byref(c), self._ptr_params, self._act_structs, self._w_structs, dlogits.contiguous().data_ptr() if dlogits is not None else None,
+            gptr, self.workspace.data_ptr(), stage_from, stage_to, STAGE_INJECT if inject else 0, native.stream_ptr()), "qatvit_student_backward_stages")
         return views
 
 
@@ -245,15 +379,29 @@ class _StudentStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, engine, *params):
         ctx.engine = engine
-        return engine.forward(images)
+        out = engine.forward(images)
+        ctx.generation = engine.generation
+        ctx.step_cfg = engine.cfg
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
         # The native backward writes every parameter gradient into one flat buffer; hand the views to the parameters
         # directly (what `zero_grad(set_to_none=True)` + autograd would end up with) instead of returning them, so
-        # autograd's AccumulateGrad does not clone 152 tensors per step.
+        # autograd's AccumulateGrad does not clone 152 tensors per step.  Stock ``DDP(prepared)`` keeps working on top of
+        # this because DDP's reducer is driven by post-accumulate-grad hooks that fire when ``.grad`` is assigned here
+        # (tests/test_gpu_dp.py); the native bucketed path (``enable_data_parallel``) is the one bench.py measures.
         eng = ctx.engine
-        grads = eng.backward(dlogits)
+        if eng.generation != ctx.generation:
+            # The activations, STE masks and qparams of a step live in the engine's one workspace, not in autograd's graph:
+            # a later forward (an evaluation under no_grad, a second micro-batch) has overwritten them.  Stock autograd
+            # would keep both alive; here the second backward would silently differentiate the wrong step - refuse.
+            raise RuntimeError(
+                "qat-vit_amd: another forward of this model ran between this forward and its backward; the native step keeps the "
+                "saved activations of ONE forward per model. Call backward() before the next forward (gradient accumulation: "
+                "forward/backward per micro-batch)."
+            )
+        grads = eng.backward(dlogits, ctx.step_cfg)
         for p, g in zip(eng.params, grads):
             if p.grad is None:
                 p.grad = g
@@ -271,13 +419,15 @@ def engine_of(wrapper) -> Optional["StudentEngine"]:
     return _ENGINES.get(wrapper)
 
 
+def bind(wrapper, batch: int) -> "StudentEngine":
+    """Create (or return) the engine of a prepared wrapper without running a step."""
+    eng = _ENGINES.get(wrapper)
+    if eng is None:
+        eng = _ENGINES[wrapper] = StudentEngine(wrapper, batch)
+    return eng
+
+
 def student_forward(wrapper, images: torch.Tensor) -> torch.Tensor:
-    eng: Optional[StudentEngine] = _ENGINES.get(wrapper)
-    if eng is None or eng.cfg.batch != images.shape[0]:
-        pg = eng.pg if eng is not None else None
-        eng = StudentEngine(wrapper, images.shape[0])
-        if pg is not None:
-            eng.enable_data_parallel(pg)
-        _ENGINES[wrapper] = eng
+    eng = bind(wrapper, images.shape[0])
     eng.sync_state = torch.is_grad_enabled()   # read here: inside autograd.Function.forward grad mode is always off
     return _StudentStep.apply(images, eng, *eng.params)

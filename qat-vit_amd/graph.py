@@ -35,6 +35,10 @@ class GraphedStudentStep:
         eng = engine_of(model)
         if eng is None or eng.pg is not None:
             raise RuntimeError("GraphedStudentStep: needs a prepared single-GPU student (no data-parallel group)")
+        # the graph records raw addresses of the engine's workspace and fake-quant arena: keep the engine alive and pin its workspace
+        # (a later, larger batch would otherwise re-allocate it under the graph)
+        self.engine = eng
+        eng.frozen = True
         for p in model.parameters():
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
@@ -53,6 +57,10 @@ class GraphedStudentStep:
     @torch.no_grad()
     def __call__(self, images: torch.Tensor, labels: torch.Tensor, teacher_out: Optional[torch.Tensor] = None):
         """Copies the batch into the captured buffers and replays; returns (logits, loss, parts) - tensors owned by the graph."""
+        if engine_of(self.model) is not self.engine:
+            raise RuntimeError("GraphedStudentStep: the model was re-bound to another native engine after capture; capture again")
+        if images.shape != self.x.shape:
+            raise RuntimeError(f"GraphedStudentStep was captured for batch shape {tuple(self.x.shape)}, got {tuple(images.shape)}")
         self.x.copy_(images)
         self.y.copy_(labels)
         if self.t is not None:

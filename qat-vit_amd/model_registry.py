@@ -12,8 +12,8 @@ Out of scope here: Jetson detection, the OWL-ViT detecti
 entries and ``get_model_complexity``'s constants.  ``PLATFORM`` is the constant "mi355x".
 
 The difference that matters: once ``prepare_qat`` has run on the wrapper and the input is
-a CUDA(HIP) tensor, ``QATWrapper.forward`` executes in libqatvit.so.  CPU tensors are
-refused - there is no CPU fallback in this package.
+a CUDA(HIP) tensor, ``QATWrapper.forward`` executes in libqatvit.so.  A prepared (QAT) wrapper refuses
+CPU tensors - there is no CPU fallback for the hot path; the float tree before ``prepare_qat`` is plain ``nn.Module`` code.
 """
 from __future__ import annotations
 
@@ -47,11 +47,12 @@ class QATWrapper(nn.Module):
     def forward(self, x: torch.Tensor, **kwargs):
         if self.task != "classification":
             raise ValueError("only the classification task is on the MI355X QAT path")
-        if not x.is_cuda:
-            raise RuntimeError("qat-vit_amd executes on MI355X only; got a CPU tensor (no CPU fallback exists)")
-        if hasattr(self.quant, "activation_post_process"):  # prepare_qat() has run: native step
+        if hasattr(self.quant, "activation_post_process"):  # prepare_qat() has run: native step, MI355X only
+            if not x.is_cuda:
+                raise RuntimeError("qat-vit_amd executes the QAT student on MI355X only; got a CPU tensor (no CPU fallback exists)")
             return self.dequant(engine.student_forward(self, x))
-        # float (pre-QAT) model: stubs are identities (torch/ao/quantization/stubs.py:25-26,43-44)
+        # float (pre-QAT) or convert()-ed tree: the stubs are identities / stock quantized modules
+        # (torch/ao/quantization/stubs.py:25-26,43-44); ordinary nn.Module code on whatever device the tree lives on
         return self.dequant(self.model(self.quant(x)))
 
     def fuse_model(self) -> None:

@@ -43,11 +43,13 @@ SIGNATURES = {
     "qatvit_student_init": (c_int, [c_void_p, c_void_p, c_void_p]),
     "qatvit_student_forward": (c_int, [c_void_p] * 8),
     "qatvit_student_backward": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_void_p]),
+    "qatvit_student_forward_stages": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
+    "qatvit_student_backward_stages": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
     "qatvit_student_tensor_offset": (c_int64, [c_void_p, c_char_p, c_int32]),
     "qatvit_teacher_workspace_bytes": (c_int64, [c_void_p]),
     "qatvit_teacher_forward": (c_int, [c_void_p] * 8),
-    "qatvit_profile_start": (c_int, [c_int32, c_int32]),
-    "qatvit_profile_stop": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "qatvit_profile_start": (c_int, [c_void_p, c_int32, c_int32]),
+    "qatvit_profile_stop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 
@@ -85,7 +87,7 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library drift
             fn.restype, fn.argtypes = res, args
-        if L.qatvit_abi_version() != 1:
+        if L.qatvit_abi_version() != 2:
             raise RuntimeError("libqatvit.so ABI version mismatch")
         _lib = L
     return _lib

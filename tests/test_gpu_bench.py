@@ -28,3 +28,24 @@ def test_bench_json_contract(native_lib):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and 0 < rf["frac"] < 1
     assert d["value"] > 0 and abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_workers(native_lib):
+    """`bench.py --gpus 2` started directly (no torchrun, no WORLD_SIZE): the parent spawns both ranks before touching the GPU and relays
+    rank 0's line.  Rehearsal on ONE GPU: both ranks on device 0, gloo transport (RCCL refuses two ranks per device)."""
+    env = dict(os.environ, BENCH_ONE_DEVICE="1", BENCH_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                        "--no-cpu-baseline", "--no-kernel-rates", "--no-extras"], capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 16 * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    # a failing worker makes the launcher fail (the driver must not read a half result as success)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8",
+                          "--backend", "no_such_backend", "--no-cpu-baseline", "--no-kernel-rates", "--no-extras"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=env)
+    assert bad.returncode != 0

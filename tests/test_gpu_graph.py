@@ -23,10 +23,14 @@ def test_graphed_step_matches_eager(native_lib):
     g = torch.Generator().manual_seed(1)
     xs = [torch.randn(4, 3, 32, 32, generator=g).cuda() * (1 + i) for i in range(3)]
     ys = [torch.randint(0, 10, (4,), generator=g).cuda() for _ in range(3)]
-    step = GraphedStudentStep(b, xs[0], ys[0], warmup=1)
-    # the capture (warm-up + captured run) observed xs[0] twice on `b`; bring `a` to the same state eagerly
-    for _ in range(2):
-        F.kd_ce_loss(a(xs[0]), None, ys[0], 4.0, 0.5, 0.1)[0].backward()
+    w0 = torch.randn(4, 3, 32, 32, generator=g).cuda() * 5                  # warm-up data differs from every replayed batch
+    step = GraphedStudentStep(b, w0, ys[0], warmup=1)
+    # stream capture records kernels without executing them: `b` has observed w0 exactly once (the eager warm-up).  Bring `a` to the
+    # same state eagerly; an observation missed or added by capture / replay then shows up in the buffer comparison below, because
+    # every later batch has a different range (an EMA over identical data would hide it).
+    F.kd_ce_loss(a(w0), None, ys[0], 4.0, 0.5, 0.1)[0].backward()
+    for (n, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(u, v), n
     for x, y in zip(xs, ys):
         for p in a.parameters():
             p.grad = None
@@ -39,3 +43,13 @@ def test_graphed_step_matches_eager(native_lib):
             assert q.grad is not None and rel_l2(q.grad.cpu(), p.grad.cpu()) < 1e-6, n
         for (n, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
             assert torch.equal(u, v), n                         # fake-quant state advanced identically
+    # an evaluation forward at another (smaller) batch between replays runs in the same workspace and must not disturb the graph
+    with torch.no_grad():
+        a(xs[0][:2]); b(xs[0][:2])
+    out_b, _, _ = step(xs[1], ys[1])
+    for p in a.parameters():
+        p.grad = None
+    out_a = a(xs[1])
+    assert torch.equal(out_a, out_b)
+    with pytest.raises(RuntimeError, match="exceeds the workspace"):
+        b(torch.cat([xs[0], xs[1]]))                                     # growing would re-allocate under the captured graph

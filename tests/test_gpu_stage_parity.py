@@ -1,0 +1,264 @@
+"""Teacher-forced, stage-level parity of the native QAT student step at FULL model size (ViT-S, batch 8: BASELINE config C1
+shapes with the qnnpack qconfig, config C3 semantics with x86).
+
+The whole-network comparison cannot be tighter than the fp32 noise floor (fake-quant is discontinuous and the 76 activation
+quantizers compound one-step flips: tests/test_gpu_step.py).  Here every stage is run on the ORACLE's input instead: the oracle
+(oracle/step_ref.py: the reference's wrapper / QAT enable / loss over stock torch.ao, CPU) records the tensor entering every stage in
+both directions; each native stage - embedding, every transformer block, final norm + head, and the same for the backward - is then
+executed alone through ``qatvit_student_forward_stages`` / ``qatvit_student_backward_stages`` with QATVIT_STAGE_INJECT
+(include/qatvit.h) on that recorded input, so no upstream drift enters and every kernel that runs in the real step (NT epilogue
+variants 0 / 3 / 4 / 5, int8 and split-A GEMMs, k_resid_fq_lnstats, k_ln_apply_quant, attention fwd / bwd, k_ln_bwd_fq with its fused
+mask output, TN weight gradients, k_embed_bwd, k_head_fwd / bwd) is compared tensor by tensor:
+
+  (a) integer codes of every activation quantizer: fewer than 1e-4 of the elements differ, by at most one step;
+  (b) relative L2 <= 1e-3 on every pre-fake-quant tensor, every float GEMM operand, the residual stream, the residual-stream
+      gradient and every parameter gradient of the stage.
+
+Reference call sites: forward ``ddp_model(images)`` qat_trainer.py:341, loss :343-349, ``loss.backward()`` :359.
+A per-quantizer table is written to gpurun_out/ (committed copy: profiles/round2_stage_flip_table_*.txt)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import qat_vit_amd  # noqa: E402
+from oracle import step_ref  # noqa: E402
+from qat_vit_amd import engine as E  # noqa: E402
+from tests.util import capture_fq_io, fq_modules, prepare, rel_l2  # noqa: E402
+
+CODE_FLIP_FRAC = 1e-4
+TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleTrace:
+    """One oracle step with everything a stage needs recorded: inputs of every stage (forward and backward), the float GEMM operands
+    between the quantizers, every activation quantizer's (input, output), every parameter gradient."""
+
+    def __init__(self, po, x, y, t):
+        m = po.model
+        self.block_in, self.g_block_in = {}, {}
+        self.proj_in, self.fc2_in, self.norm2_in = {}, {}, {}
+        depth = len(m.blocks)
+        self.depth = depth
+
+        def keep_grad(store, key):
+            def h(g):
+                store[key] = g.detach().clone()
+            return h
+
+        def pre_block(i):
+            def h(mod, inp):
+                self.block_in[i] = inp[0].detach().clone()
+                inp[0].register_hook(keep_grad(self.g_block_in, i))
+            return h
+
+        hs = [b.register_forward_pre_hook(pre_block(i)) for i, b in enumerate(m.blocks)]
+        hs.append(m.norm.register_forward_pre_hook(pre_block(depth)))
+        for i, b in enumerate(m.blocks):
+            hs.append(b.attn.proj.register_forward_pre_hook(lambda mod, inp, i=i: self.proj_in.__setitem__(i, inp[0].detach().clone())))
+            hs.append(b.mlp.fc2.register_forward_pre_hook(lambda mod, inp, i=i: self.fc2_in.__setitem__(i, inp[0].detach().clone())))
+            hs.append(b.norm2.register_forward_pre_hook(lambda mod, inp, i=i: self.norm2_in.__setitem__(i, inp[0].detach().clone())))
+        self.fq_io = capture_fq_io(po)
+        for q in po.parameters():
+            q.grad = None
+        out = po(x)
+        self.g_logits = {}
+        out.register_hook(keep_grad(self.g_logits, 0))
+        if t is None:
+            loss = torch.nn.CrossEntropyLoss(label_smoothing=0.1)(out, y)
+        else:
+            loss, _, _ = step_ref.kd_ce_loss(out, t, y, 4.0, 0.5, 0.1)
+        loss.backward()
+        self.logits = out.detach()
+        self.grads = {n: q.grad.detach().clone() for n, q in po.named_parameters()}
+        self.fq = fq_modules(po)
+        for h in hs:
+            h.remove()
+
+    def codes(self, name):
+        """q - zero_point of an activation quantizer's output (integers in fp32)."""
+        f = self.fq[name]
+        return torch.round(self.fq_io[name][1] / f.scale)
+
+    def pre(self, name):
+        return self.fq_io[name][0]
+
+
+class Table:
+    def __init__(self):
+        self.rows = []
+
+    def codes(self, stage, name, ours, ref):
+        ours, ref = ours.float().cpu().reshape(-1), ref.float().cpu().reshape(-1)
+        d = (ours - ref).abs()
+        frac, mx = (d != 0).float().mean().item(), d.max().item()
+        self.rows.append((stage, name, "codes", ours.numel(), frac, mx))
+        assert frac < CODE_FLIP_FRAC and mx <= 1, (stage, name, frac, mx)
+
+    def close(self, stage, name, ours, ref, tol=TOL):
+        e = rel_l2(ours.detach().float().cpu().numpy(), ref.detach().float().cpu().numpy())
+        self.rows.append((stage, name, "rel_l2", int(np.prod(ref.shape)), e, 0.0))
+        assert e <= tol, (stage, name, e)
+
+    def write(self, path, header):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(header + "\n")
+            f.write(f"{'stage':<14}{'tensor':<34}{'kind':<8}{'elements':>12}{'differing frac / rel L2':>26}{'max |code diff|':>17}\n")
+            for st, n, k, ne, v, mx in self.rows:
+                f.write(f"{st:<14}{n:<34}{k:<8}{ne:>12}{v:>26.3e}{(int(mx) if k == 'codes' else ''):>17}\n")
+            cf = [r for r in self.rows if r[2] == "codes"]
+            tot = sum(r[3] for r in cf)
+            f.write(f"\nall activation quantizers: {sum(r[3] * r[4] for r in cf):.0f} differing codes of {tot} ({sum(r[3] * r[4] for r in cf) / tot:.2e}), "
+                    f"max |diff| {int(max(r[5] for r in cf))}; worst rel L2 {max(r[4] for r in self.rows if r[2] == 'rel_l2'):.2e}\n")
+
+
+def _fq_of_codes(pre, fqmod, qmin, qmax):
+    """q - zp codes our consumer kernels produce from a pre-FQ tensor and the module's (scale, zero_point): x * (1/s), rint, + zp, clamp."""
+    inv = (1.0 / fqmod.scale.float()).to(pre.device)
+    zp = fqmod.zero_point.float().to(pre.device)
+    return torch.clamp(torch.round(pre * inv) + zp, qmin, qmax) - zp
+
+
+def _run(backend, seed, teacher, golden_tag):
+    B, T = 8, 197
+    w = step_ref.build_student("vit_small_patch16_224", seed=seed)
+    po = step_ref.enable_qat(w, backend)
+    stu = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True)
+    stu.load_state_dict(w.state_dict())
+    p = prepare(stu.cuda(), backend)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
+    t = torch.randn(B, 10, generator=g) * 2 if teacher else None
+    tr = OracleTrace(po, x, y, t)
+    depth, D = tr.depth, p.model.embed_dim
+    M = B * T
+    eng = E.bind(p, B)
+    c = eng.cfg
+    qa, qb = c.act_qmin, c.act_qmax
+    n_act = len(eng.act_fq)
+    tot = eng.fq_total
+    fresh = eng.fq_arena.clone()
+
+    def reset_act_observers(idxs):
+        """The given activation quantizers (C-ABI act_fq order: quant, patch_embed, 6 per block, norm, head) back to 'never observed',
+        so that the stage's one observation equals the oracle's first step.  (Weights keep theirs: an identical weight is an EMA fixed point.)"""
+        f32, i32 = eng.fq_arena[:12 * tot].view(torch.float32), eng.fq_arena[12 * tot:].view(torch.int32)
+        f0, i0 = fresh[:12 * tot].view(torch.float32), fresh[12 * tot:].view(torch.int32)
+        ix = torch.tensor(list(idxs), device=eng.device)
+        for k in range(3):
+            f32[k * tot:k * tot + n_act][ix] = f0[k * tot:k * tot + n_act][ix]
+        i32[:n_act][ix] = i0[:n_act][ix]
+
+    # one ordinary step first: engine, weights and every buffer exist; nothing of it is compared here
+    xc, yc = x.cuda(), y.cuda()
+    from qat_vit_amd import functional as F
+    out = p(xc)
+    F.kd_ce_loss(out, None if t is None else t.cuda(), yc, 4.0, 0.5, 0.1)[0].backward()
+    fqm = fq_modules(p)
+    tab = Table()
+    A = "activation_post_process"
+
+    # ================================================================= forward, stage by stage
+    reset_act_observers([0, 1])
+    eng.forward_stages(xc, 0, 0)
+    np_ = T - 1
+    ref_img = tr.codes(f"quant.{A}").reshape(B, 3, 14, 16, 14, 16).permute(0, 2, 4, 1, 3, 5).reshape(B * np_, 768)
+    tab.codes("embed", "quant (input image)", eng.tensor("imgq", 0, (B * np_, 768), torch.bfloat16), ref_img)
+    y0_ref = tr.pre(f"model.patch_embed.proj.{A}").permute(0, 2, 3, 1).reshape(-1, D)
+    y0 = eng.tensor("Y0", 0, (B * np_, D))
+    tab.close("embed", "patch_embed.proj pre-FQ", y0, y0_ref)
+    tab.codes("embed", "patch_embed.proj", _fq_of_codes(y0, fqm[f"model.patch_embed.proj.{A}"], qa, qb),
+              tr.codes(f"model.patch_embed.proj.{A}").permute(0, 2, 3, 1).reshape(-1, D))
+    tab.close("embed", "x_in[0] (cls, pos added)", eng.tensor("x_in", 0, (M, D)), tr.block_in[0].reshape(M, D))
+    for i in range(depth):
+        st, pre = f"block{i}", f"model.blocks.{i}"
+        reset_act_observers(range(2 + 6 * i, 8 + 6 * i))
+        eng.tensor("x_in", i, (M, D)).copy_(tr.block_in[i].reshape(M, D).cuda())
+        eng.forward_stages(None, i + 1, i + 1, inject=True)
+        tab.codes(st, "norm1", eng.tensor("h1q", i, (M, D), torch.bfloat16), tr.codes(f"{pre}.norm1.{A}").reshape(M, D))
+        qkv = eng.tensor("qkv", i, (M, 3 * D))
+        tab.close(st, "attn.qkv pre-FQ", qkv, tr.pre(f"{pre}.attn.qkv.{A}").reshape(M, 3 * D))
+        tab.codes(st, "attn.qkv", _fq_of_codes(qkv, fqm[f"{pre}.attn.qkv.{A}"], qa, qb), tr.codes(f"{pre}.attn.qkv.{A}").reshape(M, 3 * D))
+        o = eng.tensor("O_hi", i, (M, D), torch.bfloat16).float() + eng.tensor("O_lo", i, (M, D), torch.bfloat16).float()
+        tab.close(st, "attention out (proj operand)", o, tr.proj_in[i].reshape(M, D))
+        yp = eng.tensor("Yproj", i, (M, D))
+        tab.close(st, "attn.proj pre-FQ", yp, tr.pre(f"{pre}.attn.proj.{A}").reshape(M, D))
+        tab.codes(st, "attn.proj", _fq_of_codes(yp, fqm[f"{pre}.attn.proj.{A}"], qa, qb), tr.codes(f"{pre}.attn.proj.{A}").reshape(M, D))
+        tab.close(st, "x_mid", eng.tensor("x_mid", i, (M, D)), tr.norm2_in[i].reshape(M, D))
+        tab.codes(st, "norm2", eng.tensor("h2q", i, (M, D), torch.bfloat16), tr.codes(f"{pre}.norm2.{A}").reshape(M, D))
+        Hd = c.mlp_hidden
+        code = eng.tensor("Y1", i, (M, Hd), torch.int16).int() & 0xffff                     # (q - qmin) | in_range << 15
+        f1 = fqm[f"{pre}.mlp.fc1.{A}"]
+        tab.codes(st, "mlp.fc1", (code & 0x7fff).float() + qa - f1.zero_point.float(), tr.codes(f"{pre}.mlp.fc1.{A}").reshape(M, Hd))
+        ref_in = (tr.pre(f"{pre}.mlp.fc1.{A}") * (1.0 / tr.fq[f"{pre}.mlp.fc1.{A}"].scale)).round() + tr.fq[f"{pre}.mlp.fc1.{A}"].zero_point
+        ref_mask = ((ref_in >= qa) & (ref_in <= qb)).reshape(M, Hd)
+        mism = ((code >> 15).bool().cpu() != ref_mask).float().mean().item()
+        tab.rows.append((st, "mlp.fc1 STE mask", "codes", M * Hd, mism, 1.0 if mism > 0 else 0.0))
+        assert mism < CODE_FLIP_FRAC
+        gl = eng.tensor("G_hi", i, (M, Hd), torch.bfloat16).float() + eng.tensor("G_lo", i, (M, Hd), torch.bfloat16).float()
+        tab.close(st, "gelu out (fc2 operand)", gl, tr.fc2_in[i].reshape(M, Hd))
+        y2 = eng.tensor("Y2", i, (M, D))
+        tab.close(st, "mlp.fc2 pre-FQ", y2, tr.pre(f"{pre}.mlp.fc2.{A}").reshape(M, D))
+        tab.codes(st, "mlp.fc2", _fq_of_codes(y2, fqm[f"{pre}.mlp.fc2.{A}"], qa, qb), tr.codes(f"{pre}.mlp.fc2.{A}").reshape(M, D))
+        tab.close(st, f"x_in[{i + 1}] (block output)", eng.tensor("x_in", i + 1, (M, D)), tr.block_in[i + 1].reshape(M, D))
+    reset_act_observers([n_act - 2, n_act - 1])
+    eng.tensor("x_in", depth, (M, D)).copy_(tr.block_in[depth].reshape(M, D).cuda())
+    logits = eng.forward_stages(None, depth + 1, depth + 1, inject=True)
+    tab.codes("head", "norm (cls rows)", eng.tensor("hq", 0, (B, D)), tr.codes(f"model.norm.{A}")[:, 0])
+    lp = eng.tensor("logits_pre", 0, (B, 10))
+    tab.close("head", "head pre-FQ", lp, tr.pre(f"model.head.{A}"))
+    tab.codes("head", "head (logits)", _fq_of_codes(lp, fqm[f"model.head.{A}"], qa, qb), tr.codes(f"model.head.{A}"))
+    tab.close("head", "logits", logits, tr.logits, tol=5e-3)            # 80 values on a 256-level grid: one flipped code is 4e-3 here
+    # every activation quantizer's state after its one observation: the oracle's, to fp32 rounding of the observed min / max
+    for n, f in fqm.items():
+        if "weight_fake_quant" in n:
+            assert torch.allclose(f.scale.cpu(), tr.fq[n].scale, rtol=1e-6), n
+            assert torch.equal(f.zero_point.cpu(), tr.fq[n].zero_point), n
+        else:
+            assert torch.allclose(f.scale.cpu(), tr.fq[n].scale, rtol=2e-5), (n, f.scale.item(), tr.fq[n].scale.item())
+            assert (f.zero_point.cpu() - tr.fq[n].zero_point).abs().max().item() <= 1, n
+
+    # ================================================================= backward, stage by stage (forward state = the teacher-forced one)
+    names = [n for n, _ in p.named_parameters()]
+    pidx = {id(q): k for k, q in enumerate(eng.params)}
+    name_of = {pidx[id(q)]: n for n, q in p.named_parameters()}
+
+    def check_grads(stage, views, which):
+        for k in which:
+            tab.close(stage, "d " + name_of[k].replace("model.", ""), views[k], tr.grads[name_of[k]])
+
+    n_par = len(eng.params)
+    v = eng.backward_stages(tr.g_logits[0].cuda(), 0, 0)
+    check_grads("bwd head", v, range(n_par - 4, n_par))
+    dxA = eng.tensor("dxA", 0, (M, D))
+    tab.close("bwd head", f"d x_in[{depth}]", dxA, tr.g_block_in[depth].reshape(M, D))
+    for s in range(1, depth + 1):
+        i = depth - s
+        dxA.copy_(tr.g_block_in[i + 1].reshape(M, D).cuda())
+        v = eng.backward_stages(None, s, s, inject=True)
+        check_grads(f"bwd block{i}", v, range(4 + 12 * i, 4 + 12 * i + 12))
+        tab.close(f"bwd block{i}", f"d x_in[{i}]", dxA, tr.g_block_in[i].reshape(M, D))
+    dxA.copy_(tr.g_block_in[0].reshape(M, D).cuda())
+    v = eng.backward_stages(None, depth + 1, depth + 1, inject=True)
+    check_grads("bwd embed", v, range(0, 4))
+    assert len(names) == n_par
+    path = os.path.join(ROOT, "gpurun_out", f"round2_stage_flip_table_{golden_tag}.txt")
+    tab.write(path, f"# teacher-forced stage parity, ViT-S batch {B}, {backend} qconfig, {'KD' if teacher else 'CE only'}; native stage on the oracle's input vs the oracle "
+                    f"(torch {torch.__version__} CPU eager QAT); produced by tests/test_gpu_stage_parity.py")
+    return tab
+
+
+def test_stage_parity_c1_qnnpack(native_lib):
+    """BASELINE config C1 shapes: ViT-S + QATWrapper, batch 8, qnnpack (per-tensor weights, [0,255] activations), CE only."""
+    _run("qnnpack", 21, False, "c1_qnnpack")
+
+
+def test_stage_parity_c3_x86(native_lib):
+    """BASELINE config C3 semantics at batch 8: x86 qconfig (per-channel weights, [0,127] activations), KD loss on."""
+    _run("x86", 22, True, "c3_x86")

@@ -246,14 +246,57 @@ def test_observers_can_be_frozen(native_lib):
     assert abs(f.activation_post_process.max_val.item() - (np.float32(m1) + np.float32(0.01) * (np.float32(x2.max().item()) - np.float32(m1)))) < 1e-6
 
 
-def test_batch_size_change_rebuilds_engine(native_lib):
+def test_batch_size_is_a_runtime_argument(native_lib):
+    """The reference's loaders have no drop_last (qat_trainer.py:228-254) and evaluation uses its own batch (:49-61,371): a smaller batch
+    runs in the SAME engine and workspace (no allocation), a larger one grows the workspace once; results equal a fresh model's."""
     w = step_ref.RefQATWrapper(randomize_(RefVisionTransformer("vit_tiny_test", num_classes=10, img_size=32), 3))
     p = _product_from(w, "qnnpack", **TINY)
-    a = p(torch.randn(4, 3, 32, 32, device="cuda"))
-    b = p(torch.randn(2, 3, 32, 32, device="cuda"))
-    assert a.shape == (4, 10) and b.shape == (2, 10)
+    q = _product_from(w, "qnnpack", **TINY)
+    g = torch.Generator().manual_seed(5)
+    x4, x2, x6 = (torch.randn(n, 3, 32, 32, generator=g).cuda() for n in (4, 2, 6))
+    y2 = torch.randint(0, 10, (2,), generator=g).cuda()
+    a = p(x4)
+    eng = engine_of(p)
+    ws = eng.workspace.data_ptr()
+    mem = torch.cuda.memory_allocated()
+    o2, _ = _step(p, x2, y2, None)                                # training step at the smaller batch
+    assert engine_of(p) is eng and eng.workspace.data_ptr() == ws and eng.capacity == 4 and eng.cfg.batch == 2
+    assert torch.cuda.memory_allocated() - mem < (1 << 20) + sum(t.numel() * 4 for t in p.parameters()) * 1.1   # only the gradients
+    with torch.no_grad():
+        q(x4)
+    r2, _ = _step(q, x2, y2, None)                                # same two observations on a model that never saw another size
+    assert torch.equal(o2, r2)
+    for (n, u), (_, v) in zip(p.named_parameters(), q.named_parameters()):
+        assert rel_l2(u.grad.cpu(), v.grad.cpu()) < 1e-6, n       # (bias / LayerNorm gradients use fp32 atomics)
+    for (n, u), (_, v) in zip(p.named_buffers(), q.named_buffers()):
+        assert torch.equal(u, v), n
+    b = p(x6)                                                      # larger than anything seen: one re-allocation
+    assert a.shape == (4, 10) and b.shape == (6, 10) and engine_of(p) is eng and eng.capacity == 6
     with pytest.raises(RuntimeError, match="MI355X only"):
         p(torch.randn(2, 3, 32, 32))
+
+
+def test_second_forward_before_backward_is_refused(native_lib):
+    """The saved activations of a step live in the engine's workspace: an evaluation forward (or a second micro-batch) between a
+    forward and its backward would silently corrupt the gradients - the backward raises instead."""
+    w = step_ref.RefQATWrapper(randomize_(RefVisionTransformer("vit_tiny_test", num_classes=10, img_size=32), 3))
+    p = _product_from(w, "qnnpack", **TINY)
+    x = torch.randn(4, 3, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (4,), device="cuda")
+    out = p(x)
+    loss, _ = F.kd_ce_loss(out, None, y, 4.0, 0.5, 0.1)
+    with torch.no_grad():
+        p(x[:2])
+    with pytest.raises(RuntimeError, match="another forward"):
+        loss.backward()
+    _step(p, x, y, None)                                           # the ordinary order still works afterwards
+
+
+def test_float_tree_runs_on_cpu_before_prepare(native_lib):
+    """Before prepare_qat (the reference's pre-QAT epochs) and after convert() the wrapper is ordinary nn.Module code on any device."""
+    stu = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True, **TINY)
+    out = stu(torch.randn(2, 3, 32, 32))
+    assert out.shape == (2, 10) and not out.is_cuda
 
 
 def test_engine_data_parallel_path_single_rank(native_lib):

@@ -33,15 +33,7 @@ def fq_modules(prepared):
 
 def ws_tensor(eng, name, blk, shape, dtype=None):
     """A named intermediate tensor of the native engine's last step (view into its workspace)."""
-    import ctypes
-
-    dtype = dtype or torch.float32
-    off = eng.lib.qatvit_student_tensor_offset(ctypes.byref(eng.cfg), name.encode(), blk)
-    assert off >= 0, name
-    n = 1
-    for s in shape:
-        n *= s
-    return eng.workspace[off:off + n * (4 if dtype == torch.float32 else 2)].view(dtype).view(*shape)
+    return eng.tensor(name, blk, shape, dtype or torch.float32)
 
 
 def capture_fq_io(prepared):
