@@ -101,6 +101,13 @@ int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                    int32_t lda, int32_t ldb, int32_t ldc, const float* s1, const float* s2, const float* col_scale,
                    const float* bias, uint32_t* stats, void* stream);
 
+/* The same product with fp16 bit patterns in all three matrices: A = (A16_hi + A16_lo), an fp16 (hi, lo) pair of a float tensor pre-scaled
+ * by a power of two that the caller folds into *s1 (22 significant bits, 2^-23 relative, against 2^-17 for a bf16 pair); B16 = the weight
+ * integers as fp16 (exact).  v_mfma_f32_16x16x32_f16, fp32 accumulate.  Used for the two forward GEMMs with a float operand (attn.proj, mlp.fc2),
+ * whose outputs are fake-quantized next.  N % 384 == 0, K % 32 == 0. */
+int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                       int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream);
+
 /* The same product for two operands that both sit on a quantisation grid (qkv / fc1 / patch-embed forward), on int8 MFMA:
  *   A8 int8 [M,lda] = q - center (center = (qmin+qmax+1)/2 of the activation range), B8 int8 [N,ldb] = weight integers,
  *   wsum int32 [N] = row sums of B8, a_qp = {scale, 1/scale, zero_point, enabled} of A's quantizer (device):
@@ -132,6 +139,11 @@ int qatvit_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
 int32_t qatvit_attn_padded_tokens(int32_t T);
 int qatvit_attn_forward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
                         int32_t D, void* O_hi, void* O_lo, float* lse, void* stream);
+/* The same forward, additionally writing O as the fp16 (hi, lo) pair the attn.proj FORWARD GEMM reads: O = (O16_hi + O16_lo) * (*o16_scale),
+ * o16_scale (device float, written by the kernel) = qkv scale / 64.  Inside the forward the softmax probabilities and V enter the MFMA as
+ * fp16 (P scaled by 2^14): 2^-23 per element where a bf16 pair has 2^-17 - the forward feeds fake-quantizers, the backward does not. */
+int qatvit_attn_forward_f16(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
+                            int32_t D, void* O_hi, void* O_lo, float* lse, void* O16_hi, void* O16_lo, float* o16_scale, void* stream);
 int qatvit_attn_backward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
                          int32_t D, const void* O_hi, const void* O_lo, const float* lse, float* delta, const float* dO,
                          void* dqkv_hi, void* dqkv_lo, const float* col_scale, void* stream);
@@ -194,6 +206,18 @@ int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qa
 int qatvit_student_forward_stages(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
                                   const float* images, float* logits, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags,
                                   void* stream);
+/* One of the four parts of one transformer block of the forward - each begins where a test can inject the oracle's tensor behind a
+ * fake-quantizer that would otherwise amplify upstream one-step flips (a flipped key perturbs a whole head's attention; a flipped fc1
+ * code a whole row of fc2 outputs):
+ *   part 0: norm1 -> qkv GEMM                                         input x_in[block]            ("x_in")
+ *   part 1: attention -> proj GEMM -> residual (+ norm2 statistics)    input pre-fake-quant qkv     ("qkv"; reads x_in[block] as it stands)
+ *   part 2: norm2 -> fc1 (both passes) -> GELU                         input x_mid[block]           ("x_mid")
+ *   part 3: fc2 GEMM -> residual (+ next LayerNorm's statistics)       input the GELU output planes ("G_hi"/"G_lo", "G16_hi"/"G16_lo" and
+ *                                                                      "scal16"[1]; reads x_mid[block] as it stands)
+ * parts 0..3 in order == forward stage block + 1.  QATVIT_STAGE_INJECT: that input was written by the caller; the observer statistics
+ * (and LayerNorm row statistics) its producer would have left are recomputed first. */
+int qatvit_student_forward_part(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, void* workspace,
+                                int32_t block, int32_t part, int32_t flags, void* stream);
 int qatvit_student_backward_stages(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
                                    const float* dlogits, void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags,
                                    void* stream);

@@ -22,6 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kAW = 8;  // waves per attention workgroup (two per SIMD)
 
@@ -79,6 +80,28 @@ __device__ inline void split_acc2(const f32x4& a, const f32x4& b, bf16x8& hi, bf
         hi[j] = (__bf16)a[j]; lo[j] = (__bf16)(a[j] - (float)hi[j]);
         hi[j + 4] = (__bf16)b[j]; lo[j + 4] = (__bf16)(b[j] - (float)hi[j + 4]);
     }
+}
+
+// The forward keeps its float MFMA operands (softmax probabilities, and the output handed to attn.proj) as fp16 (hi, lo) pairs:
+// 11 + 11 significant bits (2^-23 relative) against 8 + 8 (2^-17) for a bf16 pair - the forward feeds fake-quantizers, where an operand
+// error of 2^-17 flips ~1e-3 of the downstream codes by one step, 2^-23 flips ~2e-5 (what fp32 reordering does anyway).  fp16 has a
+// narrow exponent, so the values are pre-scaled by a power of two (exact) into [2^-10, 2^15): P in (0, 1] by 2^14, O / s in [-255, 255]
+// by 2^6.  The backward (no quantizer downstream, tiny dynamic-range-free gradients) stays on bf16 pairs.
+constexpr float kPScale = 16384.f;      // 2^14: softmax probabilities
+constexpr float kOScale = 64.f;         // 2^6: attention output in units of the qkv scale
+__device__ inline void split_acc2_h(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (_Float16)a[j]; lo[j] = (_Float16)(a[j] - (float)hi[j]);
+        hi[j + 4] = (_Float16)b[j]; lo[j + 4] = (_Float16)(b[j] - (float)hi[j + 4]);
+    }
+}
+__device__ inline void store_split8_h(_Float16* hi, _Float16* lo, int64_t off, const float (&v)[8], float scale) {
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float x = v[j] * scale; h[j] = (_Float16)x; l[j] = (_Float16)(x - (float)h[j]); }
+    *reinterpret_cast<f16x8*>(hi + off) = h;
+    *reinterpret_cast<f16x8*>(lo + off) = l;
 }
 
 // Re-tile one wave's 16 x HD fp32 accumulator block (MFMA layout: column on the lane, 4 rows per register group) through a
@@ -165,6 +188,9 @@ struct AttnArgs {
     __bf16* dqkv_hi;    // [B*T, 3*D] hi/lo of d(loss)/d(pre-FQ qkv): already multiplied by the FQ mask (and by col_scale)
     __bf16* dqkv_lo;
     const float* col_scale;  // optional [3*D]: per-channel weight scale of attn.qkv folded into dqkv (see k_mask_bwd)
+    _Float16* O16_hi;   // fwd out (optional): fp16 (hi, lo) pair of O / (*o16_scale), the A operand of the attn.proj forward GEMM
+    _Float16* O16_lo;
+    float* o16_scale;   // fwd out (optional): the scalar the pair has to be multiplied by = qkv scale / 2^6
 };
 
 // stage one [T][HD] slice (q, k or v of head h) into an LDS image; `which`: 0 q, 1 k, 2 v
@@ -179,7 +205,13 @@ __device__ inline bf16x8 quant8(const float4& a, const float4& b, const AQP& q) 
 // (pins: an empty asm that "uses" the loaded values right after the load loop - left alone, LLVM sinks half of the loads below the first
 //  half's conversions, two memory round trips per image instead of one)
 __device__ inline void pin4(const float4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
-template <int HD, bool TR, int NKT, int NWV = kAW>
+__device__ inline f16x8 quant8_h(const float4& a, const float4& b, const AQP& q) {
+    f16x8 f;
+    f[0] = (_Float16)qint(a.x, q); f[1] = (_Float16)qint(a.y, q); f[2] = (_Float16)qint(a.z, q); f[3] = (_Float16)qint(a.w, q);
+    f[4] = (_Float16)qint(b.x, q); f[5] = (_Float16)qint(b.y, q); f[6] = (_Float16)qint(b.z, q); f[7] = (_Float16)qint(b.w, q);
+    return f;
+}
+template <int HD, bool TR, int NKT, int NWV = kAW, bool F16 = false>
 __device__ inline void stage_tokens(char* img, const float* base, int T, int ld, const AQP& q) {
     constexpr int CH = HD / 8;  // 16-B chunks per token row
     constexpr int TOTAL = NKT * 16 * CH, ITERS = (TOTAL + NWV * 64 - 1) / (NWV * 64);
@@ -198,12 +230,12 @@ __device__ inline void stage_tokens(char* img, const float* base, int T, int ld,
     for (int it = 0; it < ITERS; ++it) {
         const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
         if (i < TOTAL) {
-            bf16x8 f;
-            if (tok < T) f = quant8(a[it], b[it], q);
-            else
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f;
-            *reinterpret_cast<bf16x8*>(img + (TR ? tr_off<HD>(tok, ch) : row_off<HD>(tok, ch))) = f;
+            uint4 f = make_uint4(0u, 0u, 0u, 0u);    // (+0.0 in either 16-bit format)
+            if (tok < T) {
+                if constexpr (F16) f = __builtin_bit_cast(uint4, quant8_h(a[it], b[it], q));
+                else f = __builtin_bit_cast(uint4, quant8(a[it], b[it], q));
+            }
+            *reinterpret_cast<uint4*>(img + (TR ? tr_off<HD>(tok, ch) : row_off<HD>(tok, ch))) = f;
         }
     }
 }
@@ -254,7 +286,8 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
     const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
     const float* base = p.qkv + (int64_t)b * T * ld + h * HD;
     stage_tokens<HD, false, NKT>(sK, base + D, T, ld, q);
-    stage_tokens<HD, true, NKT>(sV, base + 2 * D, T, ld, q);
+    stage_tokens<HD, true, NKT, kAW, true>(sV, base + 2 * D, T, ld, q);   // fp16 integers: the B operand of the fp16 P.V product
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.o16_scale) *p.o16_scale = q.s * (1.0f / kOScale);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const float c = q.s * q.s * p.softmax_scale;
@@ -296,30 +329,36 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
             }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        const float invl = 1.0f / l;
+        const float invl = kPScale / l;      // probabilities enter the MFMA scaled by 2^14 (fp16 range); taken out again below
         if (g == 0 && qt * 16 + r < T) p.lse[(int64_t)blockIdx.x * TP + qt * 16 + r] = m + logf(l);
         f32x4 o[HD / 16];
 #pragma unroll
         for (int jd = 0; jd < HD / 16; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKT / 2; ++ks) {
-            bf16x8 ph, pl;
+            f16x8 ph, pl;
             const f32x4 pa = s[2 * ks] * invl, pb = s[2 * ks + 1] * invl;
-            split_acc2(pa, pb, ph, pl);
+            split_acc2_h(pa, pb, ph, pl);
 #pragma unroll
             for (int jd = 0; jd < HD / 16; ++jd) {
-                const bf16x8 vf = tr_frag2<HD>(sV, 32 * ks, 32 * ks + 16, 16 * jd, lane);
-                o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vf, o[jd], 0, 0, 0);
-                o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vf, o[jd], 0, 0, 0);
+                const f16x8 vf = __builtin_bit_cast(f16x8, tr_frag2<HD>(sV, 32 * ks, 32 * ks + 16, 16 * jd, lane));
+                o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vf, o[jd], 0, 0, 0);
+                o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vf, o[jd], 0, 0, 0);
             }
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            float ov[8];
+            float ov[8];          // sum_k P v_int, in units of the qkv scale
             int orow, oc;
-            const bool act = wave_retile8<HD>(sO, o, q.s, lane, half, ov, orow, oc);
+            const bool act = wave_retile8<HD>(sO, o, 1.0f / kPScale, lane, half, ov, orow, oc);
             const int qq = qt * 16 + 8 * half + orow;
-            if (act && qq < T) store_split8(p.O_hi, p.O_lo, ((int64_t)b * T + qq) * D + h * HD + 8 * oc, ov);
+            if (act && qq < T) {
+                const int64_t off = ((int64_t)b * T + qq) * D + h * HD + 8 * oc;
+                if (p.O16_hi) store_split8_h(p.O16_hi, p.O16_lo, off, ov, kOScale);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ov[k] *= q.s;
+                store_split8(p.O_hi, p.O_lo, off, ov);
+            }
         }
     }
 }
@@ -675,9 +714,10 @@ static int dispatch(int which, const AttnArgs& a, hipStream_t st) {
 int attn_padded_tokens(int T) { return T <= 32 ? 32 : 224; }
 
 int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, void* O_hi, void* O_lo, float* lse,
-                    hipStream_t st) {
+                    hipStream_t st, void* O16_hi, void* O16_lo, float* o16_scale) {
     AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), reinterpret_cast<__bf16*>(O_hi), reinterpret_cast<__bf16*>(O_lo), lse,
-               nullptr, nullptr, nullptr, nullptr, nullptr};
+               nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<_Float16*>(O16_hi), reinterpret_cast<_Float16*>(O16_lo), o16_scale};
+    if ((O16_hi != nullptr) != (O16_lo != nullptr) || (O16_hi && !o16_scale)) { set_error("attention forward: O16_hi / O16_lo / o16_scale go together"); return 1; }
     return dispatch(0, a, st);
 }
 
@@ -685,7 +725,7 @@ int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B
                     const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st) {
     AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), reinterpret_cast<__bf16*>(const_cast<void*>(O_hi)),
                reinterpret_cast<__bf16*>(const_cast<void*>(O_lo)), const_cast<float*>(lse), delta, dO, reinterpret_cast<__bf16*>(dqkv_hi),
-               reinterpret_cast<__bf16*>(dqkv_lo), col_scale};
+               reinterpret_cast<__bf16*>(dqkv_lo), col_scale, nullptr, nullptr, nullptr};
     if (dispatch(1, a, st)) return 1;
     return dispatch(2, a, st);
 }

@@ -91,6 +91,14 @@ int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     return 0;
 }
 
+int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                       int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream) {
+    QV_CHECK_ARG(A16_hi && A16_lo && B16 && C, "qatvit_gemm_nt_f16: null pointer argument");
+    if (launch_gemm_nt(A16_hi, A16_lo, B16, C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream, nullptr, nullptr, true)) return 1;
+    QV_CHECK_LAUNCH("qatvit_gemm_nt_f16");
+    return 0;
+}
+
 int qatvit_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int32_t center, float* C, int32_t M, int32_t N,
                       int32_t K, int32_t lda, int32_t ldb, int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias,
                       uint32_t* stats, void* stream) {
@@ -122,6 +130,15 @@ int qatvit_attn_forward(const float* qkv, const float* qp, int32_t qmin, int32_t
     QV_CHECK_ARG(B >= 1 && T >= 1 && H >= 1, "qatvit_attn_forward: empty shape");
     if (launch_attn_fwd(qkv, qp, qmin, qmax, B, T, H, D, O_hi, O_lo, lse, (hipStream_t)stream)) return 1;
     QV_CHECK_LAUNCH("qatvit_attn_forward");
+    return 0;
+}
+
+int qatvit_attn_forward_f16(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H, int32_t D, void* O_hi,
+                            void* O_lo, float* lse, void* O16_hi, void* O16_lo, float* o16_scale, void* stream) {
+    QV_CHECK_ARG(qkv && qp && O_hi && O_lo && lse && O16_hi && O16_lo && o16_scale, "qatvit_attn_forward_f16: null pointer argument");
+    QV_CHECK_ARG(B >= 1 && T >= 1 && H >= 1, "qatvit_attn_forward_f16: empty shape");
+    if (launch_attn_fwd(qkv, qp, qmin, qmax, B, T, H, D, O_hi, O_lo, lse, (hipStream_t)stream, O16_hi, O16_lo, o16_scale)) return 1;
+    QV_CHECK_LAUNCH("qatvit_attn_forward_f16");
     return 0;
 }
 

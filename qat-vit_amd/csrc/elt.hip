@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64) void k_embed_bwd(const float* __restrict__ dx0,
 // wq[n][k] = q(W[n][k]) - zp (bf16), wqT[k][n] = same, transposed (dgrad's B operand)
 __device__ inline void wquant_body(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
                                    __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K, int bx, int by,
-                                   int8_t* __restrict__ w8 = nullptr, int32_t* __restrict__ wsum = nullptr) {
+                                   int8_t* __restrict__ w8 = nullptr, int32_t* __restrict__ wsum = nullptr, _Float16* __restrict__ w16 = nullptr) {
     // 32x32 tile transpose through LDS
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -571,6 +571,7 @@ __device__ inline void wquant_body(const float* __restrict__ W, const float* __r
             v = q.on != 0.f ? fqi(W[(int64_t)n * K + k], q, qmin, qmax) : W[(int64_t)n * K + k];
             wq[(int64_t)n * K + k] = (__bf16)v;
             if (w8) w8[(int64_t)n * K + k] = (int8_t)v;   // the same integer for the int8-MFMA forward GEMMs
+            if (w16) w16[(int64_t)n * K + k] = (_Float16)v;   // ... and for the fp16-pair forward GEMMs (|v| <= 128: exact)
         }
         tile[ty + 8 * i][tx] = v;
     }
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256) void k_w_quant_all(const WQuantTab t) {
     while (wi + 1 < t.n && (int)blockIdx.x >= t.blk0[wi + 1]) ++wi;
     const int b = blockIdx.x - t.blk0[wi], kt = (t.K[wi] + 31) / 32;
     wquant_body(t.W[wi], t.qp[wi], t.per_channel, t.qmin, t.qmax, reinterpret_cast<__bf16*>(t.wq[wi]), reinterpret_cast<__bf16*>(t.wqT[wi]), t.N[wi],
-                t.K[wi], b % kt, b / kt, reinterpret_cast<int8_t*>(t.w8[wi]), t.wsum[wi]);
+                t.K[wi], b % kt, b / kt, reinterpret_cast<int8_t*>(t.w8[wi]), t.wsum[wi], reinterpret_cast<_Float16*>(t.w16[wi]));
 }
 
 // ============================================================================ launchers

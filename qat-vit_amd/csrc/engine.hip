@@ -71,6 +71,7 @@ struct Plan {
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
     int64_t w8_off[64 * 4 + 8], wsum_off[64 * 4 + 8], wsum_base, wsum_bytes, imgq8, h1q8, h2q8;   // int8 operands of the forward grid x grid GEMMs
+    int64_t w16_off[64 * 4 + 8], O16_hi, O16_lo, G16_hi, G16_lo, scal16;   // fp16 operands of the forward float x grid GEMMs (proj, fc2): shared by all blocks
     int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo, tn_scratch;
     int64_t total, stats_words;
     int TP;
@@ -129,7 +130,14 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
         p->w_off[wi] = take((int64_t)N * K * 2);
         p->wT_off[wi] = take((int64_t)N * K * 2);
         p->w8_off[wi] = take((int64_t)N * K);
+        const int kind = (wi == 0 || wi == d.n_w - 1) ? -1 : (wi - 1) % WB_COUNT;
+        p->w16_off[wi] = (kind == WB_PROJ || kind == WB_FC2) ? take((int64_t)N * K * 2) : -1;
     }
+    // the float A operands of the two forward GEMMs with a float operand, as fp16 (hi, lo) pairs: written and consumed inside one block's
+    // forward, so ONE set serves every block (the bf16 pairs next to them stay per block: the weight-gradient GEMMs read them in the backward)
+    p->O16_hi = take(M * D * 2); p->O16_lo = take(M * D * 2);
+    p->G16_hi = take(M * Hd * 2); p->G16_lo = take(M * Hd * 2);
+    p->scal16 = take(2 * sizeof(float));   // {attention-output pair scale, gelu pair scale}: device scalars the producers write
     p->imgq8 = take((int64_t)d.B * d.np * d.Kpe);
     p->wsum_base = o;
     for (int wi = 0; wi < d.n_w; ++wi) {
@@ -201,6 +209,20 @@ static bool use_i8() {
     return on != 0;
 }
 
+// QATVIT_F16=0: the float operands of the proj / fc2 FORWARD GEMMs as bf16 (hi, lo) pairs (2^-17 per element) instead of fp16 pairs (2^-23):
+// the round-1 arithmetic, kept to measure what the extra precision buys (tests/test_gpu_stage_parity.py flip table)
+static bool use_f16() {
+    static const int on = getenv("QATVIT_F16") ? atoi(getenv("QATVIT_F16")) : 1;
+    return on != 0;
+}
+
+// QATVIT_WBATCH=0: one launch triple per weight instead of three multi-tensor launches (tuning; also the path of models deeper than the
+// tables hold).  That path does not write the fp16 weight copies, so the fp16-pair forward GEMMs are off with it.
+static bool w_batched(const Dims& d) {
+    static const int wbatch = getenv("QATVIT_WBATCH") ? atoi(getenv("QATVIT_WBATCH")) : 1;
+    return wbatch && d.n_w <= kMaxW;
+}
+
 struct Ctx {
     const qatvit_cfg& c;
     Dims d;
@@ -237,6 +259,19 @@ struct Ctx {
         return launch_gemm_nt(A_hi, A_lo, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
                               c.w_per_channel ? f.scale : nullptr, bias, with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, nullptr, post);
     }
+    // the same product with the float A operand as an fp16 (hi, lo) pair scaled by *pair_scale (a device scalar its producer wrote) and the
+    // weight integers as fp16
+    int linear_fwd_f16(const void* A16_hi, const void* A16_lo, const float* pair_scale, int M, int wi, const float* bias, float* C, int ai_out) const {
+        int N, K; wshape(d, wi, &N, &K);
+        const qatvit_fq& f = wfq[wi];
+        ProfScope ps(prof, 1, 2.0 * M * N * K, st);
+        return launch_gemm_nt(A16_hi, A16_lo, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
+                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, nullptr, nullptr, true);
+    }
+    bool f16_ok(int wi) const {
+        int N, K; wshape(d, wi, &N, &K);
+        return use_f16() && w_batched(d) && p.w16_off[wi] >= 0 && N % 384 == 0 && K % 32 == 0;
+    }
     int center() const { return (c.act_qmin + c.act_qmax + 1) / 2; }
     // the same forward product with int8 operands: A8 = q - center written next to the bf16 grid by its producer, weight integers + row sums
     // from k_w_quant_all.  Falls back to the bf16 form for shapes the int8 tile does not cover.
@@ -271,9 +306,107 @@ struct Ctx {
     }
 };
 
+// One transformer block of the forward, in four parts that each start where the stage-level parity tests inject the oracle's tensor (behind
+// a fake-quantizer that would otherwise amplify upstream one-step flips): 0 = norm1 -> qkv GEMM; 1 = attention -> proj -> residual;
+// 2 = norm2 -> fc1 -> GELU; 3 = fc2 -> residual.
+static int fwd_block(const Ctx& x, int i, int parts) {
+    const Dims& d = x.d;
+    const Plan& p = x.p;
+    const qatvit_cfg& c = x.c;
+    hipStream_t st = x.st;
+    const int qa = c.act_qmin, qb = c.act_qmax;
+    const int M = (int)d.M;
+    {
+        float* xin = x.blk<float>(p.x_in, i);
+        float* xmid = x.blk<float>(p.x_mid, i);
+        if (parts & 1) {   // ---- part 0: norm1 -> qkv
+        x.qparams_act(x.aidx(i, AB_N1));
+        launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
+                              qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h1q8, i) : nullptr, x.center());
+        if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB),
+                              x.blk<float>(p.qkv, i), x.aidx(i, AB_QKV)))
+            return 1;
+        }
+        const bool proj16 = x.f16_ok(x.widx(i, WB_PROJ)), fc2_16 = x.f16_ok(x.widx(i, WB_FC2)) && fc1_recompute();
+        float* const scal16 = x.at<float>(p.scal16);
+        if (parts & 2) {   // ---- part 1: attention -> proj -> residual (+ statistics of norm2)
+        x.qparams_act(x.aidx(i, AB_QKV));
+        if (launch_attn_fwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
+                            x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), st, proj16 ? x.at<void>(p.O16_hi) : nullptr,
+                            proj16 ? x.at<void>(p.O16_lo) : nullptr, proj16 ? scal16 : nullptr))
+            return 1;
+        if (proj16) {
+            if (x.linear_fwd_f16(x.at<void>(p.O16_hi), x.at<void>(p.O16_lo), scal16, M, x.widx(i, WB_PROJ), x.bprm(i, B_PROJB), x.blk<float>(p.Yproj, i),
+                                 x.aidx(i, AB_PROJ)))
+                return 1;
+        } else if (x.linear_fwd(x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), M, x.widx(i, WB_PROJ), nullptr, x.bprm(i, B_PROJB),
+                                x.blk<float>(p.Yproj, i), x.aidx(i, AB_PROJ)))
+            return 1;
+        x.qparams_act(x.aidx(i, AB_PROJ));
+        launch_resid_fq_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, nullptr, nullptr, xmid,
+                                x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B), c.ln_eps,
+                                x.act_stats(x.aidx(i, AB_N2)), kStatSlots, d.M, d.D, d.T, st, x.blk<void>(p.mproj, i));
+        }
+        if (parts & 4) {   // ---- part 2: norm2 -> fc1 (both passes) -> GELU
+        x.qparams_act(x.aidx(i, AB_N2));
+        launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
+                              x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h2q8, i) : nullptr,
+                              x.center());
+        if (fc1_recompute()) {
+            // fc1 is a K = D GEMM whose [M, 4D] fp32 output would be written once and read twice: run it TWICE instead.  Pass 1 only
+            // feeds the observer (min/max, nothing stored); pass 2 - the same kernel on the same operands, so the same bits - quantises
+            // with the fresh qparams and stores gelu(fq(.)) as the (hi, lo) pair fc2 reads plus a uint16 code (grid index | in-range
+            // bit) for the backward.  The fp32 pre-FQ tensor and the separate fq+gelu pass (620 MB per block) disappear.
+            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
+            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
+                             x.aidx(i, AB_FC1), &p1))
+                return 1;
+            x.qparams_act(x.aidx(i, AB_FC1));
+            NTPost p2{nullptr, x.act_qp(x.aidx(i, AB_FC1)), qa, qb, nullptr, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), 4,
+                      x.blk<void>(p.Y1, i)};
+            if (fc2_16) { p2.out16_hi = x.at<void>(p.G16_hi); p2.out16_lo = x.at<void>(p.G16_lo); p2.out16_scale = scal16 + 1; }
+            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
+                             x.aidx(i, AB_FC1), &p2, false))
+                return 1;
+        } else {
+            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B),
+                             x.blk<float>(p.Y1, i), x.aidx(i, AB_FC1)))
+                return 1;
+            x.qparams_act(x.aidx(i, AB_FC1));
+            launch_fq_gelu(x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), d.M * d.Hd, st);
+        }
+        }
+        if (parts & 8) {   // ---- part 3: fc2 -> residual (+ statistics of the next LayerNorm)
+        if (fc2_16) {
+            if (x.linear_fwd_f16(x.at<void>(p.G16_hi), x.at<void>(p.G16_lo), scal16 + 1, M, x.widx(i, WB_FC2), x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i),
+                                 x.aidx(i, AB_FC2)))
+                return 1;
+        } else if (x.linear_fwd(x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), M, x.widx(i, WB_FC2), nullptr, x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i),
+                                x.aidx(i, AB_FC2)))
+            return 1;
+        x.qparams_act(x.aidx(i, AB_FC2));
+        // residual + statistics of the NEXT LayerNorm (block i+1's norm1, or the final norm)
+        const bool last = (i + 1 == d.depth);
+        const float* g = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth) : x.bprm(i + 1, B_N1W);
+        const float* bt = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth + 1) : x.bprm(i + 1, B_N1B);
+        float* mean = last ? x.at<float>(p.meanF) : x.blk<float>(p.mean1, i + 1);
+        float* rstd = last ? x.at<float>(p.rstdF) : x.blk<float>(p.rstd1, i + 1);
+        launch_resid_fq_lnstats(1, xmid, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, nullptr, nullptr, x.blk<float>(p.x_in, i + 1),
+                                mean, rstd, g, bt, c.ln_eps, x.act_stats(last ? x.a_norm() : x.aidx(i + 1, AB_N1)), kStatSlots, d.M, d.D, d.T, st,
+                                x.blk<void>(p.m2, i));
+        }
+        return 0;
+    }
+}
+
 // x_in[i] (the input of block i, or of the final norm for i == depth) was written into the workspace by the caller (teacher forcing in
 // the stage-level parity tests): compute what the producer of that tensor would have left behind for its consumer - the row mean / rstd
 // and the min/max of the LayerNorm output that the consumer's first fake-quant observes.
+static int inject_ln_stats_of(const Ctx& x, const float* tensor, const float* g, const float* bt, float* mean, float* rstd, int ai) {
+    launch_ws_init(x.act_stats(ai), kStatSlots * kStatStride / 2, x.st);   // whatever an earlier, unconsumed producer accumulated is stale
+    return launch_resid_fq_lnstats(2, tensor, nullptr, x.act_qp(0), x.c.act_qmin, x.c.act_qmax, nullptr, nullptr, nullptr, mean, rstd, g, bt, x.c.ln_eps,
+                                   x.act_stats(ai), kStatSlots, x.d.M, x.d.D, x.d.T, x.st);
+}
 static int inject_ln_stats(const Ctx& x, int i) {
     const Dims& d = x.d;
     const Plan& p = x.p;
@@ -282,10 +415,28 @@ static int inject_ln_stats(const Ctx& x, int i) {
     const float* bt = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth + 1) : x.bprm(i, B_N1B);
     float* mean = last ? x.at<float>(p.meanF) : x.blk<float>(p.mean1, i);
     float* rstd = last ? x.at<float>(p.rstdF) : x.blk<float>(p.rstd1, i);
-    const int ai = last ? x.a_norm() : x.aidx(i, AB_N1);
-    launch_ws_init(x.act_stats(ai), kStatSlots * kStatStride / 2, x.st);   // whatever an earlier, unconsumed producer accumulated is stale
-    return launch_resid_fq_lnstats(2, x.blk<float>(p.x_in, i), nullptr, x.act_qp(0), x.c.act_qmin, x.c.act_qmax, nullptr, nullptr, nullptr, mean, rstd, g, bt,
-                                   x.c.ln_eps, x.act_stats(ai), kStatSlots, d.M, d.D, d.T, x.st);
+    return inject_ln_stats_of(x, x.blk<float>(p.x_in, i), g, bt, mean, rstd, last ? x.a_norm() : x.aidx(i, AB_N1));
+}
+// one part of one block (fwd_block); `inject`: the part's input was written by the caller - part 0: x_in[block]; part 1: the pre-fake-quant
+// qkv[block] (x_in[block] is read as it stands); part 2: x_mid[block]; part 3: the GELU output planes (G_hi / G_lo, and G16_hi / G16_lo with
+// their scale when the fp16 path is on; x_mid[block] is read as it stands) - nothing to recompute for it
+static int fwd_part(const Ctx& x, int block, int part, bool inject) {
+    const Dims& d = x.d;
+    const Plan& p = x.p;
+    if (inject) {
+        if (part == 0) {
+            if (inject_ln_stats(x, block)) return 1;
+        } else if (part == 1) {
+            const int ai = x.aidx(block, AB_QKV);
+            launch_ws_init(x.act_stats(ai), kStatSlots * kStatStride / 2, x.st);
+            launch_minmax(x.blk<float>(p.qkv, block), 1, d.M * 3 * d.D, 0, x.act_stats(ai), kStatSlots, x.st);
+        } else if (part == 2) {
+            if (inject_ln_stats_of(x, x.blk<float>(p.x_mid, block), x.bprm(block, B_N2W), x.bprm(block, B_N2B), x.blk<float>(p.mean2, block),
+                                   x.blk<float>(p.rstd2, block), x.aidx(block, AB_N2)))
+                return 1;
+        }
+    }
+    return fwd_block(x, block, 1 << part);
 }
 
 // forward stages: 0 = weight preparation + input fake-quant + patch embedding (leaves x_in[0]); s in 1..depth = block s-1 (leaves
@@ -299,8 +450,7 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
     if (inject && s_from >= 1 && inject_ln_stats(x, s_from - 1)) return 1;
     if (s_from == 0) {
     // ---- weights: observe, qparams, integer operands (row-major and transposed) - all 50 tensors in three launches
-    static const int wbatch = getenv("QATVIT_WBATCH") ? atoi(getenv("QATVIT_WBATCH")) : 1;   // 0: one launch triple per weight (tuning)
-    if (wbatch && d.n_w <= kMaxW) {
+    if (w_batched(d)) {
         WObsTab to{};
         WQpTab tq{};
         WQuantTab tw{};
@@ -321,6 +471,7 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
             tq.qp[wi] = x.w_qp(wi); tw.qp[wi] = x.w_qp(wi);
             tw.wq[wi] = x.at<void>(p.w_off[wi]); tw.wqT[wi] = x.at<void>(p.wT_off[wi]);
             tw.w8[wi] = use_i8() ? x.at<void>(p.w8_off[wi]) : nullptr;
+            tw.w16[wi] = x.f16_ok(wi) ? x.at<void>(p.w16_off[wi]) : nullptr;
             tw.wsum[wi] = use_i8() ? x.at<int32_t>(p.wsum_off[wi]) : nullptr;
         }
         if (use_i8()) launch_zero_i32(x.at<int32_t>(p.wsum_base), p.wsum_bytes / 4, st);   // row sums are accumulated with integer atomics
@@ -352,69 +503,8 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
                                 x.act_stats(x.aidx(0, AB_N1)), kStatSlots, d.M, d.D, d.T, st))
         return 1;
     }   // stage 0
-    const int M = (int)d.M;
-    for (int i = (s_from < 1 ? 0 : s_from - 1); i < d.depth && i + 1 <= s_to; ++i) {
-        float* xin = x.blk<float>(p.x_in, i);
-        float* xmid = x.blk<float>(p.x_mid, i);
-        // norm1 -> qkv
-        x.qparams_act(x.aidx(i, AB_N1));
-        launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
-                              qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h1q8, i) : nullptr, x.center());
-        if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB),
-                              x.blk<float>(p.qkv, i), x.aidx(i, AB_QKV)))
-            return 1;
-        x.qparams_act(x.aidx(i, AB_QKV));
-        if (launch_attn_fwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
-                            x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), st))
-            return 1;
-        if (x.linear_fwd(x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), M, x.widx(i, WB_PROJ), nullptr, x.bprm(i, B_PROJB),
-                         x.blk<float>(p.Yproj, i), x.aidx(i, AB_PROJ)))
-            return 1;
-        x.qparams_act(x.aidx(i, AB_PROJ));
-        launch_resid_fq_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, nullptr, nullptr, xmid,
-                                x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B), c.ln_eps,
-                                x.act_stats(x.aidx(i, AB_N2)), kStatSlots, d.M, d.D, d.T, st, x.blk<void>(p.mproj, i));
-        // norm2 -> fc1 -> gelu -> fc2
-        x.qparams_act(x.aidx(i, AB_N2));
-        launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
-                              x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h2q8, i) : nullptr,
-                              x.center());
-        if (fc1_recompute()) {
-            // fc1 is a K = D GEMM whose [M, 4D] fp32 output would be written once and read twice: run it TWICE instead.  Pass 1 only
-            // feeds the observer (min/max, nothing stored); pass 2 - the same kernel on the same operands, so the same bits - quantises
-            // with the fresh qparams and stores gelu(fq(.)) as the (hi, lo) pair fc2 reads plus a uint16 code (grid index | in-range
-            // bit) for the backward.  The fp32 pre-FQ tensor and the separate fq+gelu pass (620 MB per block) disappear.
-            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
-            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
-                             x.aidx(i, AB_FC1), &p1))
-                return 1;
-            x.qparams_act(x.aidx(i, AB_FC1));
-            const NTPost p2{nullptr, x.act_qp(x.aidx(i, AB_FC1)), qa, qb, nullptr, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), 4,
-                            x.blk<void>(p.Y1, i)};
-            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
-                             x.aidx(i, AB_FC1), &p2, false))
-                return 1;
-        } else {
-            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B),
-                             x.blk<float>(p.Y1, i), x.aidx(i, AB_FC1)))
-                return 1;
-            x.qparams_act(x.aidx(i, AB_FC1));
-            launch_fq_gelu(x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), d.M * d.Hd, st);
-        }
-        if (x.linear_fwd(x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), M, x.widx(i, WB_FC2), nullptr, x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i),
-                         x.aidx(i, AB_FC2)))
-            return 1;
-        x.qparams_act(x.aidx(i, AB_FC2));
-        // residual + statistics of the NEXT LayerNorm (block i+1's norm1, or the final norm)
-        const bool last = (i + 1 == d.depth);
-        const float* g = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth) : x.bprm(i + 1, B_N1W);
-        const float* bt = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth + 1) : x.bprm(i + 1, B_N1B);
-        float* mean = last ? x.at<float>(p.meanF) : x.blk<float>(p.mean1, i + 1);
-        float* rstd = last ? x.at<float>(p.rstdF) : x.blk<float>(p.rstd1, i + 1);
-        launch_resid_fq_lnstats(1, xmid, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, nullptr, nullptr, x.blk<float>(p.x_in, i + 1),
-                                mean, rstd, g, bt, c.ln_eps, x.act_stats(last ? x.a_norm() : x.aidx(i + 1, AB_N1)), kStatSlots, d.M, d.D, d.T, st,
-                                x.blk<void>(p.m2, i));
-    }
+    for (int i = (s_from < 1 ? 0 : s_from - 1); i < d.depth && i + 1 <= s_to; ++i)
+        if (fwd_block(x, i, 15)) return 1;
     if (s_to < d.depth + 1) return 0;
     // ---- final norm (observer saw all tokens), cls pooling, head
     x.qparams_act(x.a_norm());
@@ -570,6 +660,19 @@ int qatvit_student_forward_stages(const qatvit_cfg* cfg, void* const* params, co
     return run_forward(cfg, params, act_fq, weight_fq, images, logits, workspace, stage_from, stage_to, flags, stream, "qatvit_student_forward_stages");
 }
 
+int qatvit_student_forward_part(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, void* workspace,
+                                int32_t block, int32_t part, int32_t flags, void* stream) {
+    QV_CHECK_ARG(cfg && params && act_fq && weight_fq && workspace, "qatvit_student_forward_part: null argument");
+    if (check_cfg(*cfg)) return 1;
+    QV_CHECK_ARG(block >= 0 && block < cfg->depth && part >= 0 && part <= 3 && (flags & ~QATVIT_STAGE_INJECT) == 0,
+                 "qatvit_student_forward_part: bad block %d / part %d / flags %d", block, part, flags);
+    Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream, prof_of(workspace)};
+    if (make_plan(*cfg, &x.p)) return 1;
+    if (fwd_part(x, block, part, (flags & QATVIT_STAGE_INJECT) != 0)) return 1;
+    QV_CHECK_LAUNCH("qatvit_student_forward_part");
+    return 0;
+}
+
 static int run_backward(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, const float* dlogits,
                         void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags, void* stream, const char* who) {
     QV_CHECK_ARG(cfg && params && act_fq && weight_fq && grads && workspace, "%s: null argument", who);
@@ -653,7 +756,8 @@ int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, in
         {"x_mid", p.x_mid, true}, {"h1q", p.h1q, true}, {"qkv", p.qkv, true}, {"O_hi", p.O_hi, true}, {"O_lo", p.O_lo, true}, {"Yproj", p.Yproj, true}, {"h2q", p.h2q, true},
         {"Y1", p.Y1, true}, {"G_hi", p.G_hi, true}, {"G_lo", p.G_lo, true}, {"Y2", p.Y2, true}, {"dxA", p.dxA, false}, {"dqkv_hi", p.dqkv_hi, false},
         {"dqkv_lo", p.dqkv_lo, false}, {"dO", p.dO, false},
-        {"dH", p.dH, false}, {"lse", p.lse, true},
+        {"dH", p.dH, false}, {"lse", p.lse, true}, {"O16_hi", p.O16_hi, false}, {"O16_lo", p.O16_lo, false}, {"G16_hi", p.G16_hi, false},
+        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) return t.off + (t.per_block ? p.blk_stride * block : 0);

@@ -26,6 +26,7 @@
 namespace qv {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -108,6 +109,11 @@ struct NTArgs {
     const float* post_colscale;
     __bf16* out_hi;
     __bf16* out_lo;
+    // mode 4 (optional): the same gelu(fq(C)) a second time as an fp16 (hi, lo) pair pre-scaled by a power of two (the A operand of the fc2
+    // FORWARD GEMM); *out16_scale receives the factor that takes the pair back to real units
+    _Float16* out16_hi;
+    _Float16* out16_lo;
+    float* out16_scale;
 };
 
 constexpr int kStandIn = 512;
@@ -171,11 +177,26 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
         }
         return n;
     };
-    if (PM == 4 && tid <= p.post_qmax - p.post_qmin) {
-        const float gv = gelu_fwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
-        const __bf16 gh = (__bf16)gv;
-        const __bf16 gl = (__bf16)(gv - (float)gh);
-        sLutF[tid] = (uint32_t)__builtin_bit_cast(uint16_t, gh) | ((uint32_t)__builtin_bit_cast(uint16_t, gl) << 16);
+    uint32_t* sLutH = sLutF + 256;   // mode 4: packed fp16 (hi | lo << 16) pair of 2^k * gelu(grid value)
+    if constexpr (PM == 4) {
+        static_assert(RING == 0 || RING >= SLAB * LDC * 4 + 2048, "ring too small for the two mode-4 tables");
+        // |gelu(x)| <= |x|, so the largest grid magnitude bounds the table: 2^k maps it into [2^13, 2^14) - inside fp16's range with
+        // eleven bits to spare below for the lo part (every thread computes the same k from the same device scalars)
+        const float ga = fabsf(((float)p.post_qmin - p.post_qp[2]) * p.post_qp[0]), gb = fabsf(((float)p.post_qmax - p.post_qp[2]) * p.post_qp[0]);
+        int ex;
+        (void)frexpf(fmaxf(ga, gb), &ex);
+        const float gs = ldexpf(1.0f, 14 - ex);
+        if (p.out16_scale && blockIdx.x == 0 && tid == 0) *p.out16_scale = ldexpf(1.0f, ex - 14);
+        if (tid <= p.post_qmax - p.post_qmin) {
+            const float gv = gelu_fwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
+            const __bf16 gh = (__bf16)gv;
+            const __bf16 gl = (__bf16)(gv - (float)gh);
+            sLutF[tid] = (uint32_t)__builtin_bit_cast(uint16_t, gh) | ((uint32_t)__builtin_bit_cast(uint16_t, gl) << 16);
+            const float g16 = gv * gs;
+            const _Float16 hh = (_Float16)g16;
+            const _Float16 hl = (_Float16)(g16 - (float)hh);
+            sLutH[tid] = (uint32_t)__builtin_bit_cast(uint16_t, hh) | ((uint32_t)__builtin_bit_cast(uint16_t, hl) << 16);
+        }
     }
     float ca[TNT], cb[TNT];
 #pragma unroll
@@ -282,7 +303,8 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         if (ok[u]) *reinterpret_cast<float4*>(p.C + off[u]) = v[u];
                 } else if constexpr (PM == 4) {
                     const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
-                    uint32_t w[U][4], cd[U][4];
+                    const bool w16 = p.out16_hi != nullptr;   // uniform
+                    uint32_t w[U][4], wh[U][4], cd[U][4];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const float cv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -291,19 +313,26 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                             const float t = rintf(cv[e] * qinv) + qzp;
                             const uint32_t ix = (uint32_t)(int)(fminf(fmaxf(t, fmin_), fmax_) - fmin_);
                             w[u][e] = sLutF[ix];
+                            wh[u][e] = sLutH[ix];
                             cd[u][e] = ix | ((t >= fmin_ && t <= fmax_) ? 0x8000u : 0u);
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        uint2 hi2, lo2, cc;
+                        uint2 hi2, lo2, cc, h16, l16;
                         hi2.x = (w[u][0] & 0xffffu) | (w[u][1] << 16); hi2.y = (w[u][2] & 0xffffu) | (w[u][3] << 16);
                         lo2.x = (w[u][0] >> 16) | (w[u][1] & 0xffff0000u); lo2.y = (w[u][2] >> 16) | (w[u][3] & 0xffff0000u);
+                        h16.x = (wh[u][0] & 0xffffu) | (wh[u][1] << 16); h16.y = (wh[u][2] & 0xffffu) | (wh[u][3] << 16);
+                        l16.x = (wh[u][0] >> 16) | (wh[u][1] & 0xffff0000u); l16.y = (wh[u][2] >> 16) | (wh[u][3] & 0xffff0000u);
                         cc.x = cd[u][0] | (cd[u][1] << 16); cc.y = cd[u][2] | (cd[u][3] << 16);
                         if (ok[u]) {
                             *reinterpret_cast<uint2*>(p.out_hi + off[u]) = hi2;
                             *reinterpret_cast<uint2*>(p.out_lo + off[u]) = lo2;
                             *reinterpret_cast<uint2*>(p.post_code + off[u]) = cc;
+                        }
+                        if (ok[u] && w16) {
+                            *reinterpret_cast<uint2*>(p.out16_hi + off[u]) = h16;
+                            *reinterpret_cast<uint2*>(p.out16_lo + off[u]) = l16;
                         }
                     }
                 } else {   // PM == 5
@@ -383,6 +412,14 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     *reinterpret_cast<uint2*>(p.out_hi + off) = hi2;
                     *reinterpret_cast<uint2*>(p.out_lo + off) = lo2;
                     *reinterpret_cast<uint2*>(p.post_code + off) = c2;
+                    if (p.out16_hi) {
+                        const uint32_t x0 = sLutH[cd[0] & 0xffu], x1 = sLutH[cd[1] & 0xffu], x2 = sLutH[cd[2] & 0xffu], x3 = sLutH[cd[3] & 0xffu];
+                        uint2 h16, l16;
+                        h16.x = (x0 & 0xffffu) | (x1 << 16); h16.y = (x2 & 0xffffu) | (x3 << 16);
+                        l16.x = (x0 >> 16) | (x1 & 0xffff0000u); l16.y = (x2 >> 16) | (x3 & 0xffff0000u);
+                        *reinterpret_cast<uint2*>(p.out16_hi + off) = h16;
+                        *reinterpret_cast<uint2*>(p.out16_lo + off) = l16;
+                    }
                 } else if constexpr (PM == 5) {
                     uint2 c2;
                     if constexpr (CODE_LDS) c2 = *reinterpret_cast<const uint2*>(sCodeH + (rl * BN + 4 * c4) * 2);
@@ -455,11 +492,15 @@ __device__ inline int nt_off32(int row, int chunk) {
 // ABL: timing-only ablations (tools/bench_gemm.py, tools/stamp_nt.py): 1 = no LDS reads / MFMA, 2 = no DMA, 3 = no epilogue,
 // 5 = s_memtime stamps of the k-loop into p.C (no epilogue)
 // NWD: number of waves (the first NWD, the older wave of each SIMD pair) that issue the LDS-DMA pieces; 0 = all of them
-template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0, int PM = 0, bool I8 = false>
+// F16: both operands hold fp16 bit patterns (a float A operand as an fp16 (hi, lo) pair pre-scaled by a power of two, the weight integers
+// as fp16): v_mfma_f32_16x16x32_f16 - same tile, same LDS images, same rate as the bf16 form, 2^-23 instead of 2^-17 per A element.
+template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0, int PM = 0, bool I8 = false,
+          bool F16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {   // two waves per SIMD (one 8-wave or two 4-wave workgroups)
     // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
     static_assert(BK == 64 || BK == 32, "BK");
     static_assert(!I8 || (TA == 1 && TB == 1 && TM > 4 && BK == 32), "int8 operands: tall single-image tiles only");
+    static_assert(!F16 || (!I8 && TB == 1 && TM > 4), "fp16 operands: tall tiles only");
     constexpr int WR = 16 * TM, WC = 16 * TNT;      // rows / columns per wave
     constexpr int BM = WR * WM, BN = WC * WN, NW = WN * WM;
     constexpr int IMGA = BM * BK * 2;               // bytes of one [BM][BK] bf16 image
@@ -606,6 +647,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
                             if constexpr (I8) {   // one stage row (64 B) = 64 int8 k-values: v_mfma_i32_16x16x64_i8, same 16-B-per-lane fragments
                                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[i % PF][t]), __builtin_bit_cast(i32x4, bfrag[j]),
                                                                                   acc[i][j], 0, 0, 0);
+                            } else if constexpr (F16) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i % PF][t]), __builtin_bit_cast(f16x8, bfrag[j]),
+                                                                                   acc[i][j], 0, 0, 0);
                             } else {
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % PF][t], bfrag[j], acc[i][j], 0, 0, 0);
                             }
@@ -637,15 +681,15 @@ static void allow_lds(K kernel, size_t bytes) {
 }
 
 // one kernel instantiation per epilogue variant (NTArgs::pm); the timing-only ablations exist for the plain epilogue only
-template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD, bool I8 = false>
+template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD, bool I8 = false, bool F16 = false>
 static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
-#define QV_PM(PM_)                                                                                                  \
-    do {                                                                                                            \
-        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8>, lds), true);   \
-        (void)once;                                                                                                 \
-        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8><<<grid, WM * WN * 64, lds, st>>>(a);          \
+#define QV_PM(PM_)                                                                                                       \
+    do {                                                                                                                 \
+        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16>, lds), true);   \
+        (void)once;                                                                                                      \
+        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16><<<grid, WM * WN * 64, lds, st>>>(a);          \
     } while (0)
-    if constexpr (ABL != 0) {
+    if constexpr (ABL != 0 || F16) {   // (the fp16 form is only used with the plain epilogue: proj / fc2 forward)
         QV_PM(0);
     } else if constexpr (I8) {   // the grid x grid forward GEMMs only use these three epilogues
         switch (a.pm) {
@@ -668,7 +712,11 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
 
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                   const void* B_lo, const NTPost* post) {
+                   const void* B_lo, const NTPost* post, bool f16) {
+    if (f16 && (!A_lo || B_lo || post || N % 384 != 0 || K % 32 != 0)) {
+        set_error("gemm_nt: the fp16 form takes a split A operand, N %% 384 == 0, the plain epilogue (N=%d K=%d)", N, K);
+        return 1;
+    }
     if (M < 1 || N % 128 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) {
         set_error("gemm_nt: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d ldc=%d (need N%%128==0, K%%64==0, lda/ldb%%8==0, ldc%%4==0)", M, N, K,
                   lda, ldb, ldc);
@@ -676,13 +724,14 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
              reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
-             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (post && post->mode >= 3) {
         a.post_mode = post->mode;
         a.pm = post->mode;
         a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.post_colscale = post->colscale;
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
         a.post_code = reinterpret_cast<uint16_t*>(post->code);
+        a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
         if (post->mode > 5 || (post->mode != 3 && (!a.post_qp || !a.out_hi || !a.out_lo || !a.post_code || a.post_qmax - a.post_qmin >= 256))) {
             set_error("gemm_nt: incomplete arguments for epilogue mode %d", post->mode);
             return 1;
@@ -735,6 +784,11 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     if ((tall == 4 || (pm5_4w && a.pm == 5)) && A_lo && N % 384 == 0 && K % 32 == 0) {   // 112 x 384 tiles, 4 waves, 2 stages (76 KiB): two workgroups per CU
         constexpr size_t lds4 = 2 * (2 * 112 + 384) * 64;
         nt_launch<2, 2, 1, 7, 1, 0, 4, 6, 32, 0>(a, cdiv(M, 112) * (N / 384), lds4, st);
+        return 0;
+    }
+    if (f16) {
+        constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
+        nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);
         return 0;
     }
     if (tall && A_lo && N % 384 == 0 && K % 32 == 0) {
@@ -815,13 +869,15 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
         return 1;
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A8), nullptr, reinterpret_cast<const __bf16*>(B8), nullptr, C, M, N, K / 2, lda / 2, ldb / 2, ldc, s1, s2,
-             col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, 0, 0, wsum, a_qp, center, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+             col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, 0, 0, wsum, a_qp, center, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr,
+             nullptr, nullptr, nullptr};
     if (post) {
         if (post->mode != 3 && post->mode != 4) { set_error("gemm_nt_i8: epilogue mode %d not available", post->mode); return 1; }
         a.post_mode = a.pm = post->mode;
         a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax;
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
         a.post_code = reinterpret_cast<uint16_t*>(post->code);
+        a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
         if (post->mode == 4 && (!a.post_qp || !a.out_hi || !a.out_lo || !a.post_code || a.post_qmax - a.post_qmin >= 256)) {
             set_error("gemm_nt_i8: incomplete arguments for epilogue mode 4");
             return 1;

@@ -42,12 +42,17 @@ struct NTPost {
     //   5: like 1, with the mask and the grid index taken from `code` instead of recomputed from Y
     int mode = 0;
     void* code = nullptr;   // uint16 [M, ldc]
+    // mode 4, optional: gelu(fq(C)) once more as an fp16 (hi, lo) pair scaled by a power of two chosen from qp (the operand of the fc2
+    // FORWARD GEMM: 2^-23 per element instead of the bf16 pair's 2^-17); *out16_scale = what the pair has to be multiplied by
+    void* out16_hi = nullptr;
+    void* out16_lo = nullptr;
+    float* out16_scale = nullptr;
 };
 
 // ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                   const void* B_lo = nullptr, const NTPost* post = nullptr);
+                   const void* B_lo = nullptr, const NTPost* post = nullptr, bool f16 = false);   // f16: A_hi / A_lo / B hold fp16 bit patterns
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
                       hipStream_t st, const NTPost* post = nullptr);
@@ -92,6 +97,7 @@ struct WQpTab {
 };
 struct WQuantTab {
     const float* W[kMaxW]; const float* qp[kMaxW]; void* wq[kMaxW]; void* wqT[kMaxW]; void* w8[kMaxW]; int32_t* wsum[kMaxW];   // w8 / wsum optional (int8 copies + row sums)
+    void* w16[kMaxW];   // optional: the same integers as fp16 (B operand of the fp16-pair forward GEMMs: proj, fc2)
     int N[kMaxW], K[kMaxW], blk0[kMaxW + 1]; int n, per_channel, qmin, qmax;
 };
 int launch_w_observe_all(WObsTab& t, hipStream_t st);      // fills blk0
@@ -102,8 +108,9 @@ int launch_wquant(const float* W, const float* qp, int per_channel, int qmin, in
 
 // ---- attn.hip
 int attn_padded_tokens(int T);
+// O16_hi / O16_lo / o16_scale (optional, all or none): fp16 (hi, lo) pair of O / *o16_scale, the operand of the attn.proj FORWARD GEMM
 int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, void* O_hi, void* O_lo, float* lse,
-                    hipStream_t st);
+                    hipStream_t st, void* O16_hi = nullptr, void* O16_lo = nullptr, float* o16_scale = nullptr);
 int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const void* O_hi, const void* O_lo,
                     const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st);
 

@@ -365,6 +365,13 @@ class StudentEngine:
             native.stream_ptr()), "qatvit_student_forward_stages")
         return logits
 
+    def forward_part(self, block: int, part: int, inject: bool = False) -> None:
+        """qatvit_student_forward_part: part 0 / 1 / 2 of one block (inputs: x_in / pre-FQ qkv / x_mid of that block)."""
+        self.generation += 1
+        native.check(self.lib.qatvit_student_forward_part(ctypes.byref(self.cfg), self._ptr_params, self._act_structs, self._w_structs,
+                                                          self.workspace.data_ptr(), block, part, STAGE_INJECT if inject else 0, native.stream_ptr()),
+                     "qatvit_student_forward_part")
+
     def backward_stages(self, dlogits: Optional[torch.Tensor], stage_from: int, stage_to: int, inject: bool = False):
         """Returns per-parameter gradient views (zero for the stages that did not run)."""
         c = self.cfg

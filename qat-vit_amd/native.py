@@ -30,11 +30,13 @@ SIGNATURES = {
     "qatvit_optim_grad_norm": (c_int, [c_void_p] * 4 + [c_int32, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "qatvit_optim_adamw": (c_int, [c_void_p] * 7 + [c_int32, c_int64] + [c_double] * 5 + [c_int64, c_void_p, c_void_p]),
     "qatvit_gemm_nt": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
+    "qatvit_gemm_nt_f16": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_nt_i8": (c_int, [c_void_p] * 4 + [c_int32, c_void_p] + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_tn_scratch_bytes": (c_int64, []),
     "qatvit_gemm_tn": (c_int, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
     "qatvit_attn_padded_tokens": (c_int32, [c_int32]),
     "qatvit_attn_forward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 4),
+    "qatvit_attn_forward_f16": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 7),
     "qatvit_attn_backward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 9),
     "qatvit_student_num_params": (c_int32, [c_void_p]),
     "qatvit_student_num_act_fq": (c_int32, [c_void_p]),
@@ -44,6 +46,7 @@ SIGNATURES = {
     "qatvit_student_forward": (c_int, [c_void_p] * 8),
     "qatvit_student_backward": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_void_p]),
     "qatvit_student_forward_stages": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
+    "qatvit_student_forward_part": (c_int, [c_void_p] * 5 + [c_int32, c_int32, c_int32, c_void_p]),
     "qatvit_student_backward_stages": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
     "qatvit_student_tensor_offset": (c_int64, [c_void_p, c_char_p, c_int32]),
     "qatvit_teacher_workspace_bytes": (c_int64, [c_void_p]),

@@ -64,3 +64,31 @@ def test_attention_rejects_unsupported(native_lib):
     x = torch.zeros(8, device="cuda")
     assert native_lib.qatvit_attn_forward(x.data_ptr(), x.data_ptr(), 0, 255, 1, 300, 1, 64, x.data_ptr(), x.data_ptr(), x.data_ptr(), None) != 0
     assert b"unsupported" in native_lib.qatvit_last_error()
+
+
+@pytest.mark.parametrize("B,T,H,D", [(3, 197, 6, 384), (2, 197, 12, 768), (1, 17, 4, 128)])
+def test_attention_forward_f16_pair(native_lib, B, T, H, D):
+    """Forward with fp16 P.V and the fp16 (hi, lo) output pair for attn.proj: against fp64, 2e-6 (the bf16 pair written next to it: 3e-5)."""
+    torch.manual_seed(B * T + D + 1)
+    dev = "cuda"
+    qkv = torch.randn(B * T, 3 * D, device=dev) * 1.5
+    scale, zp, qmin, qmax = 8.0 / 255, 120, 0, 255
+    qp = torch.tensor([scale, 1.0, float(zp), 1.0], device=dev)
+    qp[1] = torch.ones(1, device=dev)[0] / qp[0]
+    TP = native_lib.qatvit_attn_padded_tokens(T)
+    Oh = torch.zeros(B * T, D, device=dev, dtype=torch.bfloat16)
+    Ol = torch.zeros_like(Oh)
+    O16h = torch.full((B * T, D), float("nan"), device=dev, dtype=torch.float16)
+    O16l = torch.full_like(O16h, float("nan"))
+    osc = torch.zeros(1, device=dev)
+    lse = torch.zeros(B * H, TP, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert native_lib.qatvit_attn_forward_f16(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
+                                              O16h.data_ptr(), O16l.data_ptr(), osc.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+    ro, _ = _ref(qkv, qp[0], zp, qmin, qmax, B, T, H, D, torch.zeros(B * T, D, device=dev))
+    assert osc.item() == qp[0].item() / 64
+    O16 = (O16h.double() + O16l.double()) * osc.double()
+    assert not torch.isnan(O16).any() and O16h.float().abs().max().item() < 65504
+    e16, eb = rel_l2(O16.cpu(), ro.cpu()), rel_l2((Oh.float() + Ol.float()).cpu(), ro.cpu())
+    print(f"attention fwd B={B} T={T} H={H}: fp16 pair {e16:.2e}, bf16 pair {eb:.2e}")
+    assert e16 < 2e-6 and eb < 3e-5

@@ -181,3 +181,44 @@ def test_gemm_tn_per_channel_mask_and_row_div(native_lib):
     mask = ((qv >= -128) & (qv <= 127)).double()
     assert rel_l2(C.cpu(), ((P.double().t() @ Q.double()) * mask).cpu()) < 2e-5
     assert rel_l2(db.cpu(), P.double().sum(0).cpu()) < 2e-5
+
+
+def split_h(x):
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    return hi, lo
+
+
+@pytest.mark.parametrize("M,N,K", [(1576, 384, 384), (300, 384, 1536), (50432, 384, 1536), (1000, 768, 3072)])
+def test_gemm_nt_f16_pair(native_lib, M, N, K):
+    """Forward float x grid GEMM (attn.proj, mlp.fc2) on fp16 (hi, lo) pairs: 2^-23 per operand element, fp32 accumulate.  Against fp64 on the
+    ORIGINAL fp32 operand: 1e-6 relative L2 (the bf16-pair form of the same product measures ~4e-6 and is asserted at 2e-5)."""
+    torch.manual_seed(M + N + K)
+    dev = "cuda"
+    A = torch.randn(M, K, device=dev).abs() * 3 * torch.rand(M, K, device=dev)      # wide dynamic range, like softmax-weighted sums / GELU outputs
+    A[::7] *= -0.05
+    pre = 2.0 ** 9                                                                     # power-of-two pre-scale: max |A| * 2^9 < 65504
+    assert (A.abs().max() * pre).item() < 60000
+    Ah, Al = split_h(A * pre)
+    B = torch.randint(-128, 128, (N, K), device=dev).float()
+    Bh = B.to(torch.float16)
+    s1 = torch.tensor([0.0123 / pre], device=dev)
+    s2 = torch.tensor([0.0045], device=dev)
+    bias = torch.randn(N, device=dev)
+    stats = torch.tensor([0xFF800000 - (1 << 32), 0x007FFFFF], dtype=torch.int32, device=dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    assert native_lib.qatvit_gemm_nt_f16(Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), C.data_ptr(), M, N, K, K, K, N, s1.data_ptr(), s2.data_ptr(), None,
+                                         bias.data_ptr(), stats.data_ptr(), _st()) == 0, native_lib.qatvit_last_error()
+    rows = torch.arange(0, M, max(1, M // 1500), device=dev)
+    ref = (A[rows].double() @ B.double().t()) * (0.0123 * 0.0045) + bias.double()
+    assert not torch.isnan(C).any()
+    e16 = rel_l2(C[rows].cpu(), ref.cpu())
+    # the bf16-pair form on the same operand, for the record
+    Abh, Abl = split(A)
+    Cb = torch.empty_like(C)
+    s1b = torch.tensor([0.0123], device=dev)
+    assert native_lib.qatvit_gemm_nt(Abh.data_ptr(), Abl.data_ptr(), B.to(torch.bfloat16).data_ptr(), Cb.data_ptr(), M, N, K, K, K, N, s1b.data_ptr(),
+                                     s2.data_ptr(), None, bias.data_ptr(), None, _st()) == 0
+    eb = rel_l2(Cb[rows].cpu(), ref.cpu())
+    print(f"nt M={M} N={N} K={K}: fp16 pair {e16:.2e}, bf16 pair {eb:.2e}")
+    assert e16 < 1e-6 and e16 < eb
