@@ -675,6 +675,147 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     nt_epilogue<WM, WN, TM, TNT, SLAB, PM, NSTAGE * STAGE, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
 
+// ============================================================================ NT, B operand through registers
+// The same 208 x 384 tile (1 x 8 waves, each 208 rows x 48 columns), but only the A operand goes through LDS.  In the 1 x 8 wave layout a
+// B (weight) fragment belongs to ONE wave - wave wn needs rows 48 wn .. 48 wn + 47 of the weight and nobody else does - so staging the
+// 384-row B tile in LDS buys no reuse: it only pushes 24 KB per k-step through the LDS-DMA path, which delivers ~25 GB/s per CU (6.4 TB/s
+// chip-wide, L2 hits included) and was the bound of every K >= 1152 launch.  Here each lane fetches its 16 bytes of the next k-step's three B
+// fragments (MFMA B layout: row = lane & 15, 8-element k chunk = lane >> 4) straight from L2 into registers with buffer_load_dwordx4 one
+// k-step ahead (two register sets), and the ring holds A only: half the LDS-DMA bytes and instructions, no B fragment ds_reads, a deeper ring.
+// The loads are inline asm (beside LDS-DMA hipcc waits vmcnt(0) for every ordinary load result: the ring would drain each step); completion
+// is counted by hand in the one in-order vmcnt queue: B(kt) is issued at the top of step kt-1 BEFORE that step's A pieces, so "B(kt) and
+// everything older (A tile kt included, ring depth >= 3) has arrived" == "at most this wave's A pieces of step kt-1 are outstanding".
+__device__ inline v4i32 load16_asm(v4i32 rsrc, uint32_t voff) {
+    v4i32 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
+    return v;
+}
+// the wait that makes the asm-loaded fragments valid: nothing may be scheduled across it (hipcc moves register-only MFMAs past an asm
+// s_waitcnt despite the memory clobber; sched_barrier(0) is the fence - cdna_hip_programming.md rule 18)
+template <int N> __device__ inline void wait_vmcnt_b() {
+    wait_vmcnt<N>();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int TA, int NSTAGE, int PM, bool I8, bool F16, int LDSB>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt_br(const NTArgs p) {
+    constexpr int TM = 13, TNT = 3, WN = 8, BM = 208, BN = 384;
+    constexpr int IMGA = BM * 64;                     // one [208][32 x 2 B] image
+    constexpr int STAGE = TA * IMGA;
+    constexpr int PAI = BM / 16;                      // 1-KiB pieces per image (16 tile rows of 64 B)
+    constexpr int NP = TA * PAI, NDF = NP / 8, NDX = NP % 8, NPW = NDF + (NDX ? 1 : 0);
+    static_assert(NSTAGE >= 3 && NSTAGE <= 4 && NSTAGE * STAGE <= LDSB, "ring");
+    static_assert(!(I8 && (TA != 1 || F16)), "operand kinds");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int tilesN = p.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
+    const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(p.A0, (int64_t)p.M * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(TA == 2 ? p.A1 : p.A0, (int64_t)p.M * p.lda * 2);
+    const v4i32 rB = make_rsrc_v(p.B, (int64_t)p.N * p.ldb * 2);
+    const int lR = lane >> 3, lL = (lane & 7) ^ lR;
+    const int prow = 2 * lR + (lL >> 2), pk = lL & 3;
+    uint32_t boff[TNT];
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) boff[j] = (uint32_t)(((int64_t)(n0 + wave * (16 * TNT) + 16 * j + r) * p.ldb + 8 * g) * 2);
+
+    auto issue_piece = [&](int kt, int c) {   // this wave's c-th A piece of k-tile kt
+        char* st = smem + (kt % NSTAGE) * STAGE;
+        const int pc = c * 8 + wave;
+        if (c == NDF && wave >= NDX) return;
+        const int img = (TA == 2 && pc >= PAI) ? 1 : 0, q = pc - img * PAI;
+        const uint32_t off = (uint32_t)(((int64_t)(m0 + q * 16 + prow) * p.lda + kt * 32 + pk * 8) * 2);
+        if (img == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lds_void*)(st + q * 1024), 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (lds_void*)(st + IMGA + q * 1024), 16, off, 0, 0, 0);
+    };
+    auto load_b = [&](int kt, v4i32 (&b)[TNT]) {
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) b[j] = load16_asm(rB, boff[j] + (uint32_t)kt * 64u);
+    };
+
+    using acc_t = std::conditional_t<I8, i32x4, f32x4>;
+    acc_t acc[TM][TNT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) acc[i][j] = acc_t{};
+
+    const int nk = p.K / 32;
+    v4i32 b0[TNT], b1[TNT];
+    // issue order (one in-order vmcnt queue per wave):  A(0) .. A(NSTAGE-3) B(0) A(NSTAGE-2) | step 0: B(1) A(NSTAGE-1) | step 1: B(2) A(NSTAGE) | ...
+    // so at the top of EVERY step kt, B(kt) and everything older (A tile kt included) has arrived once at most the ONE A tile issued after
+    // B(kt) - tile kt + NSTAGE - 2, if it exists - is outstanding
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 2; ++s)
+        if (s < nk) {
+#pragma unroll
+            for (int c = 0; c < NPW; ++c) issue_piece(s, c);
+        }
+    load_b(0, b0);
+    if (NSTAGE - 2 < nk) {
+#pragma unroll
+        for (int c = 0; c < NPW; ++c) issue_piece(NSTAGE - 2, c);
+    }
+
+    auto step = [&](int kt, v4i32 (&bc)[TNT], v4i32 (&bn)[TNT]) {
+        const bool big = NDX && wave < NDX;
+        if (kt + NSTAGE - 2 >= nk) wait_vmcnt_b<0>();
+        else if (big) wait_vmcnt_b<NDF + 1>();
+        else wait_vmcnt_b<NDF>();
+        __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone left buffer (kt-1) % NSTAGE
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) load_b(kt + 1, bn);
+        const bool more = kt + NSTAGE - 1 < nk;
+        const char* st = smem + (kt % NSTAGE) * STAGE;
+        constexpr int PF = 3;
+        bf16x8 af[PF][TA];
+        auto read_a = [&](int i) {
+#pragma unroll
+            for (int t = 0; t < TA; ++t) af[i % PF][t] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + nt_off32(16 * i + r, g));
+        };
+#pragma unroll
+        for (int i = 0; i < PF - 1; ++i) read_a(i);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            // (pin the group order: without the LDS-DMA issues in between - the last NSTAGE-1 steps - hipcc hoists all 13 groups' fragment
+            //  reads to the top of the step, 52-104 live registers, and spills)
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < NPW; ++c)
+                    if ((c * TM) / NPW == i) issue_piece(kt + NSTAGE - 1, c);
+            }
+            if (i + PF - 1 < TM) read_a(i + PF - 1);
+#pragma unroll
+            for (int t = 0; t < TA; ++t)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) {
+                    if constexpr (I8) {
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[i % PF][t]), __builtin_bit_cast(i32x4, bc[j]), acc[i][j], 0, 0, 0);
+                    } else if constexpr (F16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i % PF][t]), __builtin_bit_cast(f16x8, bc[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % PF][t], __builtin_bit_cast(bf16x8, bc[j]), acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+    // (nk is even for every shape of the step: K % 64 == 0 is checked by the launcher)
+#pragma clang loop unroll(disable)
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, b0, b1);
+        step(kt + 1, b1, b0);
+    }
+    __syncthreads();  // all fragment reads done: the LDS is free for the epilogue
+    constexpr bool PM5_48 = PM == 5 && LDSB >= 48 * (BN + 4) * 4 + 1024 + 2 * 48 * BN * 2 && LDSB < 64 * (BN + 4) * 4 + 1024 + 2 * 64 * BN * 2;
+    constexpr int SLAB = PM5_48 ? 48 : 64;
+    static_assert(LDSB >= SLAB * (BN + 4) * 4 + 2048, "LDS too small for the epilogue slab");
+    nt_epilogue<1, WN, TM, TNT, SLAB, PM, LDSB, I8>(p, acc, smem, m0, n0, tid, lane, wave, 0, wave, r, g);
+}
+
 template <typename K>
 static void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -708,6 +849,37 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
         }
     }
 #undef QV_PM
+}
+
+// QATVIT_NT_BREG=1: the tall NT launches take their B operand through registers (k_gemm_nt_br).  Default 0 (both operands through LDS): measured
+// equal within +-3 % on every shape of the step (profiles/round2_nt_breg_ab.txt) - the LDS-DMA fill rate is NOT what bounds these kernels
+static int nt_breg() {
+    static const int on = getenv("QATVIT_NT_BREG") ? atoi(getenv("QATVIT_NT_BREG")) : 0;
+    return on;
+}
+template <int TA, int NS, bool I8, bool F16, int LDSB>
+static void nt_br_launch(const NTArgs& a, int grid, hipStream_t st) {
+#define QV_BR(PM_)                                                                                   \
+    do {                                                                                             \
+        static bool once = (allow_lds(k_gemm_nt_br<TA, NS, PM_, I8, F16, LDSB>, (size_t)LDSB), true); \
+        (void)once;                                                                                  \
+        k_gemm_nt_br<TA, NS, PM_, I8, F16, LDSB><<<grid, 512, LDSB, st>>>(a);                         \
+    } while (0)
+    if constexpr (F16) {
+        QV_BR(0);
+    } else if constexpr (I8 || TA == 1) {
+        switch (a.pm) {
+            case 3: QV_BR(3); break;
+            case 4: QV_BR(4); break;
+            default: QV_BR(0); break;
+        }
+    } else {
+        switch (a.pm) {
+            case 5: QV_BR(5); break;
+            default: QV_BR(0); break;
+        }
+    }
+#undef QV_BR
 }
 
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
@@ -786,9 +958,18 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         nt_launch<2, 2, 1, 7, 1, 0, 4, 6, 32, 0>(a, cdiv(M, 112) * (N / 384), lds4, st);
         return 0;
     }
+    // LDS of the B-through-registers form: split A, 4 stages x 26 KiB = 104 KiB ring (the mode-5 epilogue needs 146 KiB: slab + two code buffers);
+    // grid A, 4 stages x 13 KiB, epilogue slab 99 KiB
+    constexpr int kLdsBr2 = 150 * 1024, kLdsBr1 = 100 * 1024;
     if (f16) {
+        if (nt_breg() && K % 64 == 0) { nt_br_launch<2, 4, false, true, kLdsBr2>(a, cdiv(M, 208) * (N / 384), st); return 0; }
         constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
         nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);
+        return 0;
+    }
+    if (nt_breg() && !B_lo && N % 384 == 0 && K % 64 == 0 && (a.pm == 0 || (A_lo && a.pm == 5) || (!A_lo && (a.pm == 3 || a.pm == 4)))) {
+        if (A_lo) nt_br_launch<2, 4, false, false, kLdsBr2>(a, cdiv(M, 208) * (N / 384), st);
+        else nt_br_launch<1, 4, false, false, kLdsBr1>(a, cdiv(M, 208) * (N / 384), st);
         return 0;
     }
     if (tall && A_lo && N % 384 == 0 && K % 32 == 0) {
@@ -886,6 +1067,7 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
         set_error("gemm_nt_i8: null output");
         return 1;
     }
+    if (nt_breg() && a.K % 64 == 0) { nt_br_launch<1, 4, true, false, 100 * 1024>(a, cdiv(M, 208) * (N / 384), st); return 0; }
     constexpr size_t lds = 3 * (208 + 384) * 64;
     nt_launch<1, 3, 1, 13, 1, 0, 8, 3, 32, 0, true>(a, cdiv(M, 208) * (N / 384), lds, st);
     return 0;
