@@ -143,10 +143,15 @@ int qatvit_attn_forward(const float* qkv, const float* qp, int32_t qmin, int32_t
  * o16_scale (device float, written by the kernel) = qkv scale / 64.  Inside the forward the softmax probabilities and V enter the MFMA as
  * fp16 (P scaled by 2^14): 2^-23 per element where a bf16 pair has 2^-17 - the forward feeds fake-quantizers, the backward does not. */
 int qatvit_attn_forward_f16(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
-                            int32_t D, void* O_hi, void* O_lo, float* lse, void* O16_hi, void* O16_lo, float* o16_scale, void* stream);
+                            int32_t D, void* O_hi, void* O_lo, float* lse, void* O16_hi, void* O16_lo, float* o16_scale, void* qkv_codes,
+                            void* qkv_mask, void* stream);
+/* qkv_codes / qkv_mask (optional, both or neither): the forward also saves the quantised qkv it computed on load, in per-head slices (every
+ * workgroup's accesses are whole contiguous runs): codes[b][h][which][t][d] = clamp(q) - qmin as uint8 (which = 0 q / 1 k / 2 v, d < D / H;
+ * B*T*3*D bytes) and the STE mask, bit (d & 7) of byte mask[b][h][which][t][d >> 3] (B*T*3*D/8 bytes).  Given them the backward reads 1.125
+ * bytes per element instead of re-quantising the 4-byte pre-fake-quant tensor twice (its `qkv` argument may then be NULL).  Bit-identical results. */
 int qatvit_attn_backward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
                          int32_t D, const void* O_hi, const void* O_lo, const float* lse, float* delta, const float* dO,
-                         void* dqkv_hi, void* dqkv_lo, const float* col_scale, void* stream);
+                         void* dqkv_hi, void* dqkv_lo, const float* col_scale, const void* qkv_codes, const void* qkv_mask, void* stream);
 
 /* ===========================================================================
  * The whole student step.

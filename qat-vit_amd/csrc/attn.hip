@@ -33,6 +33,78 @@ __device__ inline bool qin(float x, const AQP& q) {
     return t >= q.fqmin && t <= q.fqmax;
 }
 
+// 8 consecutive pre-FQ values -> their 8 codes (clamp(q) - qmin, one byte each) and the 8 STE-mask bits
+__device__ inline void encode8(const float4& a, const float4& b, const AQP& q, uint2& codes, uint32_t& mask) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t c[8];
+    mask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float t = rintf(v[j] * q.inv) + q.zp;
+        mask |= (uint32_t)(t >= q.fqmin && t <= q.fqmax) << j;
+        c[j] = (uint32_t)(int)(fminf(fmaxf(t, q.fqmin), q.fqmax) - q.fqmin);
+    }
+    codes.x = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+    codes.y = c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24);
+}
+// the same in one pass with the MFMA fragment: t = rint(x / s) + zp is formed once per element
+template <bool F16>
+__device__ inline uint4 quant_encode8(const float4& a, const float4& b, const AQP& q, uint2& codes, uint32_t& mask) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t c[8];
+    float fi[8];
+    mask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float t = rintf(v[j] * q.inv) + q.zp;
+        const float tc = fminf(fmaxf(t, q.fqmin), q.fqmax);
+        mask |= (uint32_t)(t == tc) << j;
+        c[j] = 0;
+        fi[j] = tc - q.zp;
+        if (j < 4) codes.x = __builtin_amdgcn_cvt_pk_u8_f32(tc - q.fqmin, j, j == 0 ? 0u : codes.x);     // (one instruction: convert + insert byte j)
+        else codes.y = __builtin_amdgcn_cvt_pk_u8_f32(tc - q.fqmin, j - 4, j == 4 ? 0u : codes.y);
+    }
+    (void)c;
+    if constexpr (F16) {
+        f16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (_Float16)fi[j];
+        return __builtin_bit_cast(uint4, f);
+    } else {
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (__bf16)fi[j];
+        return __builtin_bit_cast(uint4, f);
+    }
+}
+// The CH (= HD / 8: 8 or 4) lanes that hold the CH mask bytes of one token row are consecutive (lane % CH == chunk): gather them with CH - 1
+// lane shuffles so that the chunk-0 lane stores the row's CH bytes at once (a 1-byte global store per lane costs ~12x its bytes)
+template <int CH>
+__device__ inline void store_mask_row(uint8_t* dst_row, uint32_t mk, int ch, bool valid) {
+    static_assert(CH == 8 || CH == 4, "head_dim 64 or 32");
+    uint32_t lo = mk & 0xffu, hi = 0;
+#pragma unroll
+    for (int k = 1; k < CH; ++k) {
+        const uint32_t o = (uint32_t)__shfl_down((int)(mk & 0xffu), k, 64);
+        if (k < 4) lo |= o << (8 * k);
+        else hi |= o << (8 * (k - 4));
+    }
+    if (valid && ch == 0) {
+        if constexpr (CH == 8) *reinterpret_cast<uint2*>(dst_row) = make_uint2(lo, hi);
+        else *reinterpret_cast<uint32_t*>(dst_row) = lo;
+    }
+}
+// 8 codes -> the bf16 fragment of integers q - zp (what quant8 produces from the pre-FQ values)
+__device__ inline bf16x8 decode8(const uint2& codes, float off /* qmin - zp */) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[j] = (__bf16)((float)((codes.x >> (8 * j)) & 0xffu) + off);
+        f[4 + j] = (__bf16)((float)((codes.y >> (8 * j)) & 0xffu) + off);
+    }
+    return f;
+}
+
 // ---- LDS images of a [tokens][HD] bf16 tile
 template <int HD> __device__ inline int row_off(int row, int chunk) {   // for ds_read_b128 row fragments
     if constexpr (HD == 64) return row * 128 + ((chunk ^ (row & 7)) << 4);
@@ -191,6 +263,12 @@ struct AttnArgs {
     _Float16* O16_hi;   // fwd out (optional): fp16 (hi, lo) pair of O / (*o16_scale), the A operand of the attn.proj forward GEMM
     _Float16* O16_lo;
     float* o16_scale;   // fwd out (optional): the scalar the pair has to be multiplied by = qkv scale / 2^6
+    // The quantised qkv as the forward saw it, for the backward (optional; fwd out / bwd in), in per-head slices so that a workgroup's
+    // accesses are whole contiguous runs: codes[b][h][which][t][d] = clamp(q) - qmin as uint8 (which = 0 q, 1 k, 2 v; d < head_dim), and the
+    // STE mask (qmin <= q <= qmax) one bit per element, bit (d & 7) of byte cmask[b][h][which][t][d >> 3].  With them the two backward
+    // kernels read 1.125 bytes per element instead of re-quantising the 4-byte pre-FQ tensor (3 x 232 MB per layer at batch 256).
+    uint8_t* codes;
+    uint8_t* cmask;
 };
 
 // stage one [T][HD] slice (q, k or v of head h) into an LDS image; `which`: 0 q, 1 k, 2 v
@@ -212,7 +290,8 @@ __device__ inline f16x8 quant8_h(const float4& a, const float4& b, const AQP& q)
     return f;
 }
 template <int HD, bool TR, int NKT, int NWV = kAW, bool F16 = false>
-__device__ inline void stage_tokens(char* img, const float* base, int T, int ld, const AQP& q) {
+__device__ inline void stage_tokens(char* img, const float* base, int T, int ld, const AQP& q, uint8_t* codes = nullptr, uint8_t* cmask = nullptr) {
+    // codes / cmask (forward only): the slice's codes [T][HD] and mask bytes [T][HD / 8], written once next to the staging
     constexpr int CH = HD / 8;  // 16-B chunks per token row
     constexpr int TOTAL = NKT * 16 * CH, ITERS = (TOTAL + NWV * 64 - 1) / (NWV * 64);
     float4 a[ITERS], b[ITERS];
@@ -229,12 +308,41 @@ __device__ inline void stage_tokens(char* img, const float* base, int T, int ld,
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
+        uint32_t mk = 0;
         if (i < TOTAL) {
             uint4 f = make_uint4(0u, 0u, 0u, 0u);    // (+0.0 in either 16-bit format)
             if (tok < T) {
-                if constexpr (F16) f = __builtin_bit_cast(uint4, quant8_h(a[it], b[it], q));
+                if (codes) {   // uniform
+                    uint2 cd;
+                    f = quant_encode8<F16>(a[it], b[it], q, cd, mk);
+                    *reinterpret_cast<uint2*>(codes + tok * HD + ch * 8) = cd;
+                } else if constexpr (F16) f = __builtin_bit_cast(uint4, quant8_h(a[it], b[it], q));
                 else f = __builtin_bit_cast(uint4, quant8(a[it], b[it], q));
             }
+            *reinterpret_cast<uint4*>(img + (TR ? tr_off<HD>(tok, ch) : row_off<HD>(tok, ch))) = f;
+        }
+        if (codes) store_mask_row<CH>(cmask + tok * CH, mk, ch, i < TOTAL && tok < T);   // (all lanes take part in the shuffles)
+    }
+}
+// the same image from the saved codes (backward): 8 bytes per 8 features instead of 32
+template <int HD, bool TR, int NKT, int NWV = kAW>
+__device__ inline void stage_codes(char* img, const uint8_t* base, int T, float off) {
+    constexpr int CH = HD / 8;
+    constexpr int TOTAL = NKT * 16 * CH, ITERS = (TOTAL + NWV * 64 - 1) / (NWV * 64);
+    uint2 c[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
+        c[it] = *reinterpret_cast<const uint2*>(base + min(tok, T - 1) * HD + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) asm volatile("" ::"v"(c[it].x), "v"(c[it].y));
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
+        if (i < TOTAL) {
+            uint4 f = make_uint4(0u, 0u, 0u, 0u);
+            if (tok < T) f = __builtin_bit_cast(uint4, decode8(c[it], off));
             *reinterpret_cast<uint4*>(img + (TR ? tr_off<HD>(tok, ch) : row_off<HD>(tok, ch))) = f;
         }
     }
@@ -273,9 +381,10 @@ __device__ inline void stage_split_tr(char* img_hi, char* img_lo, const float* b
 
 __device__ inline AQP make_aqp(const float* qp, int qmin, int qmax) { return AQP{qp[0], qp[1], qp[2], (float)qmin, (float)qmax}; }
 
+
 // ============================================================================ forward
 template <int HD, int NKT>
-__global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
+__global__ __launch_bounds__(kAW * 64, 4) void k_attn_fwd(const AttnArgs p) {   // 4 waves per SIMD: two workgroups per CU (<= 128 VGPRs)
     constexpr int IMG = NKT * 16 * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;         // row image
@@ -285,8 +394,12 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
     const float* base = p.qkv + (int64_t)b * T * ld + h * HD;
-    stage_tokens<HD, false, NKT>(sK, base + D, T, ld, q);
-    stage_tokens<HD, true, NKT, kAW, true>(sV, base + 2 * D, T, ld, q);   // fp16 integers: the B operand of the fp16 P.V product
+    const int64_t sl = (int64_t)T * HD;                                                                       // one slice of the code plane
+    uint8_t* const cbase = p.codes ? p.codes + (int64_t)blockIdx.x * 3 * sl : nullptr;                        // this (image, head)'s q slice; k, v follow
+    uint8_t* const mbase = p.codes ? p.cmask + (int64_t)blockIdx.x * 3 * (sl / 8) : nullptr;
+    stage_tokens<HD, false, NKT>(sK, base + D, T, ld, q, cbase ? cbase + sl : nullptr, cbase ? mbase + sl / 8 : nullptr);
+    stage_tokens<HD, true, NKT, kAW, true>(sV, base + 2 * D, T, ld, q, cbase ? cbase + 2 * sl : nullptr,
+                                           cbase ? mbase + 2 * (sl / 8) : nullptr);   // fp16 integers: the B operand of the fp16 P.V product
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.o16_scale) *p.o16_scale = q.s * (1.0f / kOScale);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
@@ -296,7 +409,21 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_fwd(const AttnArgs p) {
         const int qrow = min(qt * 16 + r, T - 1);
         bf16x8 qf[HD / 32];
 #pragma unroll
-        for (int kk = 0; kk < HD / 32; ++kk) qf[kk] = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
+        for (int kk = 0; kk < HD / 32; ++kk) {
+            const float4* pq = reinterpret_cast<const float4*>(base + (int64_t)qrow * ld + 32 * kk + 8 * g);
+            const float4 qa = pq[0], qb = pq[1];
+            if (cbase) {   // uniform.  Every q element of this head passes through exactly one lane here: save its code and mask bit
+                uint2 cd;
+                uint32_t mk;
+                qf[kk] = __builtin_bit_cast(bf16x8, quant_encode8<false>(qa, qb, q, cd, mk));
+                // lanes r, r+16, r+32, r+48 hold the mask bytes of k-chunks 4kk .. 4kk+3 of row r: gather them into the g == 0 lane
+                const uint32_t m1 = (uint32_t)__shfl_xor((int)mk, 16, 64), m2 = (uint32_t)__shfl_xor((int)mk, 32, 64), m3 = (uint32_t)__shfl_xor((int)mk, 48, 64);
+                if (qt * 16 + r < T) {
+                    *reinterpret_cast<uint2*>(cbase + qrow * HD + 32 * kk + 8 * g) = cd;
+                    if (g == 0) *reinterpret_cast<uint32_t*>(mbase + qrow * (HD / 8) + 4 * kk) = mk | (m1 << 8) | (m2 << 16) | (m3 << 24);
+                }
+            } else qf[kk] = quant8(qa, qb, q);
+        }
         f32x4 s[NKT];
 #pragma unroll
         for (int j = 0; j < NKT; ++j) {
@@ -375,8 +502,17 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, D = p.D, ld = 3 * D, TP = NKT * 16;
     const float* base = p.qkv + (int64_t)b * T * ld + h * HD;
-    stage_tokens<HD, true, NKT>(sKt, base + D, T, ld, q);
-    stage_tokens<HD, false, NKT>(sV, base + 2 * D, T, ld, q);
+    const int64_t sl = (int64_t)T * HD;
+    const uint8_t* const cbase = p.codes ? p.codes + (int64_t)blockIdx.x * 3 * sl : nullptr;
+    const uint8_t* const mbase = p.codes ? p.cmask + (int64_t)blockIdx.x * 3 * (sl / 8) : nullptr;
+    const float coff = q.fqmin - q.zp;
+    if (cbase) {
+        stage_codes<HD, true, NKT>(sKt, cbase + sl, T, coff);
+        stage_codes<HD, false, NKT>(sV, cbase + 2 * sl, T, coff);
+    } else {
+        stage_tokens<HD, true, NKT>(sKt, base + D, T, ld, q);
+        stage_tokens<HD, false, NKT>(sV, base + 2 * D, T, ld, q);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const float c = q.s * q.s * p.softmax_scale;
@@ -388,7 +524,8 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
         float dpart = 0.f;
 #pragma unroll
         for (int kk = 0; kk < HD / 32; ++kk) {
-            qf[kk] = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
+            if (cbase) qf[kk] = decode8(*reinterpret_cast<const uint2*>(cbase + qrow * HD + 32 * kk + 8 * g), coff);
+            else qf[kk] = load_q8(base + (int64_t)qrow * ld + 32 * kk + 8 * g, q);
             const float* pd = p.dO + ((int64_t)b * T + qrow) * D + h * HD + 32 * kk + 8 * g;
             const int64_t ooff = ((int64_t)b * T + qrow) * D + h * HD + 32 * kk + 8 * g;
             load_split8(pd, dh[kk], dl[kk]);
@@ -442,12 +579,18 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
         // conditional load inside the loop costs a vmcnt(0) at its merge point whether it is taken or not
         const int erow = lane / (HD / 8), ec8 = lane % (HD / 8);   // (the row / 8-column group wave_retile8 hands this lane)
         float4 xq[2][2], csq[2];
+        uint32_t mq[2] = {0u, 0u};    // with saved codes: the 8 mask bits of this lane's 8 features
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int qq = min(qt * 16 + 8 * half + (erow & 7), T - 1);
-            const float* px = p.qkv + ((int64_t)b * T + qq) * ld + h * HD + 8 * ec8;
-            xq[half][0] = *reinterpret_cast<const float4*>(px);
-            xq[half][1] = *reinterpret_cast<const float4*>(px + 4);
+            if (cbase) {
+                mq[half] = mbase[qq * (HD / 8) + ec8];
+                xq[half][0] = xq[half][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float* px = p.qkv + ((int64_t)b * T + qq) * ld + h * HD + 8 * ec8;
+                xq[half][0] = *reinterpret_cast<const float4*>(px);
+                xq[half][1] = *reinterpret_cast<const float4*>(px + 4);
+            }
         }
         csq[0] = csq[1] = make_float4(1.f, 1.f, 1.f, 1.f);
         if (p.col_scale) {
@@ -467,10 +610,13 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {  // STE mask of the qkv fake-quant (+ optional per-channel weight scale), 8 contiguous features
                     const float4 x4 = xq[half][k], cs = csq[k];
-                    gv[4 * k] = qin(x4.x, q) ? gv[4 * k] * cs.x : 0.f;
-                    gv[4 * k + 1] = qin(x4.y, q) ? gv[4 * k + 1] * cs.y : 0.f;
-                    gv[4 * k + 2] = qin(x4.z, q) ? gv[4 * k + 2] * cs.z : 0.f;
-                    gv[4 * k + 3] = qin(x4.w, q) ? gv[4 * k + 3] * cs.w : 0.f;
+                    const uint32_t mb = mq[half] >> (4 * k);
+                    const bool i0 = cbase ? (mb & 1u) : qin(x4.x, q), i1 = cbase ? (mb & 2u) : qin(x4.y, q), i2 = cbase ? (mb & 4u) : qin(x4.z, q),
+                               i3 = cbase ? (mb & 8u) : qin(x4.w, q);
+                    gv[4 * k] = i0 ? gv[4 * k] * cs.x : 0.f;
+                    gv[4 * k + 1] = i1 ? gv[4 * k + 1] * cs.y : 0.f;
+                    gv[4 * k + 2] = i2 ? gv[4 * k + 2] * cs.z : 0.f;
+                    gv[4 * k + 3] = i3 ? gv[4 * k + 3] * cs.w : 0.f;
                 }
                 store_split8(p.dqkv_hi, p.dqkv_lo, off, gv);
             }
@@ -504,7 +650,12 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     const int ci = min((int)threadIdx.x, NKT * 16 - 1);
     const float lse_i = p.lse[(int64_t)blockIdx.x * (NKT * 16) + min(ci, p.T - 1)];
     const float dlt_i = p.delta[(int64_t)blockIdx.x * (NKT * 16) + min(ci, p.T - 1)];
-    stage_tokens<HD, true, NKT, NWV>(sQt, base, T, ld, q);
+    const int64_t sl = (int64_t)T * HD;
+    const uint8_t* const cbase = p.codes ? p.codes + (int64_t)blockIdx.x * 3 * sl : nullptr;
+    const uint8_t* const mbase = p.codes ? p.cmask + (int64_t)blockIdx.x * 3 * (sl / 8) : nullptr;
+    const float coff = q.fqmin - q.zp;
+    if (cbase) stage_codes<HD, true, NKT, NWV>(sQt, cbase, T, coff);
+    else stage_tokens<HD, true, NKT, NWV>(sQt, base, T, ld, q);
     if (threadIdx.x < NKT * 16) { sLse[threadIdx.x] = lse_i; sDlt[threadIdx.x] = dlt_i; }
     stage_split_tr<HD, NKT, NWV>(sDh, sDl, dObase, T, D);
     __syncthreads();
@@ -520,7 +671,30 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     bf16x8 kf[U][KK], vf[U][KK];
     bool kvalid[U];
     f32x4 dk[U][ND], dv[U][ND];
-    {   // the owned K / V row fragments: every raw load first, pinned (left alone they come in dribs as registers free up, five or six
+    if (cbase) {   // the owned K / V row fragments from the saved codes: 8 bytes per fragment, all requested before any is converted
+        uint2 kc[U][KK], vc[U][KK];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int krow = min(16 * jt[u] + r, T - 1);
+            kvalid[u] = has[u] && 16 * jt[u] + r < T;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                kc[u][kk] = *reinterpret_cast<const uint2*>(cbase + sl + krow * HD + 32 * kk + 8 * g);
+                vc[u][kk] = *reinterpret_cast<const uint2*>(cbase + 2 * sl + krow * HD + 32 * kk + 8 * g);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(kc[u][kk].x), "v"(kc[u][kk].y), "v"(vc[u][kk].x), "v"(vc[u][kk].y));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                kf[u][kk] = decode8(kc[u][kk], coff);
+                vf[u][kk] = decode8(vc[u][kk], coff);
+            }
+    } else {   // the owned K / V row fragments: every raw load first, pinned (left alone they come in dribs as registers free up, five or six
         // dependent round trips before the sweep can start)
         float4 kr[U][KK][2], vr[U][KK][2];
 #pragma unroll
@@ -622,13 +796,23 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     // the STE mask needs the pre-FQ k / v values: all of them are requested before any is used (one memory round trip for the
     // epilogue instead of one per fragment; the sweep's operand registers are dead here)
     float4 xk[U][ND], xv[U][ND], ckc[ND], cvc[ND];
+    uint32_t mkk[U][ND], mkv[U][ND];   // with saved codes: the mask byte that holds this lane's 4 features (bits 4 (g & 1) ..)
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int id = 0; id < ND; ++id) {
-            const int64_t offk = ((int64_t)b * T + min(16 * jt[u] + r, T - 1)) * ld + D + h * HD + 16 * id + 4 * g;   // (branch-free; invalid keys are skipped below)
-            xk[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk);
-            xv[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk + D);
+            const int krow = min(16 * jt[u] + r, T - 1);   // (branch-free; invalid keys are skipped below)
+            if (cbase) {
+                const int mo = krow * (HD / 8) + (16 * id + 4 * g) / 8;
+                mkk[u][id] = mbase[sl / 8 + mo];
+                mkv[u][id] = mbase[2 * (sl / 8) + mo];
+                xk[u][id] = xv[u][id] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int64_t offk = ((int64_t)b * T + krow) * ld + D + h * HD + 16 * id + 4 * g;
+                xk[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk);
+                xv[u][id] = *reinterpret_cast<const float4*>(p.qkv + offk + D);
+                mkk[u][id] = mkv[u][id] = 0u;
+            }
         }
     // the per-column scales here too: an `if (col_scale)` load inside the store loop costs a vmcnt(0) at its merge point in every
     // iteration, taken or not - i.e. a wait for the previous iteration's stores
@@ -653,10 +837,15 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
             const int64_t offv = offk + D;
             const float4 k4 = xk[u][id], v4 = xv[u][id];
             const float4 ck = ckc[id], cv = cvc[id];
-            const float vk[4] = {qin(k4.x, q) ? dk[u][id][0] * a * ck.x : 0.f, qin(k4.y, q) ? dk[u][id][1] * a * ck.y : 0.f,
-                                 qin(k4.z, q) ? dk[u][id][2] * a * ck.z : 0.f, qin(k4.w, q) ? dk[u][id][3] * a * ck.w : 0.f};
-            const float vv[4] = {qin(v4.x, q) ? dv[u][id][0] * cv.x : 0.f, qin(v4.y, q) ? dv[u][id][1] * cv.y : 0.f,
-                                 qin(v4.z, q) ? dv[u][id][2] * cv.z : 0.f, qin(v4.w, q) ? dv[u][id][3] * cv.w : 0.f};
+            const uint32_t bk = mkk[u][id] >> (4 * (g & 1)), bv = mkv[u][id] >> (4 * (g & 1));
+            const bool ik[4] = {cbase ? (bk & 1u) != 0 : qin(k4.x, q), cbase ? (bk & 2u) != 0 : qin(k4.y, q), cbase ? (bk & 4u) != 0 : qin(k4.z, q),
+                                cbase ? (bk & 8u) != 0 : qin(k4.w, q)};
+            const bool iv[4] = {cbase ? (bv & 1u) != 0 : qin(v4.x, q), cbase ? (bv & 2u) != 0 : qin(v4.y, q), cbase ? (bv & 4u) != 0 : qin(v4.z, q),
+                                cbase ? (bv & 8u) != 0 : qin(v4.w, q)};
+            const float vk[4] = {ik[0] ? dk[u][id][0] * a * ck.x : 0.f, ik[1] ? dk[u][id][1] * a * ck.y : 0.f,
+                                 ik[2] ? dk[u][id][2] * a * ck.z : 0.f, ik[3] ? dk[u][id][3] * a * ck.w : 0.f};
+            const float vv[4] = {iv[0] ? dv[u][id][0] * cv.x : 0.f, iv[1] ? dv[u][id][1] * cv.y : 0.f,
+                                 iv[2] ? dv[u][id][2] * cv.z : 0.f, iv[3] ? dv[u][id][3] * cv.w : 0.f};
             bf16x4 kh, kl, vh, vl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -714,18 +903,23 @@ static int dispatch(int which, const AttnArgs& a, hipStream_t st) {
 int attn_padded_tokens(int T) { return T <= 32 ? 32 : 224; }
 
 int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, void* O_hi, void* O_lo, float* lse,
-                    hipStream_t st, void* O16_hi, void* O16_lo, float* o16_scale) {
+                    hipStream_t st, void* O16_hi, void* O16_lo, float* o16_scale, void* codes, void* cmask) {
     AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), reinterpret_cast<__bf16*>(O_hi), reinterpret_cast<__bf16*>(O_lo), lse,
-               nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<_Float16*>(O16_hi), reinterpret_cast<_Float16*>(O16_lo), o16_scale};
+               nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<_Float16*>(O16_hi), reinterpret_cast<_Float16*>(O16_lo), o16_scale,
+               reinterpret_cast<uint8_t*>(codes), reinterpret_cast<uint8_t*>(cmask)};
+    if ((codes != nullptr) != (cmask != nullptr) || (codes && qmax - qmin > 255)) { set_error("attention forward: codes / cmask go together (range <= 256 levels)"); return 1; }
     if ((O16_hi != nullptr) != (O16_lo != nullptr) || (O16_hi && !o16_scale)) { set_error("attention forward: O16_hi / O16_lo / o16_scale go together"); return 1; }
     return dispatch(0, a, st);
 }
 
 int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const void* O_hi, const void* O_lo,
-                    const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st) {
+                    const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st,
+                    const void* codes, const void* cmask) {
+    if ((codes != nullptr) != (cmask != nullptr)) { set_error("attention backward: codes / cmask go together"); return 1; }
     AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), reinterpret_cast<__bf16*>(const_cast<void*>(O_hi)),
                reinterpret_cast<__bf16*>(const_cast<void*>(O_lo)), const_cast<float*>(lse), delta, dO, reinterpret_cast<__bf16*>(dqkv_hi),
-               reinterpret_cast<__bf16*>(dqkv_lo), col_scale, nullptr, nullptr, nullptr};
+               reinterpret_cast<__bf16*>(dqkv_lo), col_scale, nullptr, nullptr, nullptr,
+               reinterpret_cast<uint8_t*>(const_cast<void*>(codes)), reinterpret_cast<uint8_t*>(const_cast<void*>(cmask))};
     if (dispatch(1, a, st)) return 1;
     return dispatch(2, a, st);
 }

@@ -66,7 +66,7 @@ static int wparam(const Dims& d, int wi) {  // index of the weight tensor in par
 struct Plan {
     // byte offsets into the workspace
     int64_t stats, qp_act, qp_w, imgq, Y0, meanF, rstdF, hq, logits_pre;
-    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2, qkv8, qkvm;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
     int64_t blk_stride;
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
@@ -120,6 +120,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->Y2 = take(M * D * 4);
     p->h1q8 = take(M * D); p->h2q8 = take(M * D);
     p->mproj = take(ln_maskbits_bytes(M, (int)D)); p->m2 = take(ln_maskbits_bytes(M, (int)D));
+    p->qkv8 = take(M * 3 * D); p->qkvm = take(M * 3 * D / 8);   // the quantised qkv as the attention forward saw it (codes + STE mask bits), for its backward
     p->blk_stride = o - b0;
     o = b0 + p->blk_stride * d.depth;
     // x_in[depth] (input of the final norm) lives where block `depth` would start
@@ -221,6 +222,12 @@ static bool use_f16() {
 static bool w_batched(const Dims& d) {
     static const int wbatch = getenv("QATVIT_WBATCH") ? atoi(getenv("QATVIT_WBATCH")) : 1;
     return wbatch && d.n_w <= kMaxW;
+}
+
+// QATVIT_ATTN_CODES=0: the attention backward re-quantises the pre-FQ qkv tensor instead of reading the codes its forward saved (tuning / A-B)
+static bool attn_codes(const qatvit_cfg& c) {
+    static const int on = getenv("QATVIT_ATTN_CODES") ? atoi(getenv("QATVIT_ATTN_CODES")) : 1;
+    return on != 0 && c.act_qmax - c.act_qmin <= 255;
 }
 
 struct Ctx {
@@ -333,7 +340,8 @@ static int fwd_block(const Ctx& x, int i, int parts) {
         x.qparams_act(x.aidx(i, AB_QKV));
         if (launch_attn_fwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
                             x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), st, proj16 ? x.at<void>(p.O16_hi) : nullptr,
-                            proj16 ? x.at<void>(p.O16_lo) : nullptr, proj16 ? scal16 : nullptr))
+                            proj16 ? x.at<void>(p.O16_lo) : nullptr, proj16 ? scal16 : nullptr, attn_codes(x.c) ? x.blk<void>(p.qkv8, i) : nullptr,
+                            attn_codes(x.c) ? x.blk<void>(p.qkvm, i) : nullptr))
             return 1;
         if (proj16) {
             if (x.linear_fwd_f16(x.at<void>(p.O16_hi), x.at<void>(p.O16_lo), scal16, M, x.widx(i, WB_PROJ), x.bprm(i, B_PROJB), x.blk<float>(p.Yproj, i),
@@ -582,7 +590,8 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             if (x.linear_dgrad(dYh, dYl, M, w_proj, x.at<float>(p.dO))) return 1;
             if (launch_attn_bwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
                                 x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), x.at<float>(p.delta), x.at<float>(p.dO), x.at<void>(p.dqkv_hi),
-                                x.at<void>(p.dqkv_lo), x.dy_colscale(w_qkv), st))
+                                x.at<void>(p.dqkv_lo), x.dy_colscale(w_qkv), st, attn_codes(c) ? x.blk<void>(p.qkv8, i) : nullptr,
+                                attn_codes(c) ? x.blk<void>(p.qkvm, i) : nullptr))
                 return 1;
             if (x.linear_wgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.blk<void>(p.h1q, i), nullptr, x.act_qp(x.aidx(i, AB_N1)),
                                BG(i, B_QKVW), BG(i, B_QKVB)))

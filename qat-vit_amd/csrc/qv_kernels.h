@@ -110,8 +110,10 @@ int launch_wquant(const float* W, const float* qp, int per_channel, int qmin, in
 int attn_padded_tokens(int T);
 // O16_hi / O16_lo / o16_scale (optional, all or none): fp16 (hi, lo) pair of O / *o16_scale, the operand of the attn.proj FORWARD GEMM
 int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, void* O_hi, void* O_lo, float* lse,
-                    hipStream_t st, void* O16_hi = nullptr, void* O16_lo = nullptr, float* o16_scale = nullptr);
+                    hipStream_t st, void* O16_hi = nullptr, void* O16_lo = nullptr, float* o16_scale = nullptr, void* codes = nullptr,
+                    void* cmask = nullptr);   // codes / cmask (optional): uint8 clamp(q) - qmin [B*T, 3D] and the STE mask bits [B*T, 3D/8], for the backward
 int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const void* O_hi, const void* O_lo,
-                    const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st);
+                    const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st,
+                    const void* codes = nullptr, const void* cmask = nullptr);   // with the forward's codes the pre-FQ qkv is not read at all
 
 }  // namespace qv

@@ -36,8 +36,8 @@ SIGNATURES = {
     "qatvit_gemm_tn": (c_int, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
     "qatvit_attn_padded_tokens": (c_int32, [c_int32]),
     "qatvit_attn_forward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 4),
-    "qatvit_attn_forward_f16": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 7),
-    "qatvit_attn_backward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 9),
+    "qatvit_attn_forward_f16": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 9),
+    "qatvit_attn_backward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 11),
     "qatvit_student_num_params": (c_int32, [c_void_p]),
     "qatvit_student_num_act_fq": (c_int32, [c_void_p]),
     "qatvit_student_num_weight_fq": (c_int32, [c_void_p]),

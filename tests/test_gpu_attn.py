@@ -46,7 +46,7 @@ def test_attention_fwd_bwd(native_lib, B, T, H, D, with_colscale):
     assert native_lib.qatvit_attn_forward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(), st) == 0, native_lib.qatvit_last_error()
     assert native_lib.qatvit_attn_backward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
                                            delta.data_ptr(), dO.data_ptr(), gh.data_ptr(), gl.data_ptr(), None if cs is None else cs.data_ptr(),
-                                           st) == 0, native_lib.qatvit_last_error()
+                                           None, None, st) == 0, native_lib.qatvit_last_error()
     ro, rg = _ref(qkv, qp[0], zp, qmin, qmax, B, T, H, D, dO)
     if cs is not None:
         rg = rg * cs.double()[None, :]
@@ -84,7 +84,7 @@ def test_attention_forward_f16_pair(native_lib, B, T, H, D):
     lse = torch.zeros(B * H, TP, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     assert native_lib.qatvit_attn_forward_f16(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
-                                              O16h.data_ptr(), O16l.data_ptr(), osc.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+                                              O16h.data_ptr(), O16l.data_ptr(), osc.data_ptr(), None, None, st) == 0, native_lib.qatvit_last_error()
     ro, _ = _ref(qkv, qp[0], zp, qmin, qmax, B, T, H, D, torch.zeros(B * T, D, device=dev))
     assert osc.item() == qp[0].item() / 64
     O16 = (O16h.double() + O16l.double()) * osc.double()
@@ -92,3 +92,45 @@ def test_attention_forward_f16_pair(native_lib, B, T, H, D):
     e16, eb = rel_l2(O16.cpu(), ro.cpu()), rel_l2((Oh.float() + Ol.float()).cpu(), ro.cpu())
     print(f"attention fwd B={B} T={T} H={H}: fp16 pair {e16:.2e}, bf16 pair {eb:.2e}")
     assert e16 < 2e-6 and eb < 3e-5
+
+
+@pytest.mark.parametrize("B,T,H,D,qmin,qmax,zp", [(3, 197, 6, 384, 0, 255, 120), (2, 197, 12, 768, 0, 127, 60), (1, 17, 4, 128, 0, 255, 131)])
+def test_attention_backward_from_saved_codes(native_lib, B, T, H, D, qmin, qmax, zp):
+    """The forward saves the quantised qkv (uint8 codes + STE mask bits); the backward from them equals the backward that re-quantises the
+    pre-FQ tensor, bit for bit, and never touches that tensor (NULL is passed)."""
+    torch.manual_seed(B * T + D + 7)
+    dev = "cuda"
+    qkv = torch.randn(B * T, 3 * D, device=dev) * 1.5
+    qkv[0, :9] = 40.0
+    qkv[1, 5:14] = -40.0
+    scale = 8.0 / (qmax - qmin)
+    qp = torch.tensor([scale, 1.0, float(zp), 1.0], device=dev)
+    qp[1] = torch.ones(1, device=dev)[0] / qp[0]
+    TP = native_lib.qatvit_attn_padded_tokens(T)
+    Oh = torch.zeros(B * T, D, device=dev, dtype=torch.bfloat16); Ol = torch.zeros_like(Oh)
+    O16h = torch.zeros(B * T, D, device=dev, dtype=torch.float16); O16l = torch.zeros_like(O16h)
+    osc = torch.zeros(1, device=dev)
+    lse = torch.zeros(B * H, TP, device=dev)
+    codes = torch.full((B * T, 3 * D), 77, dtype=torch.uint8, device=dev)
+    cmask = torch.full((B * T, 3 * D // 8), 0xAA, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert native_lib.qatvit_attn_forward_f16(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
+                                              O16h.data_ptr(), O16l.data_ptr(), osc.data_ptr(), codes.data_ptr(), cmask.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+    hd = D // H
+    t = (torch.round(qkv * qp[1]) + zp).view(B, T, 3, H, hd).permute(0, 3, 2, 1, 4).contiguous()      # [b][h][which][t][d]: the code plane's layout
+    assert torch.equal(codes.view(B, H, 3, T, hd).float(), t.clamp(qmin, qmax) - qmin)
+    bits = ((t >= qmin) & (t <= qmax)).view(B, H, 3, T, hd // 8, 8).to(torch.uint8)
+    want = (bits << torch.arange(8, device=dev, dtype=torch.uint8)).sum(-1).to(torch.uint8)
+    assert torch.equal(cmask.view(B, H, 3, T, hd // 8), want)
+    dO = torch.randn(B * T, D, device=dev)
+    outs = []
+    for use_codes in (False, True):
+        delta = torch.zeros(B * H, TP, device=dev)
+        gh = torch.full((B * T, 3 * D), float("nan"), device=dev, dtype=torch.bfloat16)
+        gl = torch.full_like(gh, float("nan"))
+        assert native_lib.qatvit_attn_backward(None if use_codes else qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(),
+                                               lse.data_ptr(), delta.data_ptr(), dO.data_ptr(), gh.data_ptr(), gl.data_ptr(), None,
+                                               codes.data_ptr() if use_codes else None, cmask.data_ptr() if use_codes else None, st) == 0, native_lib.qatvit_last_error()
+        outs.append((gh.clone(), gl.clone()))
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    assert not torch.isnan(outs[1][0].float()).any() and (outs[1][0][0, :9] == 0).all()

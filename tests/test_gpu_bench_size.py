@@ -129,9 +129,14 @@ def test_attention_at_b256(native_lib):
     gh = torch.full((B * T, 3 * D), float("nan"), device=dev, dtype=torch.bfloat16)
     gl = torch.full_like(gh, float("nan"))
     st = _st()
-    assert native_lib.qatvit_attn_forward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(), st) == 0
-    assert native_lib.qatvit_attn_backward(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
-                                           delta.data_ptr(), dO.data_ptr(), gh.data_ptr(), gl.data_ptr(), None, st) == 0
+    O16h = torch.zeros(B * T, D, device=dev, dtype=torch.float16); O16l = torch.zeros_like(O16h); osc = torch.zeros(1, device=dev)
+    codes = torch.zeros(B * T, 3 * D, dtype=torch.uint8, device=dev)
+    cmask = torch.zeros(B * T, 3 * D // 8, dtype=torch.uint8, device=dev)
+    # as in the step: the forward saves the quantised qkv, the backward reads only that (qkv = NULL)
+    assert native_lib.qatvit_attn_forward_f16(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
+                                              O16h.data_ptr(), O16l.data_ptr(), osc.data_ptr(), codes.data_ptr(), cmask.data_ptr(), st) == 0
+    assert native_lib.qatvit_attn_backward(None, qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
+                                           delta.data_ptr(), dO.data_ptr(), gh.data_ptr(), gl.data_ptr(), None, codes.data_ptr(), cmask.data_ptr(), st) == 0
     O = (Oh.float() + Ol.float()).view(B, T, D)
     dqkv = (gh.float() + gl.float()).view(B, T, 3, D)
     assert not torch.isnan(dqkv).any()
@@ -146,6 +151,8 @@ def test_attention_at_b256(native_lib):
         o.backward(dO[b * T:(b + 1) * T].double())
         rg = (fq.grad * mask).view(T, 3, D)
         assert rel_l2(O[b].cpu(), o.detach().cpu()) < 3e-5, b
+        o16 = ((O16h.double() + O16l.double()) * osc.double()).view(B, T, D)[b]
+        assert rel_l2(o16.cpu(), o.detach().cpu()) < 2e-6, b
         for k in range(3):
             assert rel_l2(dqkv[b, :, k].cpu(), rg[:, k].cpu()) < 3e-5, (b, k)
 

@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 kernel stats of the default bench workload (C2): tools/prof_step.sh <tag> [extra bench args]
+# writes gpurun_out/prof_<tag>/ and prints per-kernel time per STEP (29 steps in the trace: 5 warm-up + 15 timed + 9 per-kernel legs)
+TAG=$1; shift
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o c2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-kernel-rates --no-extras "$@" > $OUT/bench.log 2>&1
+echo "rc=$?"
+grep '"metric"' $OUT/bench.log | cut -c1-200
+python3 - "$OUT" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+steps = 29.0
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"total GPU kernel time per step: {tot/steps/1e6:.3f} ms   ({f})")
+for r in rows[:32]:
+    print(f'{float(r["TotalDurationNs"])/steps/1e3:9.1f} us/step {int(r["Calls"])/steps:6.1f} calls/step {float(r["AverageNs"])/1e3:8.1f} us avg  {r["Name"][:110]}')
+PY
