@@ -10,7 +10,7 @@ from .model_registry import (  # noqa: F401
     register_model,
 )
 
-from .export import export_int8, import_int8  # noqa: F401,E402
+from .export import Int8Student, export_int8, import_int8  # noqa: F401,E402
 from .optim import ClipAdamW  # noqa: F401,E402
 
-__all__ = ["ClipAdamW", "export_int8", "import_int8", "PLATFORM", "QATWrapper", "create_model", "create_student", "create_teacher", "list_available_models", "register_model"]
+__all__ = ["ClipAdamW", "Int8Student", "export_int8", "import_int8", "PLATFORM", "QATWrapper", "create_model", "create_student", "create_teacher", "list_available_models", "register_model"]

@@ -47,6 +47,15 @@ __device__ inline void encode8(const float4& a, const float4& b, const AQP& q, u
     codes.x = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
     codes.y = c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24);
 }
+__device__ inline f16x8 decode8_h(const uint2& codes, float off) {
+    f16x8 f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[j] = (_Float16)((float)((codes.x >> (8 * j)) & 0xffu) + off);
+        f[4 + j] = (_Float16)((float)((codes.y >> (8 * j)) & 0xffu) + off);
+    }
+    return f;
+}
 // the same in one pass with the MFMA fragment: t = rint(x / s) + zp is formed once per element
 template <bool F16>
 __device__ inline uint4 quant_encode8(const float4& a, const float4& b, const AQP& q, uint2& codes, uint32_t& mask) {
@@ -325,7 +334,7 @@ __device__ inline void stage_tokens(char* img, const float* base, int T, int ld,
     }
 }
 // the same image from the saved codes (backward): 8 bytes per 8 features instead of 32
-template <int HD, bool TR, int NKT, int NWV = kAW>
+template <int HD, bool TR, int NKT, int NWV = kAW, bool F16 = false>
 __device__ inline void stage_codes(char* img, const uint8_t* base, int T, float off) {
     constexpr int CH = HD / 8;
     constexpr int TOTAL = NKT * 16 * CH, ITERS = (TOTAL + NWV * 64 - 1) / (NWV * 64);
@@ -342,7 +351,10 @@ __device__ inline void stage_codes(char* img, const uint8_t* base, int T, float 
         const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
         if (i < TOTAL) {
             uint4 f = make_uint4(0u, 0u, 0u, 0u);
-            if (tok < T) f = __builtin_bit_cast(uint4, decode8(c[it], off));
+            if (tok < T) {
+                if constexpr (F16) f = __builtin_bit_cast(uint4, decode8_h(c[it], off));
+                else f = __builtin_bit_cast(uint4, decode8(c[it], off));
+            }
             *reinterpret_cast<uint4*>(img + (TR ? tr_off<HD>(tok, ch) : row_off<HD>(tok, ch))) = f;
         }
     }
@@ -397,9 +409,15 @@ __global__ __launch_bounds__(kAW * 64, 4) void k_attn_fwd(const AttnArgs p) {   
     const int64_t sl = (int64_t)T * HD;                                                                       // one slice of the code plane
     uint8_t* const cbase = p.codes ? p.codes + (int64_t)blockIdx.x * 3 * sl : nullptr;                        // this (image, head)'s q slice; k, v follow
     uint8_t* const mbase = p.codes ? p.cmask + (int64_t)blockIdx.x * 3 * (sl / 8) : nullptr;
-    stage_tokens<HD, false, NKT>(sK, base + D, T, ld, q, cbase ? cbase + sl : nullptr, cbase ? mbase + sl / 8 : nullptr);
-    stage_tokens<HD, true, NKT, kAW, true>(sV, base + 2 * D, T, ld, q, cbase ? cbase + 2 * sl : nullptr,
-                                           cbase ? mbase + 2 * (sl / 8) : nullptr);   // fp16 integers: the B operand of the fp16 P.V product
+    const bool from_codes = p.qkv == nullptr;   // uniform: inference - the qkv GEMM's epilogue already wrote the code plane, there is no fp32 qkv
+    if (from_codes) {
+        stage_codes<HD, false, NKT>(sK, cbase + sl, T, q.fqmin - q.zp);
+        stage_codes<HD, true, NKT, kAW, true>(sV, cbase + 2 * sl, T, q.fqmin - q.zp);
+    } else {
+        stage_tokens<HD, false, NKT>(sK, base + D, T, ld, q, cbase ? cbase + sl : nullptr, cbase ? mbase + sl / 8 : nullptr);
+        stage_tokens<HD, true, NKT, kAW, true>(sV, base + 2 * D, T, ld, q, cbase ? cbase + 2 * sl : nullptr,
+                                               cbase ? mbase + 2 * (sl / 8) : nullptr);   // fp16 integers: the B operand of the fp16 P.V product
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.o16_scale) *p.o16_scale = q.s * (1.0f / kOScale);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
@@ -410,6 +428,10 @@ __global__ __launch_bounds__(kAW * 64, 4) void k_attn_fwd(const AttnArgs p) {   
         bf16x8 qf[HD / 32];
 #pragma unroll
         for (int kk = 0; kk < HD / 32; ++kk) {
+            if (from_codes) {
+                qf[kk] = decode8(*reinterpret_cast<const uint2*>(cbase + qrow * HD + 32 * kk + 8 * g), q.fqmin - q.zp);
+                continue;
+            }
             const float4* pq = reinterpret_cast<const float4*>(base + (int64_t)qrow * ld + 32 * kk + 8 * g);
             const float4 qa = pq[0], qb = pq[1];
             if (cbase) {   // uniform.  Every q element of this head passes through exactly one lane here: save its code and mask bit
@@ -457,7 +479,7 @@ __global__ __launch_bounds__(kAW * 64, 4) void k_attn_fwd(const AttnArgs p) {   
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float invl = kPScale / l;      // probabilities enter the MFMA scaled by 2^14 (fp16 range); taken out again below
-        if (g == 0 && qt * 16 + r < T) p.lse[(int64_t)blockIdx.x * TP + qt * 16 + r] = m + logf(l);
+        if (p.lse && g == 0 && qt * 16 + r < T) p.lse[(int64_t)blockIdx.x * TP + qt * 16 + r] = m + logf(l);
         f32x4 o[HD / 16];
 #pragma unroll
         for (int jd = 0; jd < HD / 16; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -482,9 +504,11 @@ __global__ __launch_bounds__(kAW * 64, 4) void k_attn_fwd(const AttnArgs p) {   
             if (act && qq < T) {
                 const int64_t off = ((int64_t)b * T + qq) * D + h * HD + 8 * oc;
                 if (p.O16_hi) store_split8_h(p.O16_hi, p.O16_lo, off, ov, kOScale);
+                if (p.O_hi) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) ov[k] *= q.s;
-                store_split8(p.O_hi, p.O_lo, off, ov);
+                    for (int k = 0; k < 8; ++k) ov[k] *= q.s;
+                    store_split8(p.O_hi, p.O_lo, off, ov);
+                }
             }
         }
     }
@@ -907,7 +931,10 @@ int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B
     AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), reinterpret_cast<__bf16*>(O_hi), reinterpret_cast<__bf16*>(O_lo), lse,
                nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<_Float16*>(O16_hi), reinterpret_cast<_Float16*>(O16_lo), o16_scale,
                reinterpret_cast<uint8_t*>(codes), reinterpret_cast<uint8_t*>(cmask)};
-    if ((codes != nullptr) != (cmask != nullptr) || (codes && qmax - qmin > 255)) { set_error("attention forward: codes / cmask go together (range <= 256 levels)"); return 1; }
+    if ((!qkv && !codes) || (qkv && (codes != nullptr) != (cmask != nullptr)) || (codes && qmax - qmin > 255)) {
+        set_error("attention forward: needs the pre-FQ qkv (codes / cmask are then outputs, both or neither) or the code plane as input (range <= 256 levels)");
+        return 1;
+    }
     if ((O16_hi != nullptr) != (O16_lo != nullptr) || (O16_hi && !o16_scale)) { set_error("attention forward: O16_hi / O16_lo / o16_scale go together"); return 1; }
     return dispatch(0, a, st);
 }

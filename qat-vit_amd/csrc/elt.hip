@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_img_patches(const float* __restrict__ i
         o[2] = (__bf16)fqi(a.z, q, qmin, qmax); o[3] = (__bf16)fqi(a.w, q, qmin, qmax);
         o[4] = (__bf16)fqi(bb.x, q, qmin, qmax); o[5] = (__bf16)fqi(bb.y, q, qmin, qmax);
         o[6] = (__bf16)fqi(bb.z, q, qmin, qmax); o[7] = (__bf16)fqi(bb.w, q, qmin, qmax);
-        *reinterpret_cast<bf16x8*>(out + e) = o;
+        if (out) *reinterpret_cast<bf16x8*>(out + e) = o;
         if (out8) {
             const float sh = q.zp - (float)center;
             signed char c8[8];
@@ -213,6 +213,75 @@ __global__ __launch_bounds__(256) void k_ln_apply_quant(const float* __restrict_
                                   (signed char)((float)o[3] + sh));
             *reinterpret_cast<char4*>(out8 + row * D + c) = o8;
         }
+    }
+}
+
+// ---------------------------------------------------------------- inference: LayerNorm + quantise in one pass
+// out8[row][c] = q(LN(x)[row][c]) - center as int8 with FROZEN qparams (no observer statistics: nothing depends on a global min/max, so the
+// row statistics, the normalisation and the quantisation fuse into one read of x).  The arithmetic is the training path's, operation for
+// operation - row sum / centred sum of squares in k_resid_fq_lnstats' order, ((x - mu) * rstd) * gamma + beta as in k_ln_apply_quant - so
+// the codes equal the fake-quant forward's bit for bit.  row_stride > 1 visits rows 0, row_stride, 2 row_stride, .. only (cls tokens);
+// out8 == nullptr: statistics only (mean / rstd for k_head_fwd).
+template <int NV>
+__global__ __launch_bounds__(256) void k_ln_quant8(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                   const float* __restrict__ qp, int qmin, int qmax, int center, int8_t* __restrict__ out8,
+                                                   float* __restrict__ mean, float* __restrict__ rstd, int64_t nrows, int64_t row_stride, int D) {
+    const QP q = load_qp(qp);
+    const int lane = threadIdx.x & 63;
+    bool act[NV];
+    int cc[NV];
+    float4 g[NV], bb[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        act[j] = c < D;
+        cc[j] = act[j] ? c : 0;
+        g[j] = *reinterpret_cast<const float4*>(gamma + cc[j]);
+        bb[j] = *reinterpret_cast<const float4*>(beta + cc[j]);
+    }
+    const float sh = q.zp - (float)center;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < nrows; i += (int64_t)gridDim.x * 4) {
+        const int64_t row = i * row_stride;
+        float4 v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4*>(x + row * D + cc[j]);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) pin4(v[j]);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (act[j]) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        const float mu = wave_sum(s) / (float)D;
+        float qq = 0.f;
+        float4 cv[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            cv[j] = make_float4(v[j].x - mu, v[j].y - mu, v[j].z - mu, v[j].w - mu);
+            if (act[j]) qq += (cv[j].x * cv[j].x + cv[j].y * cv[j].y) + (cv[j].z * cv[j].z + cv[j].w * cv[j].w);
+        }
+        const float rs = rsqrtf(wave_sum(qq) / (float)D + eps);
+        if (mean && lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        if (out8) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                if (act[j]) {
+                    const char4 o = make_char4((signed char)(fqi(cv[j].x * rs * g[j].x + bb[j].x, q, qmin, qmax) + sh),
+                                               (signed char)(fqi(cv[j].y * rs * g[j].y + bb[j].y, q, qmin, qmax) + sh),
+                                               (signed char)(fqi(cv[j].z * rs * g[j].z + bb[j].z, q, qmin, qmax) + sh),
+                                               (signed char)(fqi(cv[j].w * rs * g[j].w + bb[j].w, q, qmin, qmax) + sh));
+                    *reinterpret_cast<char4*>(out8 + row * D + cc[j]) = o;
+                }
+            }
+        }
+    }
+}
+
+// x[b, 0, :] = cls + pos[0]   (the class-token rows of the embedded sequence; the patch rows come from the patch-embedding GEMM's epilogue)
+__global__ __launch_bounds__(256) void k_cls_rows(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x, int B, int T, int D) {
+    const int64_t n = (int64_t)B * D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / D), c = (int)(i % D);
+        x[(int64_t)b * T * D + c] = cls[c] + pos[c];
     }
 }
 
@@ -630,6 +699,21 @@ int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, 
                           int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8, int center) {
     k_ln_apply_quant<<<flat_grid(M * (D / 4)), 256, 0, st>>>(x, mean, rstd, gamma, beta, qp, qmin, qmax, reinterpret_cast<__bf16*>(out_bf16), M, D,
                                                              reinterpret_cast<int8_t*>(out8), center);
+    return 0;
+}
+
+int launch_ln_quant8(const float* x, const float* gamma, const float* beta, float eps, const float* qp, int qmin, int qmax, int center, void* out8,
+                     float* mean, float* rstd, int64_t nrows, int64_t row_stride, int D, hipStream_t st) {
+    if (D % 4 != 0 || D > 256 * kMaxV) { set_error("ln_quant8: D=%d unsupported (need D%%4==0, D<=768)", D); return 1; }
+    const int nv = (D + 255) / 256, grid = rows_grid(nrows);
+    int8_t* o = reinterpret_cast<int8_t*>(out8);
+    if (nv == 1) k_ln_quant8<1><<<grid, 256, 0, st>>>(x, gamma, beta, eps, qp, qmin, qmax, center, o, mean, rstd, nrows, row_stride, D);
+    else if (nv == 2) k_ln_quant8<2><<<grid, 256, 0, st>>>(x, gamma, beta, eps, qp, qmin, qmax, center, o, mean, rstd, nrows, row_stride, D);
+    else k_ln_quant8<3><<<grid, 256, 0, st>>>(x, gamma, beta, eps, qp, qmin, qmax, center, o, mean, rstd, nrows, row_stride, D);
+    return 0;
+}
+int launch_cls_rows(const float* cls, const float* pos, float* x, int B, int T, int D, hipStream_t st) {
+    k_cls_rows<<<cdiv((int64_t)B * D, 256), 256, 0, st>>>(cls, pos, x, B, T, D);
     return 0;
 }
 

@@ -114,6 +114,14 @@ struct NTArgs {
     _Float16* out16_hi;
     _Float16* out16_lo;
     float* out16_scale;
+    // inference epilogues (frozen qparams in post_qp; no statistics, no pre-FQ tensor):
+    //   mode 6: C[orow] = resid[rrow] + fq(acc)        residual stream update (proj / fc2); embed_np > 0: patch-embedding form, input row
+    //           m = b * np + p goes to token row b * (np + 1) + 1 + p and resid = pos[1 + p]
+    //   mode 7: out8 = clamp(q) - qmin as uint8 in the attention code-plane layout [b][h][which][t][d] (qkv)
+    const float* resid;
+    int embed_np;
+    uint8_t* out8;
+    int code_T, code_hd;
 };
 
 constexpr int kStandIn = 512;
@@ -303,7 +311,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         if (ok[u]) *reinterpret_cast<float4*>(p.C + off[u]) = v[u];
                 } else if constexpr (PM == 4) {
                     const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
-                    const bool w16 = p.out16_hi != nullptr;   // uniform
+                    const bool w16 = p.out16_hi != nullptr, wbf = p.out_hi != nullptr;   // uniform
                     uint32_t w[U][4], wh[U][4], cd[U][4];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -325,7 +333,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         h16.x = (wh[u][0] & 0xffffu) | (wh[u][1] << 16); h16.y = (wh[u][2] & 0xffffu) | (wh[u][3] << 16);
                         l16.x = (wh[u][0] >> 16) | (wh[u][1] & 0xffff0000u); l16.y = (wh[u][2] >> 16) | (wh[u][3] & 0xffff0000u);
                         cc.x = cd[u][0] | (cd[u][1] << 16); cc.y = cd[u][2] | (cd[u][3] << 16);
-                        if (ok[u]) {
+                        if (ok[u] && wbf) {
                             *reinterpret_cast<uint2*>(p.out_hi + off[u]) = hi2;
                             *reinterpret_cast<uint2*>(p.out_lo + off[u]) = lo2;
                             *reinterpret_cast<uint2*>(p.post_code + off[u]) = cc;
@@ -409,9 +417,11 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     hi2.x = (w[0] & 0xffffu) | (w[1] << 16); hi2.y = (w[2] & 0xffffu) | (w[3] << 16);
                     lo2.x = (w[0] >> 16) | (w[1] & 0xffff0000u); lo2.y = (w[2] >> 16) | (w[3] & 0xffff0000u);
                     c2.x = cd[0] | (cd[1] << 16); c2.y = cd[2] | (cd[3] << 16);
-                    *reinterpret_cast<uint2*>(p.out_hi + off) = hi2;
-                    *reinterpret_cast<uint2*>(p.out_lo + off) = lo2;
-                    *reinterpret_cast<uint2*>(p.post_code + off) = c2;
+                    if (p.out_hi) {
+                        *reinterpret_cast<uint2*>(p.out_hi + off) = hi2;
+                        *reinterpret_cast<uint2*>(p.out_lo + off) = lo2;
+                        *reinterpret_cast<uint2*>(p.post_code + off) = c2;
+                    }
                     if (p.out16_hi) {
                         const uint32_t x0 = sLutH[cd[0] & 0xffu], x1 = sLutH[cd[1] & 0xffu], x2 = sLutH[cd[2] & 0xffu], x3 = sLutH[cd[3] & 0xffu];
                         uint2 h16, l16;
@@ -438,6 +448,27 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     }
                     *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
                     *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
+                } else if constexpr (PM == 6) {
+                    const float qs = p.post_qp[0], qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
+                    int64_t orow = row, rrow = row;
+                    if (p.embed_np > 0) { orow = row + row / p.embed_np + 1; rrow = 1 + row % p.embed_np; }
+                    const float4 rs = *reinterpret_cast<const float4*>(p.resid + rrow * p.ldc + n0 + 4 * c4);
+                    bool in;
+                    float4 o;
+                    o.x = rs.x + fq_one(v.x, qinv, qs, qzp, fmin_, fmax_, in);
+                    o.y = rs.y + fq_one(v.y, qinv, qs, qzp, fmin_, fmax_, in);
+                    o.z = rs.z + fq_one(v.z, qinv, qs, qzp, fmin_, fmax_, in);
+                    o.w = rs.w + fq_one(v.w, qinv, qs, qzp, fmin_, fmax_, in);
+                    *reinterpret_cast<float4*>(p.C + orow * p.ldc + n0 + 4 * c4) = o;
+                } else if constexpr (PM == 7) {
+                    const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
+                    const float cv[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk = __builtin_amdgcn_cvt_pk_u8_f32(fminf(fmaxf(rintf(cv[e] * qinv) + qzp, fmin_), fmax_) - fmin_, e, pk);
+                    const int c = n0 + 4 * c4, Dm = p.N / 3, which = c / Dm, hh = (c % Dm) / p.code_hd, d = c % p.code_hd, Hh = Dm / p.code_hd;
+                    const int64_t bb = row / p.code_T, tt = row % p.code_T;
+                    *reinterpret_cast<uint32_t*>(p.out8 + ((((bb * Hh + hh) * 3 + which) * p.code_T + tt) * p.code_hd + d)) = pk;
                 } else if constexpr (PM == 2) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     const float cv[4] = {v.x, v.y, v.z, v.w};
@@ -830,12 +861,16 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
         (void)once;                                                                                                      \
         k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16><<<grid, WM * WN * 64, lds, st>>>(a);          \
     } while (0)
-    if constexpr (ABL != 0 || F16) {   // (the fp16 form is only used with the plain epilogue: proj / fc2 forward)
+    if constexpr (ABL != 0) {
         QV_PM(0);
-    } else if constexpr (I8) {   // the grid x grid forward GEMMs only use these three epilogues
+    } else if constexpr (F16) {   // proj / fc2 forward: plain epilogue (training: the observer needs the pre-FQ tensor) or the fused residual update (inference)
+        if (a.pm == 6) QV_PM(6); else QV_PM(0);
+    } else if constexpr (I8) {   // the grid x grid forward GEMMs
         switch (a.pm) {
             case 3: QV_PM(3); break;
             case 4: QV_PM(4); break;
+            case 6: QV_PM(6); break;
+            case 7: QV_PM(7); break;
             default: QV_PM(0); break;
         }
     } else {
@@ -885,8 +920,8 @@ static void nt_br_launch(const NTArgs& a, int grid, hipStream_t st) {
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
                    const void* B_lo, const NTPost* post, bool f16) {
-    if (f16 && (!A_lo || B_lo || post || N % 384 != 0 || K % 32 != 0)) {
-        set_error("gemm_nt: the fp16 form takes a split A operand, N %% 384 == 0, the plain epilogue (N=%d K=%d)", N, K);
+    if (f16 && (!A_lo || B_lo || (post && post->mode != 6) || N % 384 != 0 || K % 32 != 0)) {
+        set_error("gemm_nt: the fp16 form takes a split A operand, N %% 384 == 0, the plain or the residual (mode 6) epilogue (N=%d K=%d)", N, K);
         return 1;
     }
     if (M < 1 || N % 128 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) {
@@ -896,7 +931,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
              reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
-             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
     if (post && post->mode >= 3) {
         a.post_mode = post->mode;
         a.pm = post->mode;
@@ -904,7 +939,10 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
         a.post_code = reinterpret_cast<uint16_t*>(post->code);
         a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
-        if (post->mode > 5 || (post->mode != 3 && (!a.post_qp || !a.out_hi || !a.out_lo || !a.post_code || a.post_qmax - a.post_qmin >= 256))) {
+        a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
+        const bool ok6 = post->mode == 6 && f16 && a.post_qp && a.resid && C;
+        const bool ok345 = post->mode <= 5 && (post->mode == 3 || (a.post_qp && a.out_hi && a.out_lo && a.post_code && a.post_qmax - a.post_qmin < 256));
+        if (!ok6 && !ok345) {
             set_error("gemm_nt: incomplete arguments for epilogue mode %d", post->mode);
             return 1;
         }
@@ -962,7 +1000,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     // grid A, 4 stages x 13 KiB, epilogue slab 99 KiB
     constexpr int kLdsBr2 = 150 * 1024, kLdsBr1 = 100 * 1024;
     if (f16) {
-        if (nt_breg() && K % 64 == 0) { nt_br_launch<2, 4, false, true, kLdsBr2>(a, cdiv(M, 208) * (N / 384), st); return 0; }
+        if (nt_breg() && K % 64 == 0 && a.pm == 0) { nt_br_launch<2, 4, false, true, kLdsBr2>(a, cdiv(M, 208) * (N / 384), st); return 0; }
         constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
         nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);
         return 0;
@@ -1051,23 +1089,27 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A8), nullptr, reinterpret_cast<const __bf16*>(B8), nullptr, C, M, N, K / 2, lda / 2, ldb / 2, ldc, s1, s2,
              col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, 0, 0, wsum, a_qp, center, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr,
-             nullptr, nullptr, nullptr};
+             nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
     if (post) {
-        if (post->mode != 3 && post->mode != 4) { set_error("gemm_nt_i8: epilogue mode %d not available", post->mode); return 1; }
+        if (post->mode != 3 && post->mode != 4 && post->mode != 6 && post->mode != 7) { set_error("gemm_nt_i8: epilogue mode %d not available", post->mode); return 1; }
         a.post_mode = a.pm = post->mode;
         a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax;
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
         a.post_code = reinterpret_cast<uint16_t*>(post->code);
         a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
-        if (post->mode == 4 && (!a.post_qp || !a.out_hi || !a.out_lo || !a.post_code || a.post_qmax - a.post_qmin >= 256)) {
-            set_error("gemm_nt_i8: incomplete arguments for epilogue mode 4");
+        a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
+        const bool full4 = a.out_hi && a.out_lo && a.post_code, half4 = !a.out_hi && !a.out_lo && !a.post_code && a.out16_hi && a.out16_lo && a.out16_scale;
+        if ((post->mode == 4 && (!a.post_qp || !(full4 || half4) || a.post_qmax - a.post_qmin >= 256)) ||
+            (post->mode == 6 && (!a.post_qp || !a.resid || !C)) ||
+            (post->mode == 7 && (!a.post_qp || !a.out8 || a.code_T < 1 || a.code_hd < 8 || (N / 3) % a.code_hd != 0 || a.post_qmax - a.post_qmin >= 256))) {
+            set_error("gemm_nt_i8: incomplete arguments for epilogue mode %d", post->mode);
             return 1;
         }
     } else if (!C) {
         set_error("gemm_nt_i8: null output");
         return 1;
     }
-    if (nt_breg() && a.K % 64 == 0) { nt_br_launch<1, 4, true, false, 100 * 1024>(a, cdiv(M, 208) * (N / 384), st); return 0; }
+    if (nt_breg() && a.K % 64 == 0 && a.pm != 6 && a.pm != 7) { nt_br_launch<1, 4, true, false, 100 * 1024>(a, cdiv(M, 208) * (N / 384), st); return 0; }
     constexpr size_t lds = 3 * (208 + 384) * 64;
     nt_launch<1, 3, 1, 13, 1, 0, 8, 3, 32, 0, true>(a, cdiv(M, 208) * (N / 384), lds, st);
     return 0;

@@ -47,6 +47,15 @@ struct NTPost {
     void* out16_hi = nullptr;
     void* out16_lo = nullptr;
     float* out16_scale = nullptr;
+    // inference epilogues (qp = FROZEN qparams of the output's quantizer; no statistics, the pre-FQ tensor never exists):
+    //   6: C[orow] = resid[rrow] + fq(acc)   the residual-stream update of proj / fc2 (embed_np > 0: the patch-embedding form - input row
+    //      b * np + p goes to token row b * (np + 1) + 1 + p, resid = pos_embed rows 1 + p)
+    //   7: out8 = clamp(q) - qmin as uint8 in the attention code-plane layout [b][h][which][t][d]   (qkv; code_T tokens, code_hd = head_dim)
+    // (mode 4 with out_hi / out_lo / code all NULL writes the fp16 pair only: fc1 of the inference forward)
+    const float* resid = nullptr;
+    int embed_np = 0;
+    void* out8 = nullptr;
+    int code_T = 0, code_hd = 0;
 };
 
 // ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)
@@ -73,6 +82,11 @@ inline int64_t ln_maskbits_bytes(int64_t M, int D) { return M * ((D + 255) / 256
 struct LnBwdNext { const void* maskbits; const float* colscale; void* out_hi; void* out_lo; };
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
                           int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8 = nullptr, int center = 0);
+// inference: LayerNorm + quantise (frozen qparams) in one pass -> int8 (q - center); out8 == nullptr: row statistics only; row_stride > 1: every
+// row_stride-th row (cls tokens)
+int launch_ln_quant8(const float* x, const float* gamma, const float* beta, float eps, const float* qp, int qmin, int qmax, int center, void* out8,
+                     float* mean, float* rstd, int64_t nrows, int64_t row_stride, int D, hipStream_t st);
+int launch_cls_rows(const float* cls, const float* pos, float* x, int B, int T, int D, hipStream_t st);
 int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, void* G_hi, void* G_lo, int64_t n, hipStream_t st);
 int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, const float* col_scale, int ncols,
                     void* dst_hi, void* dst_lo, int64_t n, hipStream_t st);
