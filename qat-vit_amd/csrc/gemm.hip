@@ -122,6 +122,9 @@ struct NTArgs {
     int embed_np;
     uint8_t* out8;
     int code_T, code_hd;
+    // 4-wave tiles, two workgroups per CU: delay the second workgroup of every CU (dispatch slots 256 .. 511) by this many shader cycles so
+    // that one workgroup's store-bound epilogue runs under the other's k-loop instead of both epilogues colliding (0 = off)
+    int stagger_cycles;
 };
 
 constexpr int kStandIn = 512;
@@ -552,6 +555,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     const int tilesN = p.N / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
+    if (WM * WN == 4 && p.stagger_cycles > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {   // (uniform; bounded: the clock always advances)
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)p.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+    }
 
     const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(p.A0, (int64_t)p.M * p.lda * 2);
     const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(TA == 2 ? p.A1 : p.A0, (int64_t)p.M * p.lda * 2);
@@ -931,7 +938,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
              reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
-             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
+             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0};
     if (post && post->mode >= 3) {
         a.post_mode = post->mode;
         a.pm = post->mode;
@@ -991,7 +998,9 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     // (128-row tiles: 394 tiles = 2 rounds at 77 %), and a 208-row tile moves 7.7 B into LDS per row and k against 10 B for 128 rows.
     static const int tall = getenv("QATVIT_NT_TALL") ? atoi(getenv("QATVIT_NT_TALL")) : 1;
     static const int pm5_4w = getenv("QATVIT_NT_PM5_4W") ? atoi(getenv("QATVIT_NT_PM5_4W")) : 0;
+    static const int stagger = getenv("QATVIT_NT_STAGGER") ? atoi(getenv("QATVIT_NT_STAGGER")) : 0;   // shader cycles (4-wave tiles only)
     if ((tall == 4 || (pm5_4w && a.pm == 5)) && A_lo && N % 384 == 0 && K % 32 == 0) {   // 112 x 384 tiles, 4 waves, 2 stages (76 KiB): two workgroups per CU
+        a.stagger_cycles = stagger;
         constexpr size_t lds4 = 2 * (2 * 112 + 384) * 64;
         nt_launch<2, 2, 1, 7, 1, 0, 4, 6, 32, 0>(a, cdiv(M, 112) * (N / 384), lds4, st);
         return 0;
@@ -1089,7 +1098,7 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A8), nullptr, reinterpret_cast<const __bf16*>(B8), nullptr, C, M, N, K / 2, lda / 2, ldb / 2, ldc, s1, s2,
              col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, 0, 0, wsum, a_qp, center, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr,
-             nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
+             nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0};
     if (post) {
         if (post->mode != 3 && post->mode != 4 && post->mode != 6 && post->mode != 7) { set_error("gemm_nt_i8: epilogue mode %d not available", post->mode); return 1; }
         a.post_mode = a.pm = post->mode;
@@ -1108,6 +1117,14 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
     } else if (!C) {
         set_error("gemm_nt_i8: null output");
         return 1;
+    }
+    static const int i8_4w = getenv("QATVIT_NT_I8_4W") ? atoi(getenv("QATVIT_NT_I8_4W")) : 0;   // 112 x 384 tiles, 4 waves, 2 stages (62 KiB): two workgroups per CU
+    if (i8_4w) {
+        static const int stagger = getenv("QATVIT_NT_STAGGER") ? atoi(getenv("QATVIT_NT_STAGGER")) : 0;
+        a.stagger_cycles = stagger;
+        constexpr size_t lds4 = 2 * (112 + 384) * 64;
+        nt_launch<1, 2, 1, 7, 1, 0, 4, 6, 32, 0, true>(a, cdiv(M, 112) * (N / 384), lds4, st);
+        return 0;
     }
     if (nt_breg() && a.K % 64 == 0 && a.pm != 6 && a.pm != 7) { nt_br_launch<1, 4, true, false, 100 * 1024>(a, cdiv(M, 208) * (N / 384), st); return 0; }
     constexpr size_t lds = 3 * (208 + 384) * 64;
