@@ -230,6 +230,13 @@ static bool attn_codes(const qatvit_cfg& c) {
     return on != 0 && c.act_qmax - c.act_qmin <= 255;
 }
 
+// QATVIT_LNB_FUSE=0: the LayerNorm backward as its own kernel behind the fc1 / qkv dgrad GEMM (re-reads the fp32 gradient those wrote) instead
+// of inside their epilogue (embed_dim 384 only: the 208 x 384 tile holds whole rows)
+static bool lnb_fuse() {
+    static const int on = getenv("QATVIT_LNB_FUSE") ? atoi(getenv("QATVIT_LNB_FUSE")) : 1;
+    return on != 0;
+}
+
 struct Ctx {
     const qatvit_cfg& c;
     Dims d;
@@ -578,12 +585,22 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             if (x.linear_wgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.blk<void>(p.h2q, i), nullptr, x.act_qp(x.aidx(i, AB_N2)),
                                BG(i, B_FC1W), BG(i, B_FC1B)))
                 return 1;
-            if (x.linear_dgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.at<float>(p.dH))) return 1;
             const LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dYh, dYl};
-            if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_mid, i), x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i),
-                                 x.bprm(i, B_N2W), x.bprm(i, B_N2B), x.act_qp(x.aidx(i, AB_N2)), qa, qb, dxA, dxB, BG(i, B_N2W), BG(i, B_N2B), d.M,
-                                 d.D, d.T, 0, st, ln_fuse ? &nx_proj : nullptr))
-                return 1;
+            const bool lnb = ln_fuse && lnb_fuse() && d.D == 384;   // the dgrad tile holds whole LayerNorm rows: its epilogue IS the LayerNorm backward
+            if (lnb) {
+                NTPost post{};
+                post.mode = 8; post.qp = x.act_qp(x.aidx(i, AB_N2)); post.qmin = qa; post.qmax = qb;
+                post.lnb_x = x.blk<float>(p.x_mid, i); post.lnb_mean = x.blk<float>(p.mean2, i); post.lnb_rstd = x.blk<float>(p.rstd2, i);
+                post.lnb_gamma = x.bprm(i, B_N2W); post.lnb_beta = x.bprm(i, B_N2B); post.lnb_dx_in = dxA; post.lnb_dgamma = BG(i, B_N2W); post.lnb_dbeta = BG(i, B_N2B);
+                post.lnb_nmask = nx_proj.maskbits; post.colscale = nx_proj.colscale; post.out_hi = dYh; post.out_lo = dYl;
+                if (x.linear_dgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, dxB, &post)) return 1;
+            } else {
+                if (x.linear_dgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.at<float>(p.dH))) return 1;
+                if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_mid, i), x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i),
+                                     x.bprm(i, B_N2W), x.bprm(i, B_N2B), x.act_qp(x.aidx(i, AB_N2)), qa, qb, dxA, dxB, BG(i, B_N2W), BG(i, B_N2B), d.M,
+                                     d.D, d.T, 0, st, ln_fuse ? &nx_proj : nullptr))
+                    return 1;
+            }
             // ---- attention branch (dxB = gradient w.r.t. x_mid)
             if (!ln_fuse) launch_mask_bwd(0, dxB, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, x.dy_colscale(w_proj), d.D, dYh, dYl, d.M * d.D, st);
             if (x.linear_wgrad(dYh, dYl, M, w_proj, x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), nullptr, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
@@ -596,13 +613,22 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             if (x.linear_wgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.blk<void>(p.h1q, i), nullptr, x.act_qp(x.aidx(i, AB_N1)),
                                BG(i, B_QKVW), BG(i, B_QKVB)))
                 return 1;
-            if (x.linear_dgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.at<float>(p.dH))) return 1;
             const LnBwdNext nx_fc2{i > 0 ? x.blk<void>(p.m2, i - 1) : nullptr, i > 0 ? x.dy_colscale(x.widx(i - 1, WB_FC2)) : nullptr, dYh, dYl};
-            if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_in, i), x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i),
-                                 x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)), qa, qb, dxB, dxA, BG(i, B_N1W), BG(i, B_N1B), d.M,
-                                 d.D, d.T, 0, st,
-                                 (ln_fuse && i > 0) ? &nx_fc2 : nullptr))
-                return 1;
+            if (lnb) {
+                NTPost post{};
+                post.mode = 8; post.qp = x.act_qp(x.aidx(i, AB_N1)); post.qmin = qa; post.qmax = qb;
+                post.lnb_x = x.blk<float>(p.x_in, i); post.lnb_mean = x.blk<float>(p.mean1, i); post.lnb_rstd = x.blk<float>(p.rstd1, i);
+                post.lnb_gamma = x.bprm(i, B_N1W); post.lnb_beta = x.bprm(i, B_N1B); post.lnb_dx_in = dxB; post.lnb_dgamma = BG(i, B_N1W); post.lnb_dbeta = BG(i, B_N1B);
+                if (i > 0) { post.lnb_nmask = nx_fc2.maskbits; post.colscale = nx_fc2.colscale; post.out_hi = dYh; post.out_lo = dYl; }
+                if (x.linear_dgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, dxA, &post)) return 1;
+            } else {
+                if (x.linear_dgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.at<float>(p.dH))) return 1;
+                if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_in, i), x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i),
+                                     x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)), qa, qb, dxB, dxA, BG(i, B_N1W), BG(i, B_N1B), d.M,
+                                     d.D, d.T, 0, st,
+                                     (ln_fuse && i > 0) ? &nx_fc2 : nullptr))
+                    return 1;
+            }
         } else {
             launch_embed_bwd(dxA, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, G(P_POS), G(P_CLS), x.at<void>(p.dY0_hi), x.at<void>(p.dY0_lo), d.B,
                              d.T, d.D, st);

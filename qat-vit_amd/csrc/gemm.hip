@@ -125,6 +125,21 @@ struct NTArgs {
     // 4-wave tiles, two workgroups per CU: delay the second workgroup of every CU (dispatch slots 256 .. 511) by this many shader cycles so
     // that one workgroup's store-bound epilogue runs under the other's k-loop instead of both epilogues colliding (0 = off)
     int stagger_cycles;
+    // mode 8 (N == BN == D: the tile holds whole rows): the LayerNorm BACKWARD of the tensor this dgrad differentiates, fused - the fp32
+    // gradient w.r.t. the fake-quantised LayerNorm output never goes to memory.  With dH = acc * alpha:
+    //   g = dH * mask(LN(x)) ; dx_out = dx_in + LNbwd(g) ; dgamma += sum_rows g * xhat ; dbeta += sum_rows g ;
+    //   out_hi / out_lo (optional) = split(dx_out * nmask * post_colscale): the masked gradient of the NEXT (earlier) branch output
+    // (what k_ln_bwd_fq<1, NV, 8, true> computes from a dH it reads back from memory).  post_qp / post_qmin / post_qmax = the LayerNorm
+    // output's quantizer; C = dx_out.
+    const float* lnb_x;
+    const float* lnb_mean;
+    const float* lnb_rstd;
+    const float* lnb_gamma;
+    const float* lnb_beta;
+    const float* lnb_dx_in;
+    float* lnb_dgamma;
+    float* lnb_dbeta;
+    const unsigned long long* lnb_nmask;
 };
 
 constexpr int kStandIn = 512;
@@ -227,6 +242,23 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
         if constexpr (I8) return (float)(acc[i][j][e] + corr[j]);
         else return acc[i][j][e];
     };
+    // mode 8: per-thread state of the fused LayerNorm backward (gamma / beta / next-branch column scale once per thread; column-sum accumulators)
+    struct QPe { float s, inv, zp, on; };
+    auto lnb_in = [](float x, const QPe& qq, float fmin_, float fmax_) {
+        const float t = rintf(x * qq.inv) + qq.zp;
+        return (t >= fmin_ && t <= fmax_) || qq.on == 0.f;
+    };
+    float4 lnb_ag[2], lnb_ab[2];
+    if constexpr (PM == 8) {
+        static_assert(RING == 0 || RING >= SLAB * LDC * 4 + 2048 + 3 * BN * 4, "ring too small for the mode-8 row operands");
+        float* sRow = sC + SLAB * LDC + 512;   // published by the first slab's staging barrier
+        for (int c = tid; c < BN; c += NW * 64) {
+            sRow[c] = p.lnb_gamma[c];
+            sRow[BN + c] = p.lnb_beta[c];
+            sRow[2 * BN + c] = p.post_colscale ? p.post_colscale[c] : 1.f;
+        }
+        lnb_ag[0] = lnb_ag[1] = lnb_ab[0] = lnb_ab[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if constexpr (PM == 3) {   // statistics only: no staging, no stores
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -261,7 +293,9 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     const int rl = rt - SLAB * h + 4 * g + e;
                     const float v = accv(i, j, e) * ca[j] + cb[j];
                     sC[rl * LDC + cl] = v;
-                    if (m0 + SLAB * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+                    if constexpr (PM != 6 && PM != 7 && PM != 8) {   // (the inference epilogues and the fused LayerNorm backward feed no observer)
+                        if (m0 + SLAB * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+                    }
                 }
             }
         }
@@ -280,6 +314,87 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
         lds_barrier();
         constexpr int C4 = BN / 4;              // float4 per staged row
         const int rows_h = BM - SLAB * h < SLAB ? BM - SLAB * h : SLAB;
+        if constexpr (PM == 8) {
+            // one wave per staged row (k_ln_bwd_fq's lane -> column map: lane * 4 + 256 j), the next row's global operands requested one row ahead
+            static_assert(BN == 384, "the fused LayerNorm backward needs the whole 384-column row in the tile");
+            constexpr int NVL = 2;
+            const QPe q{p.post_qp[0], p.post_qp[1], p.post_qp[2], p.post_qp[3]};
+            const float fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
+            const bool a1 = lane < 32;                         // column group 1 (256 .. 383) exists for the first 32 lanes
+            const int c0 = lane * 4, c1 = a1 ? 256 + lane * 4 : 0;
+            const bool fuse = p.out_hi != nullptr;
+            const float* sGm = sC + SLAB * LDC + 512;          // gamma | beta | next-branch column scale, staged once per tile (behind the table area)
+            const float* sBt = sGm + BN;
+            const float* sCs = sBt + BN;
+            auto rowof = [&](int rl) { const int64_t row = (int64_t)m0 + SLAB * h + rl; return (rl < rows_h && row < p.M) ? row : (int64_t)-1; };
+            float4 xn[NVL], pn[NVL];
+            float mun = 0.f, rsn = 0.f;
+            auto fetch = [&](int64_t row) {
+                const int64_t rr = row < 0 ? (int64_t)m0 : row;   // (branch-free: a dead slot reads the tile's first row)
+                xn[0] = *reinterpret_cast<const float4*>(p.lnb_x + rr * BN + c0);
+                xn[1] = *reinterpret_cast<const float4*>(p.lnb_x + rr * BN + c1);
+                pn[0] = *reinterpret_cast<const float4*>(p.lnb_dx_in + rr * BN + c0);
+                pn[1] = *reinterpret_cast<const float4*>(p.lnb_dx_in + rr * BN + c1);
+                mun = p.lnb_mean[rr];
+                rsn = p.lnb_rstd[rr];
+            };
+            fetch(rowof(wave));
+            for (int rl = wave; rl < rows_h; rl += NW) {
+                const int64_t row = rowof(rl);
+                const float4 xv[NVL] = {xn[0], xn[1]}, pv[NVL] = {pn[0], pn[1]};
+                const float mu = mun, rs = rsn;
+                if (rl + NW < rows_h) fetch(rowof(rl + NW));   // the next row's operands travel while this row is processed
+                if (row < 0) continue;                          // wave-uniform
+                unsigned long long mk[NVL][4];
+                if (fuse) {
+#pragma unroll
+                    for (int j = 0; j < NVL; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) mk[j][e] = p.lnb_nmask[(row * NVL + j) * 4 + e];
+                }
+                float4 xh[NVL], gy[NVL];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NVL; ++j) {
+                    const int c = j == 0 ? c0 : c1;
+                    const float4 g = *reinterpret_cast<const float4*>(sGm + c), b = *reinterpret_cast<const float4*>(sBt + c);
+                    float4 d = *reinterpret_cast<const float4*>(sC + rl * LDC + c);
+                    xh[j] = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
+                    const bool i0 = lnb_in(xh[j].x * g.x + b.x, q, fmin_, fmax_), i1 = lnb_in(xh[j].y * g.y + b.y, q, fmin_, fmax_),
+                               i2 = lnb_in(xh[j].z * g.z + b.z, q, fmin_, fmax_), i3 = lnb_in(xh[j].w * g.w + b.w, q, fmin_, fmax_);
+                    d.x = i0 ? d.x : 0.f; d.y = i1 ? d.y : 0.f; d.z = i2 ? d.z : 0.f; d.w = i3 ? d.w : 0.f;
+                    gy[j] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+                    if (j == 0 || a1) {
+                        lnb_ag[j].x += d.x * xh[j].x; lnb_ag[j].y += d.y * xh[j].y; lnb_ag[j].z += d.z * xh[j].z; lnb_ag[j].w += d.w * xh[j].w;
+                        lnb_ab[j].x += d.x; lnb_ab[j].y += d.y; lnb_ab[j].z += d.z; lnb_ab[j].w += d.w;
+                        s1 += (gy[j].x + gy[j].y) + (gy[j].z + gy[j].w);
+                        s2 += (gy[j].x * xh[j].x + gy[j].y * xh[j].y) + (gy[j].z * xh[j].z + gy[j].w * xh[j].w);
+                    }
+                }
+                const float m1 = wave_sum(s1) / (float)BN, m2 = wave_sum(s2) / (float)BN;
+#pragma unroll
+                for (int j = 0; j < NVL; ++j) {
+                    if (j == 1 && !a1) continue;
+                    const int c = j == 0 ? c0 : c1;
+                    float4 o = make_float4((gy[j].x - m1 - xh[j].x * m2) * rs, (gy[j].y - m1 - xh[j].y * m2) * rs,
+                                           (gy[j].z - m1 - xh[j].z * m2) * rs, (gy[j].w - m1 - xh[j].w * m2) * rs);
+                    o.x += pv[j].x; o.y += pv[j].y; o.z += pv[j].z; o.w += pv[j].w;
+                    *reinterpret_cast<float4*>(p.C + row * BN + c) = o;
+                    if (fuse) {
+                        const float4 cs = *reinterpret_cast<const float4*>(sCs + c);
+                        const float f0 = (mk[j][0] >> lane) & 1 ? o.x * cs.x : 0.f, f1 = (mk[j][1] >> lane) & 1 ? o.y * cs.y : 0.f,
+                                    f2 = (mk[j][2] >> lane) & 1 ? o.z * cs.z : 0.f, f3 = (mk[j][3] >> lane) & 1 ? o.w * cs.w : 0.f;
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 hh, ll;
+                        hh[0] = (__bf16)f0; hh[1] = (__bf16)f1; hh[2] = (__bf16)f2; hh[3] = (__bf16)f3;
+                        ll[0] = (__bf16)(f0 - (float)hh[0]); ll[1] = (__bf16)(f1 - (float)hh[1]); ll[2] = (__bf16)(f2 - (float)hh[2]); ll[3] = (__bf16)(f3 - (float)hh[3]);
+                        *reinterpret_cast<bf16x4*>(p.out_hi + row * BN + c) = hh;
+                        *reinterpret_cast<bf16x4*>(p.out_lo + row * BN + c) = ll;
+                    }
+                }
+            }
+            continue;   // next slab (the lds_barrier at its top orders these reads of sC before the next staging)
+        }
 #ifndef QV_EPI_U
 #define QV_EPI_U 4
 #endif
@@ -488,6 +603,27 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     *reinterpret_cast<float4*>(p.C + off) = v;
                 }
             }
+        }
+    }
+    if constexpr (PM == 8) {   // dgamma / dbeta: the tile's column sums meet in LDS, one atomic per column per tile
+        lds_barrier();
+        float* sg = reinterpret_cast<float*>(smem);          // [NW][BN]
+        float* sb = sg + NW * BN;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 0 || lane < 32) {
+                const int c = lane * 4 + 256 * j;
+                *reinterpret_cast<float4*>(sg + wave * BN + c) = lnb_ag[j];
+                *reinterpret_cast<float4*>(sb + wave * BN + c) = lnb_ab[j];
+            }
+        }
+        lds_barrier();
+        for (int c = tid; c < BN; c += NW * 64) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { a += sg[w * BN + c]; b += sb[w * BN + c]; }
+            atomicAdd(&p.lnb_dgamma[c], a);
+            atomicAdd(&p.lnb_dbeta[c], b);
         }
     }
     if (p.stats) {
@@ -708,9 +844,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     // the staging slab (+ LUT, + the codes of mode 5) must fit inside the ring; mode 5 prefers 48 rows with two code buffers to 64 with one
     constexpr int RING_ = NSTAGE * STAGE;
     constexpr bool PM5_48 = PM == 5 && RING_ >= 48 * (BN + 4) * 4 + 1024 + 2 * 48 * BN * 2 && RING_ < 64 * (BN + 4) * 4 + 1024 + 2 * 64 * BN * 2;
-    constexpr int SLAB = PM5_48 ? 48 : RING_ >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;
-    static_assert(NSTAGE * STAGE >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
-    nt_epilogue<WM, WN, TM, TNT, SLAB, PM, NSTAGE * STAGE, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
+    // mode 8 (fused LayerNorm backward) stages 96 rows at a time in 160 KiB of LDS (the launch asks for it): 84 instead of 108 accumulator
+    // registers are still live while the first slab's rows are processed
+    constexpr int SLAB = PM == 8 ? 96 : PM5_48 ? 48 : RING_ >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;
+    constexpr int EPI_LDS = PM == 8 ? 160 * 1024 : NSTAGE * STAGE;
+    static_assert(EPI_LDS >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
+    nt_epilogue<WM, WN, TM, TNT, SLAB, PM, EPI_LDS, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
 
 // ============================================================================ NT, B operand through registers
@@ -887,6 +1026,9 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
             case 3: QV_PM(3); break;
             case 4: QV_PM(4); break;
             case 5: QV_PM(5); break;
+            case 8:
+                if constexpr (TA == 2 && TB == 1 && WM == 1 && WN == 8 && TM == 13 && TNT == 3) QV_PM(8);   // (whole 384-column rows per tile only)
+                break;
             default: QV_PM(0); break;
         }
     }
@@ -938,7 +1080,8 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
              reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
-             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0};
+             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+             nullptr, nullptr};
     if (post && post->mode >= 3) {
         a.post_mode = post->mode;
         a.pm = post->mode;
@@ -947,6 +1090,19 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         a.post_code = reinterpret_cast<uint16_t*>(post->code);
         a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
         a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
+        a.lnb_x = post->lnb_x; a.lnb_mean = post->lnb_mean; a.lnb_rstd = post->lnb_rstd; a.lnb_gamma = post->lnb_gamma; a.lnb_beta = post->lnb_beta;
+        a.lnb_dx_in = post->lnb_dx_in; a.lnb_dgamma = post->lnb_dgamma; a.lnb_dbeta = post->lnb_dbeta;
+        a.lnb_nmask = reinterpret_cast<const unsigned long long*>(post->lnb_nmask);
+        if (post->mode == 8) {
+            if (!(A_lo && !f16 && !B_lo && N == 384 && K % 32 == 0 && ldc == 384 && C && a.post_qp && a.lnb_x && a.lnb_mean && a.lnb_rstd && a.lnb_gamma && a.lnb_beta &&
+                  a.lnb_dx_in && a.lnb_dgamma && a.lnb_dbeta && (!a.out_hi || (a.out_lo && a.lnb_nmask)))) {
+                set_error("gemm_nt: epilogue mode 8 needs a split A operand, N == ldc == 384 and the LayerNorm operands");
+                return 1;
+            }
+            constexpr size_t lds8 = 160 * 1024;   // ring 150 KiB; the epilogue's 96-row slab + row operands need 156 KiB
+            nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208), lds8, st);
+            return 0;
+        }
         const bool ok6 = post->mode == 6 && f16 && a.post_qp && a.resid && C;
         const bool ok345 = post->mode <= 5 && (post->mode == 3 || (a.post_qp && a.out_hi && a.out_lo && a.post_code && a.post_qmax - a.post_qmin < 256));
         if (!ok6 && !ok345) {
@@ -1098,7 +1254,7 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
     }
     NTArgs a{reinterpret_cast<const __bf16*>(A8), nullptr, reinterpret_cast<const __bf16*>(B8), nullptr, C, M, N, K / 2, lda / 2, ldb / 2, ldc, s1, s2,
              col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, 0, 0, wsum, a_qp, center, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr,
-             nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0};
+             nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (post) {
         if (post->mode != 3 && post->mode != 4 && post->mode != 6 && post->mode != 7) { set_error("gemm_nt_i8: epilogue mode %d not available", post->mode); return 1; }
         a.post_mode = a.pm = post->mode;

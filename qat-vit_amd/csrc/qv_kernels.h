@@ -56,6 +56,19 @@ struct NTPost {
     int embed_np = 0;
     void* out8 = nullptr;
     int code_T = 0, code_hd = 0;
+    // mode 8 (split-A dgrad whose output rows are whole LayerNorm rows, N == 384): the LayerNorm backward fused into the epilogue -
+    // C = dx_out = dx_in + LNbwd(acc * alpha * mask(LN(x))), dgamma / dbeta accumulated, and (out_hi / out_lo non-null) the masked (hi, lo)
+    // copy of dx_out for the next branch: nmask = that branch output's STE mask words, colscale = its per-channel weight scale.
+    // qp / qmin / qmax = the LayerNorm output's quantizer.
+    const float* lnb_x = nullptr;
+    const float* lnb_mean = nullptr;
+    const float* lnb_rstd = nullptr;
+    const float* lnb_gamma = nullptr;
+    const float* lnb_beta = nullptr;
+    const float* lnb_dx_in = nullptr;
+    float* lnb_dgamma = nullptr;
+    float* lnb_dbeta = nullptr;
+    const void* lnb_nmask = nullptr;
 };
 
 // ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)
