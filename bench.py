@@ -310,9 +310,14 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(args.graph)},
         }
     # ---- per-kernel legs: every rank runs the same extra steps (collectives stay matched), rank 0 times its own launches
+    KINDS = {1: "k_gemm_nt split-A, plain epilogue (proj / fc2 forward on fp16 pairs, proj dgrad on bf16 pairs)",
+             4: "k_gemm_nt split-A dgrad + LayerNorm backward fused into the epilogue (fc1 / qkv dgrad, mode 8)",
+             5: "k_gemm_nt split-A fc2 dgrad + GELU backward fused into the epilogue (mode 5)",
+             2: "k_gemm_nt grid A on int8 MFMA (patch-embed, qkv, fc1 forward)",
+             3: "k_gemm_tn (all weight gradients; split dY, grid or split X; 2-3 bf16 passes issued)"}
     prof = {}
     nprof = 0 if args.graph else 3
-    for kind in (1, 2, 3):
+    for kind in KINDS:
         if nprof == 0:
             break
         if rank == 0:
@@ -321,42 +326,43 @@ def main():
             for _ in range(nprof):
                 step()
     if rank == 0 and prof:
-        ms, cnt, fl = prof[1]
-        tflops = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        gemms = {}
+        for kind, (ms, cnt, fl) in prof.items():
+            if ms <= 0 or cnt == 0:
+                continue
+            rate = fl / (ms * 1e-3) / 1e12
+            peak = I8_PEAK_TOPS if kind == 2 else BF16_PEAK_TFLOPS
+            gemms[kind] = {"kernel": KINDS[kind], "ms_per_step": round(ms / nprof, 3), "launches_per_step": round(cnt / nprof, 1),
+                           "avg_us_per_launch": round(1e3 * ms / cnt, 1), "algorithmic_T(FL)OPs": round(rate, 1),
+                           "peak": peak, "frac_of_peak": round(rate / peak, 4)}
+        if 2 in gemms:
+            gemms[2]["note"] = "fc1 runs twice (statistics-only pass + storing pass): both launches are timed, only one counts as algorithmic work"
+        dom = max(gemms, key=lambda k: gemms[k]["ms_per_step"])          # the dominant kernel of the step = the GEMM class with the largest time
+        g = gemms[dom]
         traffic, traffic_note = None, None
-        try:   # HBM-side bytes per launch of that kernel: NOT measured by this run - an offline rocprofv3 --pmc collection at B=256 shapes
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_gemm_pmc_traffic_tall.json")))
-            per = [v for k, v in pm.items() if "k_gemm_nt<2, 3, 1, 13" in k][0]       # proj, fc2 fwd, qkv dgrad, fc1 dgrad, fc2 dgrad
-            mix = [per[0], per[1], per[2], per[0], per[3], per[4]]                      # + proj dgrad (= proj forward's shape)
-            if args.batch == 256 and args.student == "vit_small":
-                traffic = round(sum(v["fetch_MB"] + v["write_MB"] for v in mix) / len(mix) * 1e6)
-                traffic_note = ("STATIC, not measured in this run: mean FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch over the kernel's six uses, "
-                                "offline rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/round1_gemm_pmc_traffic_tall.json")
-        except Exception:  # noqa: BLE001
-            pass
+        if dom in (1, 4, 5):
+            try:   # HBM-side bytes per launch of the split-A kernel: NOT measured by this run - an offline rocprofv3 --pmc collection at B=256 shapes
+                pm = json.load(open(os.path.join(ROOT, "profiles", "round1_gemm_pmc_traffic_tall.json")))
+                per = [v for k, v in pm.items() if "k_gemm_nt<2, 3, 1, 13" in k][0]       # proj, fc2 fwd, qkv dgrad, fc1 dgrad, fc2 dgrad
+                mix = {1: [per[0], per[1], per[0]], 4: [per[2], per[3]], 5: [per[4]]}[dom]
+                if args.batch == 256 and args.student == "vit_small":
+                    traffic = round(sum(v["fetch_MB"] + v["write_MB"] for v in mix) / len(mix) * 1e6)
+                    traffic_note = ("STATIC, not measured in this run: mean FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch of the PLAIN-epilogue kernel "
+                                    "on these shapes, offline rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/round1_gemm_pmc_traffic_tall.json"
+                                    + ("; the fused LayerNorm backward adds its own operands (x, dx_in read; dx_out, masked pair written: 308 MB) and drops the fp32 output (77 MB)"
+                                       if dom == 4 else ""))
+            except Exception:  # noqa: BLE001
+                pass
         res["roofline"] = {
-            "bound": "mfma", "kernel": "qv::k_gemm_nt split-A (float A operand as a 16-bit hi+lo pair; proj/fc2 forward + all dgrads; 208x384 tiles; "
-                                       "the largest single kernel of the step)",
-            "achieved": round(tflops, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / BF16_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_note": traffic_note, "launches": cnt, "avg_us_per_launch": round(1e3 * ms / max(1, cnt), 1),
+            "bound": "mfma", "kernel": "qv::" + g["kernel"] + " - the GEMM class with the largest share of the step (208x384 tiles)",
+            "achieved": g["algorithmic_T(FL)OPs"], "peak": g["peak"], "unit": "TOP/s" if dom == 2 else "TFLOP/s", "frac": g["frac_of_peak"],
+            "traffic": traffic, "traffic_note": traffic_note, "launches": int(g["launches_per_step"] * nprof), "avg_us_per_launch": g["avg_us_per_launch"],
             "note": f"algorithmic FLOPs 2*M*N*K per launch / HIP-event time of that launch on its launch stream, {nprof} steps run right after the timed "
-                    "region (no event is recorded inside the timed region); every launch issues two 16-bit MFMA passes (hi and lo), so issued MFMA work is 2x this figure",
+                    "region (no event is recorded inside the timed region); split-A launches issue two 16-bit MFMA passes (hi and lo): issued MFMA work is 2x "
+                    "the algorithmic figure; a fused epilogue's time (LayerNorm / GELU backward: HBM-bound work that used to be its own kernel) counts "
+                    "against the GEMM's FLOPs",
         }
-        other = {}
-        ms2, cnt2, fl2 = prof[2]
-        if ms2 > 0:
-            tf = fl2 / (ms2 * 1e-3) / 1e12
-            other["k_gemm_nt grid A on int8 MFMA (patch-embed, qkv, fc1 forward)"] = {
-                "algorithmic_TOPs": round(tf, 1), "peak_TOPs_int8": I8_PEAK_TOPS, "frac_of_int8_peak": round(tf / I8_PEAK_TOPS, 4), "launches": cnt2,
-                "avg_us_per_launch": round(1e3 * ms2 / max(1, cnt2), 1),
-                "note": "fc1 runs twice (statistics-only pass + storing pass): both launches are timed, only one counts as algorithmic work"}
-        ms3, cnt3, fl3 = prof[3]
-        if ms3 > 0:
-            tf = fl3 / (ms3 * 1e-3) / 1e12
-            other["k_gemm_tn (all weight gradients; split dY, grid or split X; 2-3 bf16 passes issued)"] = {
-                "algorithmic_TFLOPs": round(tf, 1), "frac_of_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4), "launches": cnt3,
-                "avg_us_per_launch": round(1e3 * ms3 / max(1, cnt3), 1)}
-        res["mfma_gemms"] = other
+        res["mfma_gemms"] = {KINDS[k].split(",")[0] + (" [mode 8]" if k == 4 else " [mode 5]" if k == 5 else " [plain]" if k == 1 else ""): v for k, v in gemms.items()}
     if rank == 0 and not args.no_kernel_rates:
         res["hbm_kernels"] = hbm_kernel_rates(args.batch)
     # ---- the other single-GPU-sized configurations of BASELINE.json, on the same clock discipline (fewer steps): every rank runs them

@@ -279,7 +279,9 @@ int qatvit_optim_adamw(const void* param_ptrs, const void* grad_ptrs, const void
 
 /* Measurement hooks (bench.py): bracket every launch of one GEMM class inside the steps of ONE engine - identified by its workspace
  * pointer, so engines in the same process do not see each other's sessions - with HIP events on the launch stream.
- * kind: 1 = NT with split (hi+lo) A operand, 2 = NT with grid A operand, 3 = TN (wgrad).
+ * kind: 1 = NT with split (hi+lo) A operand and the plain epilogue (proj / fc2 forward, proj dgrad), 2 = NT with grid A operand (int8 forward
+ * GEMMs), 3 = TN (wgrad), 4 = NT split-A dgrad with the LayerNorm backward fused into its epilogue (fc1 / qkv dgrad), 5 = fc2 dgrad with
+ * the GELU backward fused into its epilogue.
  * stop() synchronises on the recorded events and returns the summed kernel time, launch count and the summed
  * algorithmic FLOPs (2*M*N*K per launch, one pass). */
 int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launches);

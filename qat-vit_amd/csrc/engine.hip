@@ -174,7 +174,7 @@ static int check_cfg(const qatvit_cfg& c) {
 // it is keyed by that engine's workspace pointer, so two engines in one process (student + a second model, two threads) never see each
 // other's events; an engine without an active profile pays one map lookup per forward / backward call.
 struct Prof {
-    int kind = 0;  // 0 off, 1 NT split-A (k_gemm_nt<2,3>), 2 NT grid-A (k_gemm_nt<1,2>), 3 TN
+    int kind = 0;  // 0 off, 1 NT split-A plain epilogue, 2 NT grid-A (int8), 3 TN, 4 NT split-A dgrad + fused LayerNorm backward, 5 fc2 dgrad + fused GELU'
     std::vector<hipEvent_t> ev;
     size_t used = 0;
     double flops = 0.0;
@@ -305,7 +305,7 @@ struct Ctx {
     int linear_dgrad(const void* dY_hi, const void* dY_lo, int M, int wi, float* dX, const NTPost* post = nullptr) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(prof, 1, 2.0 * M * N * K, st);
+        ProfScope ps(prof, !post ? 1 : post->mode == 8 ? 4 : 5, 2.0 * M * N * K, st);   // plain | + fused LayerNorm backward | + fused GELU' (fc2 dgrad)
         return launch_gemm_nt(dY_hi, dY_lo, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr,
                               nullptr, nullptr, 1, st, nullptr, post);
     }
@@ -735,7 +735,7 @@ int qatvit_student_backward_stages(const qatvit_cfg* cfg, void* const* params, c
 
 // bench.py: time every launch of one GEMM class of ONE engine (identified by its workspace) with HIP events on the stream it is launched on
 int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launches) {
-    QV_CHECK_ARG(workspace && kind >= 1 && kind <= 3 && max_launches > 0, "qatvit_profile_start: bad arguments");
+    QV_CHECK_ARG(workspace && kind >= 1 && kind <= 5 && max_launches > 0, "qatvit_profile_start: bad arguments");
     Prof* pr = new Prof();
     pr->ev.assign((size_t)max_launches * 2, nullptr);
     for (auto& e : pr->ev)
