@@ -314,7 +314,9 @@ def main():
              4: "k_gemm_nt split-A dgrad + LayerNorm backward fused into the epilogue (fc1 / qkv dgrad, mode 8)",
              5: "k_gemm_nt split-A fc2 dgrad + GELU backward fused into the epilogue (mode 5)",
              2: "k_gemm_nt grid A on int8 MFMA (patch-embed, qkv, fc1 forward)",
-             3: "k_gemm_tn (all weight gradients; split dY, grid or split X; 2-3 bf16 passes issued)"}
+             3: "k_gemm_tn<1,..> + k_tn_reduce: weight gradients with grid X (qkv / fc1 / patch-embed; split dY: 2 bf16 passes issued)",
+             6: "k_gemm_tn<2,..> + k_tn_reduce: weight gradients with split X (proj / fc2; 3 bf16 passes issued)"}
+    SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_forward", 3: "tn_grid_x", 6: "tn_split_x"}
     prof = {}
     nprof = 0 if args.graph else 3
     for kind in KINDS:
@@ -354,7 +356,7 @@ def main():
             except Exception:  # noqa: BLE001
                 pass
         res["roofline"] = {
-            "bound": "mfma", "kernel": "qv::" + g["kernel"] + " - the GEMM class with the largest share of the step (208x384 tiles)",
+            "bound": "mfma", "kernel": "qv::" + g["kernel"] + " - the GEMM kernel with the largest share of the step (208x384 tiles)",
             "achieved": g["algorithmic_T(FL)OPs"], "peak": g["peak"], "unit": "TOP/s" if dom == 2 else "TFLOP/s", "frac": g["frac_of_peak"],
             "traffic": traffic, "traffic_note": traffic_note, "launches": int(g["launches_per_step"] * nprof), "avg_us_per_launch": g["avg_us_per_launch"],
             "note": f"algorithmic FLOPs 2*M*N*K per launch / HIP-event time of that launch on its launch stream, {nprof} steps run right after the timed "
@@ -362,7 +364,7 @@ def main():
                     "the algorithmic figure; a fused epilogue's time (LayerNorm / GELU backward: HBM-bound work that used to be its own kernel) counts "
                     "against the GEMM's FLOPs",
         }
-        res["mfma_gemms"] = {KINDS[k].split(",")[0] + (" [mode 8]" if k == 4 else " [mode 5]" if k == 5 else " [plain]" if k == 1 else ""): v for k, v in gemms.items()}
+        res["mfma_gemms"] = {SHORT[k]: v for k, v in gemms.items()}
     if rank == 0 and not args.no_kernel_rates:
         res["hbm_kernels"] = hbm_kernel_rates(args.batch)
     # ---- the other single-GPU-sized configurations of BASELINE.json, on the same clock discipline (fewer steps): every rank runs them

@@ -108,6 +108,13 @@ int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
                        int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream);
 
+/* qatvit_gemm_nt_f16 for an A operand that takes at most 256 distinct values (mlp.fc2: A = gelu(fq(fc1 output))): A8 uint8 [M,lda] = table
+ * index per element (lda in bytes), lut[256] = the fp16 (hi | lo << 16) pair per index.  The kernel expands the codes through the table on their
+ * way into LDS: bit-identical to qatvit_gemm_nt_f16 on the expanded planes, 1 B instead of 4 B of HBM traffic per A element.
+ * N % 384 == 0, K % 64 == 0, lda % 16 == 0. */
+int qatvit_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                         int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream);
+
 /* The same product for two operands that both sit on a quantisation grid (qkv / fc1 / patch-embed forward), on int8 MFMA:
  *   A8 int8 [M,lda] = q - center (center = (qmin+qmax+1)/2 of the activation range), B8 int8 [N,ldb] = weight integers,
  *   wsum int32 [N] = row sums of B8, a_qp = {scale, 1/scale, zero_point, enabled} of A's quantizer (device):
@@ -217,8 +224,10 @@ int qatvit_student_forward_stages(const qatvit_cfg* cfg, void* const* params, co
  *   part 0: norm1 -> qkv GEMM                                         input x_in[block]            ("x_in")
  *   part 1: attention -> proj GEMM -> residual (+ norm2 statistics)    input pre-fake-quant qkv     ("qkv"; reads x_in[block] as it stands)
  *   part 2: norm2 -> fc1 (both passes) -> GELU                         input x_mid[block]           ("x_mid")
- *   part 3: fc2 GEMM -> residual (+ next LayerNorm's statistics)       input the GELU output planes ("G_hi"/"G_lo", "G16_hi"/"G16_lo" and
- *                                                                      "scal16"[1]; reads x_mid[block] as it stands)
+ *   part 3: fc2 GEMM -> residual (+ next LayerNorm's statistics)       input the GELU output: "G_hi"/"G_lo" (bf16 pair, backward operand) and
+ *                                                                      what the forward GEMM reads - "G8"[block] (uint8 grid index per element)
+ *                                                                      + "glut"[block] (256 packed fp16 hi | lo << 16 pairs) + "scal16"[1]
+ *                                                                      (QATVIT_FC2_CODES=0: the planes "G16_hi"/"G16_lo"); reads x_mid[block]
  * parts 0..3 in order == forward stage block + 1.  QATVIT_STAGE_INJECT: that input was written by the caller; the observer statistics
  * (and LayerNorm row statistics) its producer would have left are recomputed first. */
 int qatvit_student_forward_part(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq, void* workspace,
@@ -280,7 +289,7 @@ int qatvit_optim_adamw(const void* param_ptrs, const void* grad_ptrs, const void
 /* Measurement hooks (bench.py): bracket every launch of one GEMM class inside the steps of ONE engine - identified by its workspace
  * pointer, so engines in the same process do not see each other's sessions - with HIP events on the launch stream.
  * kind: 1 = NT with split (hi+lo) A operand and the plain epilogue (proj / fc2 forward, proj dgrad), 2 = NT with grid A operand (int8 forward
- * GEMMs), 3 = TN (wgrad), 4 = NT split-A dgrad with the LayerNorm backward fused into its epilogue (fc1 / qkv dgrad), 5 = fc2 dgrad with
+ * GEMMs), 3 = TN (wgrad) with grid X operand (qkv / fc1 / patch-embed; the bracket holds k_gemm_tn + k_tn_reduce), 6 = TN with split X operand (proj / fc2), 4 = NT split-A dgrad with the LayerNorm backward fused into its epilogue (fc1 / qkv dgrad), 5 = fc2 dgrad with
  * the GELU backward fused into its epilogue.
  * stop() synchronises on the recorded events and returns the summed kernel time, launch count and the summed
  * algorithmic FLOPs (2*M*N*K per launch, one pass). */

@@ -99,6 +99,14 @@ int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, 
     return 0;
 }
 
+int qatvit_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                         int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream) {
+    QV_CHECK_ARG(A8 && lut && B16 && C, "qatvit_gemm_nt_codes: null pointer argument");
+    if (launch_gemm_nt_codes(A8, lut, B16, C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream)) return 1;
+    QV_CHECK_LAUNCH("qatvit_gemm_nt_codes");
+    return 0;
+}
+
 int qatvit_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int32_t center, float* C, int32_t M, int32_t N,
                       int32_t K, int32_t lda, int32_t ldb, int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias,
                       uint32_t* stats, void* stream) {

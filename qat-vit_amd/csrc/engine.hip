@@ -66,7 +66,7 @@ static int wparam(const Dims& d, int wi) {  // index of the weight tensor in par
 struct Plan {
     // byte offsets into the workspace
     int64_t stats, qp_act, qp_w, imgq, Y0, meanF, rstdF, hq, logits_pre;
-    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2, qkv8, qkvm;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2, qkv8, qkvm, G8, glut;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
     int64_t blk_stride;
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
@@ -121,6 +121,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->h1q8 = take(M * D); p->h2q8 = take(M * D);
     p->mproj = take(ln_maskbits_bytes(M, (int)D)); p->m2 = take(ln_maskbits_bytes(M, (int)D));
     p->qkv8 = take(M * 3 * D); p->qkvm = take(M * 3 * D / 8);   // the quantised qkv as the attention forward saw it (codes + STE mask bits), for its backward
+    p->G8 = take(M * Hd); p->glut = take(256 * 4);   // gelu(fq(fc1 output)) as one byte per element + the 256-entry table of fp16 pairs (fc2 forward from codes)
     p->blk_stride = o - b0;
     o = b0 + p->blk_stride * d.depth;
     // x_in[depth] (input of the final norm) lives where block `depth` would start
@@ -217,6 +218,13 @@ static bool use_f16() {
     return on != 0;
 }
 
+// QATVIT_FC2_CODES=0: fc2's forward A operand as the two fp16 planes (4 B per element written by fc1's storing pass and read back) instead of
+// one byte per element expanded through a 256-entry table inside the GEMM (k_gemm_nt_ac) - the same bits either way
+static bool fc2_codes() {
+    static const int on = getenv("QATVIT_FC2_CODES") ? atoi(getenv("QATVIT_FC2_CODES")) : 1;
+    return on != 0;
+}
+
 // QATVIT_WBATCH=0: one launch triple per weight instead of three multi-tensor launches (tuning; also the path of models deeper than the
 // tables hold).  That path does not write the fp16 weight copies, so the fp16-pair forward GEMMs are off with it.
 static bool w_batched(const Dims& d) {
@@ -282,6 +290,14 @@ struct Ctx {
         return launch_gemm_nt(A16_hi, A16_lo, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
                               c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, nullptr, nullptr, true);
     }
+    // the same product with the A operand as uint8 table indices [M, K] + the 256-entry table of fp16 pairs (fc2: gelu(fq(.)) takes <= 256 values)
+    int linear_fwd_codes(const void* A8, const uint32_t* lut, const float* pair_scale, int M, int wi, const float* bias, float* C, int ai_out) const {
+        int N, K; wshape(d, wi, &N, &K);
+        const qatvit_fq& f = wfq[wi];
+        ProfScope ps(prof, 1, 2.0 * M * N * K, st);
+        return launch_gemm_nt_codes(A8, lut, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
+                                    c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st);
+    }
     bool f16_ok(int wi) const {
         int N, K; wshape(d, wi, &N, &K);
         return use_f16() && w_batched(d) && p.w16_off[wi] >= 0 && N % 384 == 0 && K % 32 == 0;
@@ -314,7 +330,7 @@ struct Ctx {
                      bool dy_scaled = true) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(prof, 3, 2.0 * M * N * K, st);
+        ProfScope ps(prof, X_lo ? 6 : 3, 2.0 * M * N * K, st);   // grid X (qkv / fc1 / patch-embed wgrad) | split X (proj / fc2 wgrad)
         return launch_gemm_tn(dY_hi, dY_lo, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
                               c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
     }
@@ -342,6 +358,7 @@ static int fwd_block(const Ctx& x, int i, int parts) {
             return 1;
         }
         const bool proj16 = x.f16_ok(x.widx(i, WB_PROJ)), fc2_16 = x.f16_ok(x.widx(i, WB_FC2)) && fc1_recompute();
+        const bool fc2_c = fc2_16 && fc2_codes() && d.Hd % 64 == 0 && c.act_qmax - c.act_qmin <= 255;
         float* const scal16 = x.at<float>(p.scal16);
         if (parts & 2) {   // ---- part 1: attention -> proj -> residual (+ statistics of norm2)
         x.qparams_act(x.aidx(i, AB_QKV));
@@ -379,7 +396,8 @@ static int fwd_block(const Ctx& x, int i, int parts) {
             x.qparams_act(x.aidx(i, AB_FC1));
             NTPost p2{nullptr, x.act_qp(x.aidx(i, AB_FC1)), qa, qb, nullptr, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), 4,
                       x.blk<void>(p.Y1, i)};
-            if (fc2_16) { p2.out16_hi = x.at<void>(p.G16_hi); p2.out16_lo = x.at<void>(p.G16_lo); p2.out16_scale = scal16 + 1; }
+            if (fc2_c) { p2.out8 = x.blk<void>(p.G8, i); p2.lut_out = x.blk<uint32_t>(p.glut, i); p2.out16_scale = scal16 + 1; }
+            else if (fc2_16) { p2.out16_hi = x.at<void>(p.G16_hi); p2.out16_lo = x.at<void>(p.G16_lo); p2.out16_scale = scal16 + 1; }
             if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
                              x.aidx(i, AB_FC1), &p2, false))
                 return 1;
@@ -392,7 +410,11 @@ static int fwd_block(const Ctx& x, int i, int parts) {
         }
         }
         if (parts & 8) {   // ---- part 3: fc2 -> residual (+ statistics of the next LayerNorm)
-        if (fc2_16) {
+        if (fc2_c) {
+            if (x.linear_fwd_codes(x.blk<void>(p.G8, i), x.blk<uint32_t>(p.glut, i), scal16 + 1, M, x.widx(i, WB_FC2), x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i),
+                                   x.aidx(i, AB_FC2)))
+                return 1;
+        } else if (fc2_16) {
             if (x.linear_fwd_f16(x.at<void>(p.G16_hi), x.at<void>(p.G16_lo), scal16 + 1, M, x.widx(i, WB_FC2), x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i),
                                  x.aidx(i, AB_FC2)))
                 return 1;
@@ -735,7 +757,7 @@ int qatvit_student_backward_stages(const qatvit_cfg* cfg, void* const* params, c
 
 // bench.py: time every launch of one GEMM class of ONE engine (identified by its workspace) with HIP events on the stream it is launched on
 int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launches) {
-    QV_CHECK_ARG(workspace && kind >= 1 && kind <= 5 && max_launches > 0, "qatvit_profile_start: bad arguments");
+    QV_CHECK_ARG(workspace && kind >= 1 && kind <= 6 && max_launches > 0, "qatvit_profile_start: bad arguments");
     Prof* pr = new Prof();
     pr->ev.assign((size_t)max_launches * 2, nullptr);
     for (auto& e : pr->ev)
@@ -792,7 +814,7 @@ int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, in
         {"Y1", p.Y1, true}, {"G_hi", p.G_hi, true}, {"G_lo", p.G_lo, true}, {"Y2", p.Y2, true}, {"dxA", p.dxA, false}, {"dqkv_hi", p.dqkv_hi, false},
         {"dqkv_lo", p.dqkv_lo, false}, {"dO", p.dO, false},
         {"dH", p.dH, false}, {"lse", p.lse, true}, {"O16_hi", p.O16_hi, false}, {"O16_lo", p.O16_lo, false}, {"G16_hi", p.G16_hi, false},
-        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false},
+        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false}, {"G8", p.G8, true}, {"glut", p.glut, true},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) return t.off + (t.per_block ? p.blk_stride * block : 0);

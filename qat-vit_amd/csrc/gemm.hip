@@ -140,6 +140,10 @@ struct NTArgs {
     float* lnb_dgamma;
     float* lnb_dbeta;
     const unsigned long long* lnb_nmask;
+    // mode 4 (optional): out8 = the grid index (q - qmin) of every element as uint8 [M, ldc] and lut_out[256] = the packed fp16 (hi | lo << 16)
+    // pair of 2^k * gelu(grid value) per index - together the A operand of k_gemm_nt_ac (fc2 forward from codes: 1 B instead of 4 B per element)
+    uint32_t* lut_out;
+    const uint32_t* a_lut;   // k_gemm_nt_ac: the table its uint8 A operand (A0, lda in BYTES) is expanded through
 };
 
 constexpr int kStandIn = 512;
@@ -222,7 +226,8 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
             const _Float16 hh = (_Float16)g16;
             const _Float16 hl = (_Float16)(g16 - (float)hh);
             sLutH[tid] = (uint32_t)__builtin_bit_cast(uint16_t, hh) | ((uint32_t)__builtin_bit_cast(uint16_t, hl) << 16);
-        }
+            if (p.lut_out && blockIdx.x == 0) p.lut_out[tid] = sLutH[tid];
+        } else if (p.lut_out && blockIdx.x == 0 && tid < 256) p.lut_out[tid] = 0u;
     }
     float ca[TNT], cb[TNT];
 #pragma unroll
@@ -429,7 +434,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         if (ok[u]) *reinterpret_cast<float4*>(p.C + off[u]) = v[u];
                 } else if constexpr (PM == 4) {
                     const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
-                    const bool w16 = p.out16_hi != nullptr, wbf = p.out_hi != nullptr;   // uniform
+                    const bool w16 = p.out16_hi != nullptr, wbf = p.out_hi != nullptr, w8 = p.out8 != nullptr;   // uniform
                     uint32_t w[U][4], wh[U][4], cd[U][4];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -460,6 +465,8 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                             *reinterpret_cast<uint2*>(p.out16_hi + off[u]) = h16;
                             *reinterpret_cast<uint2*>(p.out16_lo + off[u]) = l16;
                         }
+                        if (ok[u] && w8)
+                            *reinterpret_cast<uint32_t*>(p.out8 + off[u]) = (cd[u][0] & 0xffu) | ((cd[u][1] & 0xffu) << 8) | ((cd[u][2] & 0xffu) << 16) | (cd[u][3] << 24);
                     }
                 } else {   // PM == 5
                     float dg[U][4];
@@ -548,6 +555,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         *reinterpret_cast<uint2*>(p.out16_hi + off) = h16;
                         *reinterpret_cast<uint2*>(p.out16_lo + off) = l16;
                     }
+                    if (p.out8) *reinterpret_cast<uint32_t*>(p.out8 + off) = (cd[0] & 0xffu) | ((cd[1] & 0xffu) << 8) | ((cd[2] & 0xffu) << 16) | (cd[3] << 24);
                 } else if constexpr (PM == 5) {
                     uint2 c2;
                     if constexpr (CODE_LDS) c2 = *reinterpret_cast<const uint2*>(sCodeH + (rl * BN + 4 * c4) * 2);
@@ -993,6 +1001,146 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_br(const NTArgs p) {
     nt_epilogue<1, WN, TM, TNT, SLAB, PM, LDSB, I8>(p, acc, smem, m0, n0, tid, lane, wave, 0, wave, r, g);
 }
 
+
+// ============================================================================ NT, A operand from uint8 codes through a table
+// fc2 forward: its A operand gelu(fq(fc1 output)) takes at most 256 values, so fc1's storing pass writes ONE byte per element (the grid
+// index) and a 256-entry table of packed fp16 (hi | lo << 16) pairs instead of the two 2-byte planes; here every k-step's [208][32] code tile
+// comes in through registers (16 codes per thread, 416 threads), is expanded through the table (held in LDS) and written to the hi / lo
+// LDS images in exactly the layout the LDS-DMA of the plane form produces - same fragments, same MFMAs, same bits.  HBM side: 1 B instead
+// of 4 B per A element read, and 1 B instead of 4 B written by the producer.
+// Pipeline (3-stage ring, B by LDS-DMA as before): step kt issues the code load of tile kt+2 FIRST, then tile kt+2's B pieces; codes(kt+1)
+// (loaded during step kt-1) are expanded into stage (kt+1)%3 between the MFMA groups of step kt.  One in-order vmcnt queue per wave:
+//   ... B(kt) x3 | code(kt+1) B(kt+1) x3 | code(kt+2) ...   so "at most this wave's 3 youngest B pieces outstanding" at the top of step kt
+// means B(kt) AND code(kt+1) have arrived.  The expanded tile is published by the lgkmcnt(0) + barrier at the top of the next step.
+template <int NSTAGE, int PM, int LDSB>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt_ac(const NTArgs p) {
+    constexpr int TM = 13, TNT = 3, WN = 8, BM = 208, BN = 384;
+    constexpr int IMGA = BM * 64, IMGB = BN * 64, STAGE = 2 * IMGA + IMGB;
+    constexpr int NPW = (BN / 16) / 8;                // B pieces per wave per k-tile (24 1-KiB pieces over 8 waves)
+    constexpr int NCT = BM * 2;                       // threads that carry codes: (row, 16-code half) pairs
+    static_assert(NSTAGE == 3 && NSTAGE * STAGE + 1024 <= LDSB, "ring + table");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* sLut = reinterpret_cast<uint32_t*>(smem + NSTAGE * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int tilesN = p.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
+    if (tid < 256) sLut[tid] = p.a_lut[tid];          // (published by the first barrier of the loop; the compiler waits for the load itself)
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, (int64_t)p.N * p.ldb * 2);
+    const v4i32 rA = make_rsrc_v(p.A0, (int64_t)p.M * p.lda);   // bytes: rows past M read as zero
+    const int lR = lane >> 3, lL = (lane & 7) ^ lR;
+    const int prow = 2 * lR + (lL >> 2), pk = lL & 3;
+    const bool carrier = wave < (NCT + 63) / 64;      // wave-uniform: this wave issues code loads (the last carrier wave is half full)
+    const int crow = tid >> 1, chalf = tid & 1;
+    const uint32_t aoff = tid < NCT ? (uint32_t)((int64_t)(m0 + crow) * p.lda + chalf * 16) : 0xfffffff0u;   // (out of range: reads zero)
+
+    auto issue_b = [&](int kt, int c) {
+        char* st = smem + (kt % NSTAGE) * STAGE + 2 * IMGA;
+        const int pc = c * 8 + wave;
+        const uint32_t off = (uint32_t)(((int64_t)(n0 + pc * 16 + prow) * p.ldb + kt * 32 + pk * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(st + pc * 1024), 16, off, 0, 0, 0);
+    };
+    auto load_codes = [&](int kt) { return load16_asm(rA, aoff + (uint32_t)kt * 32u); };
+    // eight codes (dwords 2 * part, 2 * part + 1 of the thread's 16) -> 16-B chunk 2 * chalf + part of row crow in the hi and the lo image;
+    // the table reads are issued one MFMA group before their results are packed and stored (LDS latency under the MFMAs)
+    uint32_t w[8];
+    auto lookup = [&](const v4i32& c, int part) {
+        const uint32_t d0 = (uint32_t)c[2 * part], d1 = (uint32_t)c[2 * part + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            w[e] = sLut[(d0 >> (8 * e)) & 0xffu];
+            w[4 + e] = sLut[(d1 >> (8 * e)) & 0xffu];
+        }
+    };
+    auto pack_store = [&](int kt, int part) {
+        v4i32 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            hi[q] = (int)__builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x05040100u);
+            lo[q] = (int)__builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x07060302u);
+        }
+        char* st = smem + (kt % NSTAGE) * STAGE + nt_off32(crow, 2 * chalf + part);
+        if (tid < NCT) {
+            *reinterpret_cast<v4i32*>(st) = hi;
+            *reinterpret_cast<v4i32*>(st + IMGA) = lo;
+        }
+    };
+
+    f32x4 acc[TM][TNT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) acc[i][j] = f32x4{};
+
+    const int nk = p.K / 32;
+    __syncthreads();                                  // the table is in LDS
+    // prologue: code(0) B(0) code(1) B(1); expand tile 0 once code(0) is here (7 younger operations may stay in flight)
+    v4i32 c0{}, c1{};
+    if (carrier) c0 = load_codes(0);
+#pragma unroll
+    for (int c = 0; c < NPW; ++c) issue_b(0, c);
+    if (carrier && 1 < nk) c1 = load_codes(1);
+    if (1 < nk) {
+#pragma unroll
+        for (int c = 0; c < NPW; ++c) issue_b(1, c);
+    }
+    if (1 < nk) wait_vmcnt_b<2 * NPW + 1>(); else wait_vmcnt_b<NPW>();
+    if (carrier) { lookup(c0, 0); pack_store(0, 0); lookup(c0, 1); pack_store(0, 1); }
+
+    auto step = [&](int kt, v4i32& ccur, v4i32& cnext) {   // ccur = codes(kt+1), cnext receives codes(kt+2)
+        if (kt + 1 < nk) wait_vmcnt_b<NPW>();
+        else wait_vmcnt_b<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile kt: B landed, A expanded by everyone; everyone left stage (kt-1)%3
+        const bool more = kt + 2 < nk, conv = carrier && kt + 1 < nk;
+        if (more && carrier) cnext = load_codes(kt + 2);
+        const char* st = smem + (kt % NSTAGE) * STAGE;
+        const char* sB = st + 2 * IMGA;
+        bf16x8 bfrag[TNT];
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off32(wave * 48 + 16 * j + r, g));
+        constexpr int PF = 3;
+        bf16x8 af[PF][2];
+        auto read_a = [&](int i) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) af[i % PF][t] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + nt_off32(16 * i + r, g));
+        };
+#pragma unroll
+        for (int i = 0; i < PF - 1; ++i) read_a(i);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            __builtin_amdgcn_sched_barrier(0);        // pin the group order (see k_gemm_nt_br)
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < NPW; ++c)
+                    if ((c * TM) / NPW == i) issue_b(kt + 2, c);
+            }
+            if (conv) {
+                if (i == 1) lookup(ccur, 0);
+                if (i == 2) pack_store(kt + 1, 0);
+                if (i == 5) lookup(ccur, 1);
+                if (i == 6) pack_store(kt + 1, 1);
+            }
+            if (i + PF - 1 < TM) read_a(i + PF - 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i % PF][t]), __builtin_bit_cast(f16x8, bfrag[j]), acc[i][j], 0, 0, 0);
+        }
+    };
+    // (nk is even: K % 64 == 0 is checked by the launcher)
+#pragma clang loop unroll(disable)
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, c1, c0);
+        step(kt + 1, c0, c1);
+    }
+    __syncthreads();  // all fragment reads done: the LDS is free for the epilogue
+    static_assert(LDSB >= 64 * (BN + 4) * 4 + 2048, "LDS too small for the epilogue slab");
+    nt_epilogue<1, WN, TM, TNT, 64, PM, LDSB, false>(p, acc, smem, m0, n0, tid, lane, wave, 0, wave, r, g);
+}
+
 template <typename K>
 static void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1242,6 +1390,25 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     return 0;
 }
 
+// fc2 forward from codes: A8 [M, lda] uint8 grid indices, lut[256] packed fp16 (hi | lo << 16) pairs, B16 [N, ldb] the weight integers as fp16
+int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
+                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st) {
+    if (M < 1 || N % 384 != 0 || K % 64 != 0 || lda % 16 != 0 || ldb % 8 != 0 || ldc % 4 != 0 || !A8 || !lut || !B16 || !C) {
+        set_error("gemm_nt_codes: unsupported arguments M=%d N=%d K=%d lda=%d ldb=%d ldc=%d (need N%%384==0, K%%64==0, lda%%16==0)", M, N, K, lda, ldb, ldc);
+        return 1;
+    }
+    NTArgs a{};
+    a.A0 = reinterpret_cast<const __bf16*>(A8); a.B = reinterpret_cast<const __bf16*>(B16); a.C = C;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.s1 = s1; a.s2 = s2; a.col_scale = col_scale; a.bias = bias; a.stats = stats; a.stat_slots = stat_slots < 1 ? 1 : stat_slots;
+    a.a_lut = lut;
+    constexpr int kLds = 3 * (2 * 208 + 384) * 64 + 1024;   // 151 KiB
+    static bool once = (allow_lds(k_gemm_nt_ac<3, 0, kLds>, (size_t)kLds), true);
+    (void)once;
+    k_gemm_nt_ac<3, 0, kLds><<<cdiv(M, 208) * (N / 384), 512, kLds, st>>>(a);
+    return 0;
+}
+
 // Grid x grid forward GEMM on int8 MFMA (v_mfma_i32_16x16x64_i8: twice the k per instruction and per LDS-DMA byte of the bf16 form).
 // A8 [M, lda] = q - center (int8), B8 [N, ldb] = weight integers (int8), wsum [N] = row sums of B8; the result equals the bf16 path's
 // bit for bit (both accumulate the same integers exactly).  Tall 208 x 384 tiles only: N % 384 == 0, K % 64 == 0.
@@ -1263,6 +1430,7 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
         a.post_code = reinterpret_cast<uint16_t*>(post->code);
         a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
         a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
+        a.lut_out = post->lut_out;
         const bool full4 = a.out_hi && a.out_lo && a.post_code, half4 = !a.out_hi && !a.out_lo && !a.post_code && a.out16_hi && a.out16_lo && a.out16_scale;
         if ((post->mode == 4 && (!a.post_qp || !(full4 || half4) || a.post_qmax - a.post_qmin >= 256)) ||
             (post->mode == 6 && (!a.post_qp || !a.resid || !C)) ||

@@ -56,6 +56,9 @@ struct NTPost {
     int embed_np = 0;
     void* out8 = nullptr;
     int code_T = 0, code_hd = 0;
+    // mode 4, optional: out8 = the grid index (q - qmin) of every element as uint8 [M, ldc] and lut_out[256] = packed fp16 (hi | lo << 16) pair of
+    // 2^k * gelu(grid value) per index (with out16_scale): the A operand of launch_gemm_nt_codes - fc2 forward from 1 B per element
+    uint32_t* lut_out = nullptr;
     // mode 8 (split-A dgrad whose output rows are whole LayerNorm rows, N == 384): the LayerNorm backward fused into the epilogue -
     // C = dx_out = dx_in + LNbwd(acc * alpha * mask(LN(x))), dgamma / dbeta accumulated, and (out_hi / out_lo non-null) the masked (hi, lo)
     // copy of dx_out for the next branch: nmask = that branch output's STE mask words, colscale = its per-channel weight scale.
@@ -78,6 +81,9 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
                       hipStream_t st, const NTPost* post = nullptr);
+// A operand = uint8 grid indices [M, lda] expanded through lut[256] (packed fp16 hi | lo << 16 pairs) inside the kernel; B16 = weight integers as fp16
+int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
+                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st);
 // scratch that lets every wgrad shape take the two-phase (non-atomic, bit-reproducible) reduction: 256 workgroups x the largest tile
 constexpr int64_t kTnScratchBytes = 256ll * 128 * 384 * 4;
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,

@@ -222,3 +222,38 @@ def test_gemm_nt_f16_pair(native_lib, M, N, K):
     eb = rel_l2(Cb[rows].cpu(), ref.cpu())
     print(f"nt M={M} N={N} K={K}: fp16 pair {e16:.2e}, bf16 pair {eb:.2e}")
     assert e16 < 1e-6 and e16 < eb
+
+
+@pytest.mark.parametrize("M,N,K", [(1576, 384, 384), (300, 384, 1536), (50432, 384, 1536), (1000, 768, 3072), (207, 384, 64)])
+def test_gemm_nt_codes_equals_planes(native_lib, M, N, K):
+    """fc2 forward from codes: uint8 table indices + a 256-entry table of fp16 (hi, lo) pairs, expanded inside the kernel, against the same
+    product on the expanded planes (qatvit_gemm_nt_f16): the same fragments through the same MFMAs, so the same bits - incl. the min/max
+    accumulator.  Skewed code histogram (GELU outputs cluster near zero), every table entry used."""
+    torch.manual_seed(M + N + K)
+    dev = "cuda"
+    idx = (torch.randn(M, K, device=dev).abs() * 40).clamp(0, 255).to(torch.uint8)
+    idx[::5, ::3] = torch.randint(0, 256, idx[::5, ::3].shape, device=dev, dtype=torch.uint8)
+    vals = torch.randn(256, device=dev) * 2.0 ** torch.randint(-6, 13, (256,), device=dev).float()
+    hi_t, lo_t = split_h(vals)
+    lut = (hi_t.view(torch.int16).int() & 0xffff) | (lo_t.view(torch.int16).int() << 16)
+    Ah, Al = hi_t[idx.long()].contiguous(), lo_t[idx.long()].contiguous()
+    Bh = torch.randint(-128, 128, (N, K), device=dev).float().to(torch.float16)
+    s1 = torch.tensor([2.0 ** -9], device=dev)
+    s2 = torch.tensor([0.0045], device=dev)
+    cs = torch.rand(N, device=dev) + 0.5
+    bias = torch.randn(N, device=dev)
+
+    def fresh():
+        return torch.tensor([0xFF800000 - (1 << 32), 0x007FFFFF], dtype=torch.int32, device=dev)
+
+    st_a, st_b = fresh(), fresh()
+    Ca = torch.full((M, N), float("nan"), device=dev)
+    Cb = torch.full((M, N), float("nan"), device=dev)
+    assert native_lib.qatvit_gemm_nt_f16(Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Ca.data_ptr(), M, N, K, K, K, N, s1.data_ptr(), s2.data_ptr(),
+                                         cs.data_ptr(), bias.data_ptr(), st_a.data_ptr(), _st()) == 0, native_lib.qatvit_last_error()
+    assert native_lib.qatvit_gemm_nt_codes(idx.data_ptr(), lut.data_ptr(), Bh.data_ptr(), Cb.data_ptr(), M, N, K, K, K, N, s1.data_ptr(), s2.data_ptr(),
+                                           cs.data_ptr(), bias.data_ptr(), st_b.data_ptr(), _st()) == 0, native_lib.qatvit_last_error()
+    torch.cuda.synchronize()
+    assert not torch.isnan(Cb).any()
+    assert torch.equal(Ca, Cb)
+    assert torch.equal(st_a, st_b)

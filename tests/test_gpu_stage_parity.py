@@ -198,6 +198,7 @@ def _run(backend, seed, teacher, golden_tag):
     tab.close("embed", "x_in[0] (cls, pos added)", eng.tensor("x_in", 0, (M, D)), tr.block_in[0].reshape(M, D))
     Hd = c.mlp_hidden
     f16 = os.environ.get("QATVIT_F16", "1") != "0"
+    fc2_codes = f16 and os.environ.get("QATVIT_FC2_CODES", "1") != "0"
 
     def cmp_part(tb, st, i, part, lim=CODE_FLIP_FRAC, tol=TOL, split_fc2=True):
         """Everything part `part` of block i left in the workspace against the oracle."""
@@ -229,7 +230,13 @@ def _run(backend, seed, teacher, golden_tag):
             tb.codes(st, "mlp.fc1 STE mask", (code >> 15).float(), ref_mask.float(), lim)
             gl = eng.tensor("G_hi", i, (M, Hd), torch.bfloat16).float() + eng.tensor("G_lo", i, (M, Hd), torch.bfloat16).float()
             tb.close(st, "gelu out (bf16 pair, bwd)", gl, tr.fc2_in[i].reshape(M, Hd), tol)
-            if f16:
+            if f16 and fc2_codes:   # what the fc2 forward GEMM reads: one byte per element + the 256-entry table of fp16 (hi, lo) pairs
+                sc = eng.tensor("scal16", 0, (2,))
+                lut = eng.tensor("glut", i, (256,), torch.int32)
+                pair = (lut & 0xffff).to(torch.int16).view(torch.float16).float() + ((lut >> 16) & 0xffff).to(torch.int16).view(torch.float16).float()
+                g16 = pair[eng.tensor("G8", i, (M, Hd), torch.uint8).long()] * sc[1]
+                tb.close(st, "gelu out (codes + fp16 pair table, fwd)", g16, tr.fc2_in[i].reshape(M, Hd), tol)
+            elif f16:
                 sc = eng.tensor("scal16", 0, (2,))
                 g16 = (eng.tensor("G16_hi", 0, (M, Hd), torch.float16).float() + eng.tensor("G16_lo", 0, (M, Hd), torch.float16).float()) * sc[1]
                 tb.close(st, "gelu out (fp16 pair, fwd)", g16, tr.fc2_in[i].reshape(M, Hd), tol)
@@ -298,8 +305,20 @@ def _run(backend, seed, teacher, golden_tag):
             kexp = 13 - int(np.floor(np.log2(g_ref.abs().max().item())))
             gs = g_ref * (2.0 ** kexp)
             g16h = gs.to(torch.float16)
-            eng.tensor("G16_hi", 0, (M, Hd), torch.float16).copy_(g16h)
-            eng.tensor("G16_lo", 0, (M, Hd), torch.float16).copy_((gs - g16h.float()).to(torch.float16))
+            if fc2_codes:   # the oracle's fc1 codes + the table of the oracle's GELU values per code
+                of1 = tr.fq[f"model.blocks.{i}.mlp.fc1.{A}"]
+                idx = (tr.codes(f"model.blocks.{i}.mlp.fc1.{A}").reshape(M, Hd) + of1.zero_point.float() - qa).round().long().cuda()
+                assert int(idx.min()) >= 0 and int(idx.max()) <= 255
+                hi_t = torch.zeros(256, dtype=torch.float16, device="cuda")
+                lo_t = torch.zeros(256, dtype=torch.float16, device="cuda")
+                hi_t[idx.reshape(-1)] = g16h.reshape(-1)
+                lo_t[idx.reshape(-1)] = (gs - g16h.float()).to(torch.float16).reshape(-1)
+                packed = (hi_t.view(torch.int16).int() & 0xffff) | (lo_t.view(torch.int16).int() << 16)
+                eng.tensor("glut", i, (256,), torch.int32).copy_(packed)
+                eng.tensor("G8", i, (M, Hd), torch.uint8).copy_(idx.to(torch.uint8))
+            else:
+                eng.tensor("G16_hi", 0, (M, Hd), torch.float16).copy_(g16h)
+                eng.tensor("G16_lo", 0, (M, Hd), torch.float16).copy_((gs - g16h.float()).to(torch.float16))
             eng.tensor("scal16", 0, (2,))[1] = 2.0 ** -kexp
         reset_act_observers([7 + 6 * i])
         eng.forward_part(i, 3, inject=True)
