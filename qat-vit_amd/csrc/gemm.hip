@@ -672,12 +672,8 @@ __device__ inline int nt_off32(int row, int chunk) {
 // NWD: number of waves (the first NWD, the older wave of each SIMD pair) that issue the LDS-DMA pieces; 0 = all of them
 // F16: both operands hold fp16 bit patterns (a float A operand as an fp16 (hi, lo) pair pre-scaled by a power of two, the weight integers
 // as fp16): v_mfma_f32_16x16x32_f16 - same tile, same LDS images, same rate as the bf16 form, 2^-23 instead of 2^-17 per A element.
-// SKEW (tall tiles): the per-k-step barrier sits in front of MFMA group TM-3 instead of group 0.  By then every fragment of the current tile is in
-// registers, so the barrier certifies "tile kt+1 landed, stage kt free" while three groups of MFMAs are still to be issued: the first fragment
-// reads of tile kt+1 (B fragments + A group 0) run under them instead of in front of an idle MFMA pipe, and the DMA of tile kt+3 starts there too
-// (three tiles in flight instead of two).
 template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0, int PM = 0, bool I8 = false,
-          bool F16 = false, bool SKEW = false>
+          bool F16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {   // two waves per SIMD (one 8-wave or two 4-wave workgroups)
     // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
     static_assert(BK == 64 || BK == 32, "BK");
@@ -750,82 +746,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
         for (int j = 0; j < TNT; ++j) acc[i][j] = acc_t{};
 
     const int nk = p.K / BK;
-    if constexpr (SKEW) {
-        static_assert(TM > 4 && BK == 32 && NSTAGE == 3 && ABL == 0 && TB == 1 && TM >= NPW, "skewed-barrier k-loop: tall tiles, three stages");
-        constexpr int GB = TM - 3;                       // the barrier sits in front of MFMA group GB
-        constexpr int PF = 3;
-        const bool big = NDX && wave < NDX;              // (wave-uniform) this wave issues NDF + 1 pieces per tile
-        auto wait_younger = [&](int y) {                 // this wave's pieces of all but the y youngest issued tiles have landed
-            if (y <= 0) wait_vmcnt<0>();
-            else if (y == 1) { if (big) wait_vmcnt<NDF + 1>(); else wait_vmcnt<NDF>(); }
-            else { if (big) wait_vmcnt<2 * (NDF + 1)>(); else wait_vmcnt<2 * NDF>(); }
-        };
-        auto frag = [&](const char* img, int row) { return *reinterpret_cast<const bf16x8*>(img + nt_off32(row, g)); };
-#pragma unroll
-        for (int s = 0; s < NSTAGE; ++s)
-            if (s < nk) issue(s);
-        wait_younger(min(nk - 1, 2));
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        bf16x8 bfrag[TNT], bn[TNT], af[PF][TA], an0[TA];
-#pragma unroll
-        for (int j = 0; j < TNT; ++j) bfrag[j] = frag(smem + TA * IMGA, wn * WC + 16 * j + r);
-#pragma unroll
-        for (int t = 0; t < TA; ++t) af[0][t] = frag(smem + t * IMGA, wm * WR + r);
-#pragma clang loop unroll(disable)
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* st = smem + (kt % NSTAGE) * STAGE;
-            const char* sn = smem + ((kt + 1) % NSTAGE) * STAGE;
-            auto read_a = [&](int i) {
-#pragma unroll
-                for (int t = 0; t < TA; ++t) af[i % PF][t] = frag(st + t * IMGA, wm * WR + 16 * i + r);
-            };
-            read_a(1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (i == GB) {
-                    // every fragment read of tile kt has been issued: wait for them, then meet - after this barrier nobody reads stage kt % 3
-                    // again, and everyone's pieces of tile kt + 1 are in LDS
-                    if (kt + 1 < nk) {
-                        wait_younger(kt + 2 < nk ? 1 : 0);
-                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-                        for (int j = 0; j < TNT; ++j) bn[j] = frag(sn + TA * IMGA, wn * WC + 16 * j + r);
-#pragma unroll
-                        for (int t = 0; t < TA; ++t) an0[t] = frag(sn + t * IMGA, wm * WR + r);
-                    }
-                }
-                // DMA: tile kt + 3 goes into the stage the barrier above just freed, its pieces spread over the 13 groups that follow the barrier
-                {
-                    const int T = i >= GB ? kt + 3 : kt + 2;
-                    const int slot = i >= GB ? i - GB : i + TM - GB;
-                    if (T < nk && (i >= GB || kt >= 1)) {
-#pragma unroll
-                        for (int c = 0; c < NPW; ++c)
-                            if ((c * TM) / NPW == slot) issue_piece(T, c);
-                    }
-                }
-                if (i <= GB - 1) read_a(i + PF - 1);      // (groups 2 .. TM-2; the last group's fragments follow this tile's group GB-1, below)
-#pragma unroll
-                for (int t = 0; t < TA; ++t)
-#pragma unroll
-                    for (int j = 0; j < TNT; ++j) {
-                        if constexpr (I8) {
-                            acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[i % PF][t]), __builtin_bit_cast(i32x4, bfrag[j]), acc[i][j], 0, 0, 0);
-                        } else if constexpr (F16) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i % PF][t]), __builtin_bit_cast(f16x8, bfrag[j]), acc[i][j], 0, 0, 0);
-                        } else {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % PF][t], bfrag[j], acc[i][j], 0, 0, 0);
-                        }
-                    }
-                if (i == GB - 1) read_a(TM - 1);         // slot (TM - 1) % PF == (GB - 1) % PF: this group's MFMAs have just consumed it
-            }
-#pragma unroll
-            for (int j = 0; j < TNT; ++j) bfrag[j] = bn[j];
-#pragma unroll
-            for (int t = 0; t < TA; ++t) af[0][t] = an0[t];
-        }
-    } else {
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (ABL != 2 && ABL != 6 && s < nk) issue(s);
@@ -924,7 +844,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
             }
         }
     }
-    }   // !SKEW
     __syncthreads();  // all fragment reads done: the ring is free for the epilogue
     if constexpr (ABL == 3 || ABL == 5 || ABL == 6) {
         nt_keep_alive<TM, TNT>(p, acc);
@@ -1228,13 +1147,13 @@ static void allow_lds(K kernel, size_t bytes) {
 }
 
 // one kernel instantiation per epilogue variant (NTArgs::pm); the timing-only ablations exist for the plain epilogue only
-template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD, bool I8 = false, bool F16 = false, bool SKEW = false>
+template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD, bool I8 = false, bool F16 = false>
 static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
-#define QV_PM(PM_)                                                                                                             \
-    do {                                                                                                                       \
-        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16, SKEW>, lds), true);   \
-        (void)once;                                                                                                            \
-        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16, SKEW><<<grid, WM * WN * 64, lds, st>>>(a);          \
+#define QV_PM(PM_)                                                                                                       \
+    do {                                                                                                                 \
+        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16>, lds), true);   \
+        (void)once;                                                                                                      \
+        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16><<<grid, WM * WN * 64, lds, st>>>(a);          \
     } while (0)
     if constexpr (ABL != 0) {
         QV_PM(0);
@@ -1262,13 +1181,6 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
         }
     }
 #undef QV_PM
-}
-
-// QATVIT_NT_SKEW: the tall NT k-loops with the per-step barrier in front of MFMA group 10 of 13 (template flag SKEW).  Bit 0: split-A bf16 / fp16
-// launches, bit 1: int8 launches.
-static int nt_skew() {
-    static const int on = getenv("QATVIT_NT_SKEW") ? atoi(getenv("QATVIT_NT_SKEW")) : 0;
-    return on;
 }
 
 // QATVIT_NT_BREG=1: the tall NT launches take their B operand through registers (k_gemm_nt_br).  Default 0 (both operands through LDS): measured
@@ -1336,8 +1248,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                 return 1;
             }
             constexpr size_t lds8 = 160 * 1024;   // ring 150 KiB; the epilogue's 96-row slab + row operands need 156 KiB
-            if (nt_skew() & 1) nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, false, true>(a, cdiv(M, 208), lds8, st);
-            else nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208), lds8, st);
+            nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208), lds8, st);
             return 0;
         }
         const bool ok6 = post->mode == 6 && f16 && a.post_qp && a.resid && C;
@@ -1404,8 +1315,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     if (f16) {
         if (nt_breg() && K % 64 == 0 && a.pm == 0) { nt_br_launch<2, 4, false, true, kLdsBr2>(a, cdiv(M, 208) * (N / 384), st); return 0; }
         constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
-        if (nt_skew() & 1) nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, true, true>(a, cdiv(M, 208) * (N / 384), lds, st);
-        else nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);
+        nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);
         return 0;
     }
     if (nt_breg() && !B_lo && N % 384 == 0 && K % 64 == 0 && (a.pm == 0 || (A_lo && a.pm == 5) || (!A_lo && (a.pm == 3 || a.pm == 4)))) {
@@ -1424,7 +1334,6 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                 nt_launch<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), lds, st);     \
             }                                                                                                 \
         } while (0)
-        if ((nt_skew() & 1) && tabl == 0 && tall == 1) { nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, false, true>(a, cdiv(M, 208) * (N / 384), lds, st); return 0; }
         if (tabl == 1) QV_TALL(1);
         else if (tabl == 2) QV_TALL(2);
         else if (tabl == 3) QV_TALL(3);
@@ -1543,8 +1452,7 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
     }
     if (nt_breg() && a.K % 64 == 0 && a.pm != 6 && a.pm != 7) { nt_br_launch<1, 4, true, false, 100 * 1024>(a, cdiv(M, 208) * (N / 384), st); return 0; }
     constexpr size_t lds = 3 * (208 + 384) * 64;
-    if (nt_skew() & 2) nt_launch<1, 3, 1, 13, 1, 0, 8, 3, 32, 0, true, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);
-    else nt_launch<1, 3, 1, 13, 1, 0, 8, 3, 32, 0, true>(a, cdiv(M, 208) * (N / 384), lds, st);
+    nt_launch<1, 3, 1, 13, 1, 0, 8, 3, 32, 0, true>(a, cdiv(M, 208) * (N / 384), lds, st);
     return 0;
 }
 
