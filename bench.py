@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (launch-bound small batches; N=1, no teacher)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rates", action="store_true")
+    ap.add_argument("--no-kernel-legs", action="store_true", help="skip the per-GEMM-class HIP-event legs (no roofline object; profiling tools)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C3 / C5 legs that follow the headline measurement")
     args = ap.parse_args()
 
@@ -318,7 +319,7 @@ def main():
              6: "k_gemm_tn<2,..> + k_tn_reduce: weight gradients with split X (proj / fc2; 3 bf16 passes issued)"}
     SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_forward", 3: "tn_grid_x", 6: "tn_split_x"}
     prof = {}
-    nprof = 0 if args.graph else 3
+    nprof = 0 if (args.graph or args.no_kernel_legs) else 3
     for kind in KINDS:
         if nprof == 0:
             break
@@ -328,41 +329,76 @@ def main():
             for _ in range(nprof):
                 step()
     if rank == 0 and prof:
+        c = eng.cfg
+        T = (c.img_size // c.patch_size) ** 2 + 1
+        Mr, Dm, Hd, dep = args.batch * T, c.embed_dim, c.mlp_hidden, c.depth
+        Kpe, Mpe = c.in_chans * c.patch_size ** 2, args.batch * (T - 1)
+        codes = os.environ.get("QATVIT_FC2_CODES", "1") != "0" and os.environ.get("QATVIT_F16", "1") != "0"
+        # ALGORITHMIC HBM bytes per step of each class: every operand once, in the format the kernel reads / writes it;
+        # weights once per launch; split-reduction partials, mask bit planes (1/32 of an fp32 plane) and re-reads are NOT counted
+        lnb = 4 * Mr * Dm * 4                                # fused LayerNorm backward: x, dx_in read; dx_out, masked (hi, lo) pair written
+        step_bytes = {
+            1: dep * ((Mr * Dm * 4 + Dm * Dm * 2 + Mr * Dm * 4)                                  # proj forward: fp16 pair in, fp32 out
+                      + (Mr * Hd * (1 if codes else 4) + Dm * Hd * 2 + Mr * Dm * 4)              # fc2 forward: codes (or fp16 pair) in, fp32 out
+                      + (Mr * Dm * 4 + Dm * Dm * 2 + Mr * Dm * 4)),                              # proj dgrad: bf16 pair in, fp32 out
+            4: dep * ((Mr * Hd * 4 + Dm * Hd * 2 + lnb) + (Mr * 3 * Dm * 4 + 3 * Dm * Dm * 2 + lnb)),   # fc1 dgrad, qkv dgrad (+ LayerNorm backward)
+            5: dep * (Mr * Dm * 4 + Dm * Hd * 2 + Mr * Hd * 2 + Mr * Hd * 4),                    # fc2 dgrad: pair in, uint16 codes in, pair out
+            2: (Mpe * Kpe + Dm * Kpe + Mpe * Dm * 4)
+               + dep * ((Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 4)                                # qkv forward: int8 in, fp32 out
+                        + (Mr * Dm + Hd * Dm)                                                    # fc1 statistics pass: nothing stored
+                        + (Mr * Dm + Hd * Dm + Mr * Hd * ((1 if codes else 4) + 2 + 4))),        # fc1 storing pass: codes (or fp16 pair) + uint16 code + bf16 pair
+            3: (Mpe * Dm * 4 + Mpe * Kpe * 2 + Dm * Kpe * 4)
+               + dep * ((Mr * 3 * Dm * 4 + Mr * Dm * 2 + 3 * Dm * Dm * 4) + (Mr * Hd * 4 + Mr * Dm * 2 + Hd * Dm * 4)),   # qkv, fc1 wgrad
+            6: dep * ((Mr * Dm * 4 + Mr * Dm * 4 + Dm * Dm * 4) + (Mr * Dm * 4 + Mr * Hd * 4 + Hd * Dm * 4)),             # proj, fc2 wgrad
+        }
         gemms = {}
         for kind, (ms, cnt, fl) in prof.items():
             if ms <= 0 or cnt == 0:
                 continue
             rate = fl / (ms * 1e-3) / 1e12
             peak = I8_PEAK_TOPS if kind == 2 else BF16_PEAK_TFLOPS
-            gemms[kind] = {"kernel": KINDS[kind], "ms_per_step": round(ms / nprof, 3), "launches_per_step": round(cnt / nprof, 1),
-                           "avg_us_per_launch": round(1e3 * ms / cnt, 1), "algorithmic_T(FL)OPs": round(rate, 1),
-                           "peak": peak, "frac_of_peak": round(rate / peak, 4)}
+            lps = cnt / nprof
+            by = step_bytes[kind] / lps if (args.student in ("vit_small", "vit_base") and lps > 0) else None
+            g = {"kernel": KINDS[kind], "ms_per_step": round(ms / nprof, 3), "launches_per_step": round(lps, 1),
+                 "avg_us_per_launch": round(1e3 * ms / cnt, 1), "algorithmic_T(FL)OPs": round(rate, 1),
+                 "peak": peak, "frac_of_peak": round(rate / peak, 4)}
+            if by:
+                gbs = by / (ms * 1e-3 / cnt) / 1e9
+                ai = (fl / cnt) / by
+                g.update({"algorithmic_MB_per_launch": round(by / 1e6, 1), "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                          "flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(peak * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
+                          "roofline_bound": "hbm" if ai < peak * 1e12 / (HBM_PEAK_GBS * 1e9) else "mfma"})
+            gemms[kind] = g
         if 2 in gemms:
             gemms[2]["note"] = "fc1 runs twice (statistics-only pass + storing pass): both launches are timed, only one counts as algorithmic work"
+        for k in (3, 6):
+            if k in gemms:
+                gemms[k]["note"] = "the bracket holds k_gemm_tn and its k_tn_reduce (ordered second-phase reduction of the split partials)"
         dom = max(gemms, key=lambda k: gemms[k]["ms_per_step"])          # the dominant kernel of the step = the GEMM class with the largest time
         g = gemms[dom]
+        hbm_bound = g.get("roofline_bound") == "hbm"
         traffic, traffic_note = None, None
-        if dom in (1, 4, 5):
-            try:   # HBM-side bytes per launch of the split-A kernel: NOT measured by this run - an offline rocprofv3 --pmc collection at B=256 shapes
-                pm = json.load(open(os.path.join(ROOT, "profiles", "round1_gemm_pmc_traffic_tall.json")))
-                per = [v for k, v in pm.items() if "k_gemm_nt<2, 3, 1, 13" in k][0]       # proj, fc2 fwd, qkv dgrad, fc1 dgrad, fc2 dgrad
-                mix = {1: [per[0], per[1], per[0]], 4: [per[2], per[3]], 5: [per[4]]}[dom]
-                if args.batch == 256 and args.student == "vit_small":
-                    traffic = round(sum(v["fetch_MB"] + v["write_MB"] for v in mix) / len(mix) * 1e6)
-                    traffic_note = ("STATIC, not measured in this run: mean FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch of the PLAIN-epilogue kernel "
-                                    "on these shapes, offline rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/round1_gemm_pmc_traffic_tall.json"
-                                    + ("; the fused LayerNorm backward adds its own operands (x, dx_in read; dx_out, masked pair written: 308 MB) and drops the fp32 output (77 MB)"
-                                       if dom == 4 else ""))
-            except Exception:  # noqa: BLE001
-                pass
+        try:   # HBM-side bytes per launch: NOT measured by this run - offline rocprofv3 --pmc passes at B=256 shapes (tools/pmc_traffic.sh)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round2_gemm_pmc_traffic.json")))
+            if args.batch == 256 and args.student == "vit_small" and str(dom) in pm:
+                traffic = round(pm[str(dom)]["bytes_per_launch"])
+                traffic_note = "STATIC, not measured in this run: " + pm[str(dom)]["note"]
+        except Exception:  # noqa: BLE001
+            pass
         res["roofline"] = {
-            "bound": "mfma", "kernel": "qv::" + g["kernel"] + " - the GEMM kernel with the largest share of the step (208x384 tiles)",
-            "achieved": g["algorithmic_T(FL)OPs"], "peak": g["peak"], "unit": "TOP/s" if dom == 2 else "TFLOP/s", "frac": g["frac_of_peak"],
+            "bound": "hbm" if hbm_bound else "mfma",
+            "kernel": "qv::" + g["kernel"] + " - the GEMM kernel with the largest share of the step (208x384 tiles)",
+            "achieved": g["algorithmic_GBps"] if hbm_bound else g["algorithmic_T(FL)OPs"],
+            "peak": HBM_PEAK_GBS if hbm_bound else g["peak"],
+            "unit": "GB/s" if hbm_bound else ("TOP/s" if dom == 2 else "TFLOP/s"),
+            "frac": g["frac_of_hbm_peak"] if hbm_bound else g["frac_of_peak"],
             "traffic": traffic, "traffic_note": traffic_note, "launches": int(g["launches_per_step"] * nprof), "avg_us_per_launch": g["avg_us_per_launch"],
-            "note": f"algorithmic FLOPs 2*M*N*K per launch / HIP-event time of that launch on its launch stream, {nprof} steps run right after the timed "
-                    "region (no event is recorded inside the timed region); split-A launches issue two 16-bit MFMA passes (hi and lo): issued MFMA work is 2x "
-                    "the algorithmic figure; a fused epilogue's time (LayerNorm / GELU backward: HBM-bound work that used to be its own kernel) counts "
-                    "against the GEMM's FLOPs",
+            "flop_per_byte": g.get("flop_per_byte"), "ridge_flop_per_byte": g.get("ridge_flop_per_byte"),
+            "mfma_side": {"achieved": g["algorithmic_T(FL)OPs"], "peak": g["peak"], "frac": g["frac_of_peak"]},
+            "note": f"per launch: algorithmic bytes (every operand once in its stored format: DESIGN.md section 4) and algorithmic FLOPs 2*M*N*K / HIP-event time of that "
+                    f"launch on its launch stream, {nprof} steps run right after the timed region (no event is recorded inside the timed region).  The bound is the "
+                    "roofline that binds at the kernel's arithmetic intensity (flop_per_byte against the ridge peak_flops / peak_bytes); the other side is in "
+                    "mfma_side.  Split-A launches issue two 16-bit MFMA passes (hi and lo): issued MFMA work is 2x the algorithmic figure",
         }
         res["mfma_gemms"] = {SHORT[k]: v for k, v in gemms.items()}
     if rank == 0 and not args.no_kernel_rates:
