@@ -334,6 +334,7 @@ def main():
         Mr, Dm, Hd, dep = args.batch * T, c.embed_dim, c.mlp_hidden, c.depth
         Kpe, Mpe = c.in_chans * c.patch_size ** 2, args.batch * (T - 1)
         codes = os.environ.get("QATVIT_FC2_CODES", "1") != "0" and os.environ.get("QATVIT_F16", "1") != "0"
+        qkv2 = os.environ.get("QATVIT_QKV_2PASS", "1") != "0" and os.environ.get("QATVIT_ATTN_CODES", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0"
         # ALGORITHMIC HBM bytes per step of each class: every operand once, in the format the kernel reads / writes it;
         # weights once per launch; split-reduction partials, mask bit planes (1/32 of an fp32 plane) and re-reads are NOT counted
         lnb = 4 * Mr * Dm * 4                                # fused LayerNorm backward: x, dx_in read; dx_out, masked (hi, lo) pair written
@@ -344,7 +345,7 @@ def main():
             4: dep * ((Mr * Hd * 4 + Dm * Hd * 2 + lnb) + (Mr * 3 * Dm * 4 + 3 * Dm * Dm * 2 + lnb)),   # fc1 dgrad, qkv dgrad (+ LayerNorm backward)
             5: dep * (Mr * Dm * 4 + Dm * Hd * 2 + Mr * Hd * 2 + Mr * Hd * 4),                    # fc2 dgrad: pair in, uint16 codes in, pair out
             2: (Mpe * Kpe + Dm * Kpe + Mpe * Dm * 4)
-               + dep * ((Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 4)                                # qkv forward: int8 in, fp32 out
+               + dep * ((2 * (Mr * Dm + 3 * Dm * Dm) + Mr * 3 * Dm * 9 // 8 if qkv2 else Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 4)   # qkv forward: statistics pass + code pass (1 B + 1 bit out), or one pass with fp32 out
                         + (Mr * Dm + Hd * Dm)                                                    # fc1 statistics pass: nothing stored
                         + (Mr * Dm + Hd * Dm + Mr * Hd * ((1 if codes else 4) + 2 + 4))),        # fc1 storing pass: codes (or fp16 pair) + uint16 code + bf16 pair
             3: (Mpe * Dm * 4 + Mpe * Kpe * 2 + Dm * Kpe * 4)
@@ -370,7 +371,7 @@ def main():
                           "roofline_bound": "hbm" if ai < peak * 1e12 / (HBM_PEAK_GBS * 1e9) else "mfma"})
             gemms[kind] = g
         if 2 in gemms:
-            gemms[2]["note"] = "fc1 runs twice (statistics-only pass + storing pass): both launches are timed, only one counts as algorithmic work"
+            gemms[2]["note"] = "fc1 and qkv run twice (statistics-only pass + storing pass): both launches are timed, only one counts as algorithmic work"
         for k in (3, 6):
             if k in gemms:
                 gemms[k]["note"] = "the bracket holds k_gemm_tn and its k_tn_reduce (ordered second-phase reduction of the split partials)"

@@ -238,6 +238,15 @@ static bool attn_codes(const qatvit_cfg& c) {
     return on != 0 && c.act_qmax - c.act_qmin <= 255;
 }
 
+// QATVIT_QKV_2PASS=0: the qkv GEMM once, writing its fp32 pre-fake-quant output (232 MB per block at batch 256) that the attention forward reads back,
+// quantises and saves as codes - instead of twice (a statistics-only pass for the observer, then a pass whose epilogue quantises with the fresh
+// qparams and writes the uint8 codes + STE mask bits in the attention layout: the fp32 tensor never exists, the attention forward reads 1 B per element)
+static bool qkv_2pass(const qatvit_cfg& c) {
+    static const int on = getenv("QATVIT_QKV_2PASS") ? atoi(getenv("QATVIT_QKV_2PASS")) : 1;
+    const int hd = c.embed_dim / c.num_heads;
+    return on != 0 && attn_codes(c) && use_i8() && (3 * c.embed_dim) % 384 == 0 && c.embed_dim % 64 == 0 && hd % 32 == 0;
+}
+
 // QATVIT_LNB_FUSE=0: the LayerNorm backward as its own kernel behind the fc1 / qkv dgrad GEMM (re-reads the fp32 gradient those wrote) instead
 // of inside their epilogue (embed_dim 384 only: the 208 x 384 tile holds whole rows)
 static bool lnb_fuse() {
@@ -339,7 +348,7 @@ struct Ctx {
 // One transformer block of the forward, in four parts that each start where the stage-level parity tests inject the oracle's tensor (behind
 // a fake-quantizer that would otherwise amplify upstream one-step flips): 0 = norm1 -> qkv GEMM; 1 = attention -> proj -> residual;
 // 2 = norm2 -> fc1 -> GELU; 3 = fc2 -> residual.
-static int fwd_block(const Ctx& x, int i, int parts) {
+static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) {
     const Dims& d = x.d;
     const Plan& p = x.p;
     const qatvit_cfg& c = x.c;
@@ -353,16 +362,29 @@ static int fwd_block(const Ctx& x, int i, int parts) {
         x.qparams_act(x.aidx(i, AB_N1));
         launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
                               qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h1q8, i) : nullptr, x.center());
-        if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB),
-                              x.blk<float>(p.qkv, i), x.aidx(i, AB_QKV)))
+        if (qkv_2pass(c)) {
+            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
+            if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
+                                  x.aidx(i, AB_QKV), &p1))
+                return 1;
+            x.qparams_act(x.aidx(i, AB_QKV));
+            NTPost p2{};
+            p2.mode = 7; p2.qp = x.act_qp(x.aidx(i, AB_QKV)); p2.qmin = qa; p2.qmax = qb;
+            p2.out8 = x.blk<void>(p.qkv8, i); p2.out8_mask = x.blk<void>(p.qkvm, i); p2.code_T = (int)d.T; p2.code_hd = (int)(d.D / d.H);
+            if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
+                                  x.aidx(i, AB_QKV), &p2, false))
+                return 1;
+        } else if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB),
+                                     x.blk<float>(p.qkv, i), x.aidx(i, AB_QKV)))
             return 1;
         }
         const bool proj16 = x.f16_ok(x.widx(i, WB_PROJ)), fc2_16 = x.f16_ok(x.widx(i, WB_FC2)) && fc1_recompute();
         const bool fc2_c = fc2_16 && fc2_codes() && d.Hd % 64 == 0 && c.act_qmax - c.act_qmin <= 255;
         float* const scal16 = x.at<float>(p.scal16);
         if (parts & 2) {   // ---- part 1: attention -> proj -> residual (+ statistics of norm2)
-        x.qparams_act(x.aidx(i, AB_QKV));
-        if (launch_attn_fwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
+        const bool from_codes = qkv_2pass(c) && !qkv_injected;   // part 0 left the code plane (and ran the observer); an injected fp32 qkv takes the one-pass route
+        if (!from_codes) x.qparams_act(x.aidx(i, AB_QKV));
+        if (launch_attn_fwd(from_codes ? nullptr : x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
                             x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), st, proj16 ? x.at<void>(p.O16_hi) : nullptr,
                             proj16 ? x.at<void>(p.O16_lo) : nullptr, proj16 ? scal16 : nullptr, attn_codes(x.c) ? x.blk<void>(p.qkv8, i) : nullptr,
                             attn_codes(x.c) ? x.blk<void>(p.qkvm, i) : nullptr))
@@ -473,7 +495,7 @@ static int fwd_part(const Ctx& x, int block, int part, bool inject) {
                 return 1;
         }
     }
-    return fwd_block(x, block, 1 << part);
+    return fwd_block(x, block, 1 << part, inject && part == 1);
 }
 
 // forward stages: 0 = weight preparation + input fake-quant + patch embedding (leaves x_in[0]); s in 1..depth = block s-1 (leaves
@@ -814,7 +836,7 @@ int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, in
         {"Y1", p.Y1, true}, {"G_hi", p.G_hi, true}, {"G_lo", p.G_lo, true}, {"Y2", p.Y2, true}, {"dxA", p.dxA, false}, {"dqkv_hi", p.dqkv_hi, false},
         {"dqkv_lo", p.dqkv_lo, false}, {"dO", p.dO, false},
         {"dH", p.dH, false}, {"lse", p.lse, true}, {"O16_hi", p.O16_hi, false}, {"O16_lo", p.O16_lo, false}, {"G16_hi", p.G16_hi, false},
-        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false}, {"G8", p.G8, true}, {"glut", p.glut, true},
+        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false}, {"G8", p.G8, true}, {"glut", p.glut, true}, {"qkv8", p.qkv8, true}, {"qkvm", p.qkvm, true},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) return t.off + (t.per_block ? p.blk_stride * block : 0);

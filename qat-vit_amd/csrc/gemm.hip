@@ -144,6 +144,9 @@ struct NTArgs {
     // pair of 2^k * gelu(grid value) per index - together the A operand of k_gemm_nt_ac (fc2 forward from codes: 1 B instead of 4 B per element)
     uint32_t* lut_out;
     const uint32_t* a_lut;   // k_gemm_nt_ac: the table its uint8 A operand (A0, lda in BYTES) is expanded through
+    // mode 7 (optional, training): the STE mask bit of every element (t = rint(v / s) + zp inside [qmin, qmax]) next to the codes, one bit per
+    // element in the same [b][h][which][t][d] order (bit d % 8 of byte (... * hd + d) / 8) - what the attention forward writes when it quantises itself
+    uint8_t* out8_mask;
 };
 
 constexpr int kStandIn = 512;
@@ -403,7 +406,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
 #ifndef QV_EPI_U
 #define QV_EPI_U 4
 #endif
-        if constexpr ((PM == 0 || PM == 4 || PM == 5) && QV_EPI_U > 1) {
+        if constexpr ((PM == 0 || PM == 4 || PM == 5 || PM == 7) && QV_EPI_U > 1) {
             // Software-pipelined store loop: U iterations' LDS reads (staged values, codes), then their table lookups, then the stores.
             // The rolled loop below is one LDS round trip (two with a table) per 16 B stored at two waves per SIMD; the row guard moves
             // onto the stores so that no branch separates the reads.
@@ -467,6 +470,36 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         }
                         if (ok[u] && w8)
                             *reinterpret_cast<uint32_t*>(p.out8 + off[u]) = (cd[u][0] & 0xffu) | ((cd[u][1] & 0xffu) << 8) | ((cd[u][2] & 0xffu) << 16) | (cd[u][3] << 24);
+                    }
+                } else if constexpr (PM == 7) {
+                    const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
+                    // element offset in the [b][h][which][t][d] plane without integer divisions: (x + 0.5) * (1 / n) floors exactly for x < 2^22, n < 2^10
+                    // (the error of the product stays far below the 0.5 / n distance to the next integer); head_dim is a power of two
+                    const int Dm = p.N / 3, Hh = Dm / p.code_hd, hsh = 31 - __builtin_clz(p.code_hd);
+                    const float invT = 1.0f / (float)p.code_T, invD = 1.0f / (float)Dm;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float cv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                        uint32_t pk = 0, mk = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = rintf(cv[e] * qinv) + qzp, tc = fminf(fmaxf(t, fmin_), fmax_);
+                            pk = __builtin_amdgcn_cvt_pk_u8_f32(tc - fmin_, e, pk);
+                            mk |= (uint32_t)(t == tc) << e;
+                        }
+                        const int idx = base + u * NT_;
+                        const int row = m0 + SLAB * h + idx / C4, c = n0 + 4 * (idx % C4);
+                        const int bb = (int)(((float)row + 0.5f) * invT), tt = row - bb * p.code_T;
+                        const int which = (int)(((float)c + 0.5f) * invD), cm = c - which * Dm, hh = cm >> hsh, d = cm & (p.code_hd - 1);
+                        const int64_t eo = ((((int64_t)bb * Hh + hh) * 3 + which) * p.code_T + tt) * p.code_hd + d;
+                        // 8 consecutive lanes hold 32 consecutive features of one row: the first of them stores their 32 mask bits (the shuffles run
+                        // unconditionally: a group shares `row`, so it is valid or invalid as a whole)
+#pragma unroll
+                        for (int k = 1; k < 8; ++k) mk |= ((uint32_t)__shfl_down((int)(mk & 0xfu), k, 64) & 0xfu) << (4 * k);
+                        if (ok[u]) {
+                            *reinterpret_cast<uint32_t*>(p.out8 + eo) = pk;
+                            if (p.out8_mask && (lane & 7) == 0) *reinterpret_cast<uint32_t*>(p.out8_mask + (eo >> 3)) = mk;
+                        }
                     }
                 } else {   // PM == 5
                     float dg[U][4];
@@ -589,12 +622,24 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                 } else if constexpr (PM == 7) {
                     const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
                     const float cv[4] = {v.x, v.y, v.z, v.w};
-                    uint32_t pk = 0;
+                    uint32_t pk = 0, mk = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk = __builtin_amdgcn_cvt_pk_u8_f32(fminf(fmaxf(rintf(cv[e] * qinv) + qzp, fmin_), fmax_) - fmin_, e, pk);
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = rintf(cv[e] * qinv) + qzp, tc = fminf(fmaxf(t, fmin_), fmax_);
+                        pk = __builtin_amdgcn_cvt_pk_u8_f32(tc - fmin_, e, pk);
+                        mk |= (uint32_t)(t == tc) << e;
+                    }
                     const int c = n0 + 4 * c4, Dm = p.N / 3, which = c / Dm, hh = (c % Dm) / p.code_hd, d = c % p.code_hd, Hh = Dm / p.code_hd;
                     const int64_t bb = row / p.code_T, tt = row % p.code_T;
-                    *reinterpret_cast<uint32_t*>(p.out8 + ((((bb * Hh + hh) * 3 + which) * p.code_T + tt) * p.code_hd + d)) = pk;
+                    const int64_t eo = (((bb * Hh + hh) * 3 + which) * p.code_T + tt) * p.code_hd + d;
+                    *reinterpret_cast<uint32_t*>(p.out8 + eo) = pk;
+                    if (p.out8_mask) {
+                        // 8 consecutive lanes hold 32 consecutive features of one row (idx % 8 == lane % 8, C4 % 8 == 0, head_dim % 32 == 0): the first of
+                        // them stores their 32 mask bits (the group is active or inactive as a whole: it shares `row`)
+#pragma unroll
+                        for (int k = 1; k < 8; ++k) mk |= ((uint32_t)__shfl_down((int)(mk & 0xfu), k, 64) & 0xfu) << (4 * k);
+                        if ((lane & 7) == 0) *reinterpret_cast<uint32_t*>(p.out8_mask + eo / 8) = mk;
+                    }
                 } else if constexpr (PM == 2) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     const float cv[4] = {v.x, v.y, v.z, v.w};
@@ -1430,11 +1475,11 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
         a.post_code = reinterpret_cast<uint16_t*>(post->code);
         a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
         a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
-        a.lut_out = post->lut_out;
+        a.lut_out = post->lut_out; a.out8_mask = reinterpret_cast<uint8_t*>(post->out8_mask);
         const bool full4 = a.out_hi && a.out_lo && a.post_code, half4 = !a.out_hi && !a.out_lo && !a.post_code && a.out16_hi && a.out16_lo && a.out16_scale;
         if ((post->mode == 4 && (!a.post_qp || !(full4 || half4) || a.post_qmax - a.post_qmin >= 256)) ||
             (post->mode == 6 && (!a.post_qp || !a.resid || !C)) ||
-            (post->mode == 7 && (!a.post_qp || !a.out8 || a.code_T < 1 || a.code_hd < 8 || (N / 3) % a.code_hd != 0 || a.post_qmax - a.post_qmin >= 256))) {
+            (post->mode == 7 && (!a.post_qp || !a.out8 || a.code_T < 1 || a.code_hd < 8 || (a.out8_mask && a.code_hd % 32 != 0) || (a.code_hd & (a.code_hd - 1)) != 0 || M >= (1 << 22) || N / 3 >= 1024 || a.code_T >= 1024 || (N / 3) % a.code_hd != 0 || a.post_qmax - a.post_qmin >= 256))) {
             set_error("gemm_nt_i8: incomplete arguments for epilogue mode %d", post->mode);
             return 1;
         }

@@ -59,6 +59,8 @@ struct NTPost {
     // mode 4, optional: out8 = the grid index (q - qmin) of every element as uint8 [M, ldc] and lut_out[256] = packed fp16 (hi | lo << 16) pair of
     // 2^k * gelu(grid value) per index (with out16_scale): the A operand of launch_gemm_nt_codes - fc2 forward from 1 B per element
     uint32_t* lut_out = nullptr;
+    // mode 7, optional (training): the STE mask bit of every element in the same order as the codes, one bit per element (head_dim % 32 == 0)
+    void* out8_mask = nullptr;
     // mode 8 (split-A dgrad whose output rows are whole LayerNorm rows, N == 384): the LayerNorm backward fused into the epilogue -
     // C = dx_out = dx_in + LNbwd(acc * alpha * mask(LN(x))), dgamma / dbeta accumulated, and (out_hi / out_lo non-null) the masked (hi, lo)
     // copy of dx_out for the next branch: nmask = that branch output's STE mask words, colscale = its per-channel weight scale.

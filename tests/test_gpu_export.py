@@ -49,9 +49,9 @@ def test_int8_export_roundtrip_is_exact(native_lib, backend):
         out = back(x)
     assert torch.equal(out, ref)
     # integer check of one layer: exported int8 weight x the quantised input grid, accumulated as integers, scaled and biased in fp32 in
-    # the kernel's order, equals the pre-fake-quant qkv tensor the native GEMM produced - bit for bit
+    # the kernel's order, equals what the native GEMM quantised (the qkv codes it wrote) - bit for bit
     from qat_vit_amd.engine import engine_of
-    from tests.util import ws_tensor
+    from tests.util import qkv_ints, ws_tensor
 
     eng = engine_of(back)
     M, D = 4 * 5, 128
@@ -65,5 +65,8 @@ def test_int8_export_roundtrip_is_exact(native_lib, backend):
         want = acc * (a["scale"].float() * s_w) + d["bias"]
     else:
         want = acc * (a["scale"].float() * s_w)[None, :] + d["bias"]
-    got = ws_tensor(eng, "qkv", 0, (M, 3 * D)).cpu()
-    assert torch.equal(got, want)
+    # (the engine never stores this fp32 tensor: the GEMM's second pass quantises it at once) - the same quantisation of `want`, then exact
+    fq = dict(back.named_modules())["model.blocks.0.attn.qkv.activation_post_process"]
+    t = torch.round(want * (1.0 / fq.scale.cpu().float())) + fq.zero_point.cpu().float()
+    want_q = torch.clamp(t, eng.cfg.act_qmin, eng.cfg.act_qmax) - fq.zero_point.cpu().float()
+    assert torch.equal(qkv_ints(eng, 0, fq).cpu(), want_q)

@@ -36,7 +36,7 @@ pytestmark = pytest.mark.gpu
 import qat_vit_amd  # noqa: E402
 from oracle import step_ref  # noqa: E402
 from qat_vit_amd import engine as E  # noqa: E402
-from tests.util import capture_fq_io, fq_modules, prepare, rel_l2  # noqa: E402
+from tests.util import capture_fq_io, fq_modules, prepare, qkv_ints, qkv_mask, rel_l2  # noqa: E402
 
 CODE_FLIP_FRAC = 1e-4
 TOL = 1e-3
@@ -199,16 +199,23 @@ def _run(backend, seed, teacher, golden_tag):
     Hd = c.mlp_hidden
     f16 = os.environ.get("QATVIT_F16", "1") != "0"
     fc2_codes = f16 and os.environ.get("QATVIT_FC2_CODES", "1") != "0"
+    qkv_2pass = os.environ.get("QATVIT_QKV_2PASS", "1") != "0" and os.environ.get("QATVIT_ATTN_CODES", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0" and qb - qa <= 255
 
     def cmp_part(tb, st, i, part, lim=CODE_FLIP_FRAC, tol=TOL, split_fc2=True):
         """Everything part `part` of block i left in the workspace against the oracle."""
         pre = f"model.blocks.{i}"
         if part == 0:
             tb.codes(st, "norm1", eng.tensor("h1q", i, (M, D), torch.bfloat16), tr.codes(f"{pre}.norm1.{A}").reshape(M, D), lim)
-            tb.close(st, "attn.qkv pre-FQ", eng.tensor("qkv", i, (M, 3 * D)), tr.pre(f"{pre}.attn.qkv.{A}").reshape(M, 3 * D), tol)
+            if qkv_2pass:   # the qkv GEMM's second pass wrote codes + STE mask bits (no fp32 tensor): the quantised values and the mask it left
+                tb.codes(st, "attn.qkv (codes from the GEMM epilogue)", qkv_ints(eng, i, fqm[f"{pre}.attn.qkv.{A}"]), tr.codes(f"{pre}.attn.qkv.{A}").reshape(M, 3 * D), lim)
+                oq = tr.fq[f"{pre}.attn.qkv.{A}"]
+                ref_in = (tr.pre(f"{pre}.attn.qkv.{A}") * (1.0 / oq.scale)).round() + oq.zero_point
+                tb.codes(st, "attn.qkv STE mask", qkv_mask(eng, i).float(), ((ref_in >= qa) & (ref_in <= qb)).reshape(M, 3 * D).float(), lim)
+            else:
+                tb.close(st, "attn.qkv pre-FQ", eng.tensor("qkv", i, (M, 3 * D)), tr.pre(f"{pre}.attn.qkv.{A}").reshape(M, 3 * D), tol)
         elif part == 1:
-            qkv = eng.tensor("qkv", i, (M, 3 * D))
-            tb.codes(st, "attn.qkv", _fq_of_codes(qkv, fqm[f"{pre}.attn.qkv.{A}"], qa, qb), tr.codes(f"{pre}.attn.qkv.{A}").reshape(M, 3 * D), lim)
+            # the codes the attention forward worked from (saved by itself from an injected fp32 qkv, or by the qkv GEMM's second pass)
+            tb.codes(st, "attn.qkv", qkv_ints(eng, i, fqm[f"{pre}.attn.qkv.{A}"]), tr.codes(f"{pre}.attn.qkv.{A}").reshape(M, 3 * D), lim)
             o = eng.tensor("O_hi", i, (M, D), torch.bfloat16).float() + eng.tensor("O_lo", i, (M, D), torch.bfloat16).float()
             tb.close(st, "attention out (bf16 pair, bwd)", o, tr.proj_in[i].reshape(M, D), tol)
             if f16:   # the fp16 (hi, lo) pair the proj forward GEMM actually read (one buffer shared by all blocks: this block's)

@@ -54,3 +54,25 @@ def cosine(a, b):
     a = np.asarray(a, np.float64).ravel()
     b = np.asarray(b, np.float64).ravel()
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+def qkv_ints(eng, block, fq_mod):
+    """The fake-quantised qkv of one block as integers q - zp, [tokens, 3 * embed_dim] in the module's column order, from the uint8 code plane
+    (q - qmin, layout [image][head][q|k|v][token][d]) that the qkv GEMM's second pass - or, with QATVIT_QKV_2PASS=0, the attention forward -
+    left in the workspace.  The fp32 pre-fake-quant qkv tensor does not exist in the two-pass form."""
+    c = eng.cfg
+    B, H, D = c.batch, c.num_heads, c.embed_dim
+    T = (c.img_size // c.patch_size) ** 2 + 1
+    c8 = eng.tensor("qkv8", block, (B, H, 3, T, D // H), torch.uint8)
+    return c8.permute(0, 3, 2, 1, 4).reshape(B * T, 3 * D).float() + c.act_qmin - fq_mod.zero_point.float()
+
+
+def qkv_mask(eng, block):
+    """The STE mask bits saved next to the codes, as a bool [tokens, 3 * embed_dim] tensor."""
+    c = eng.cfg
+    B, H, D = c.batch, c.num_heads, c.embed_dim
+    T = (c.img_size // c.patch_size) ** 2 + 1
+    hd = D // H
+    m = eng.tensor("qkvm", block, (B, H, 3, T, hd // 8), torch.uint8).int()
+    bits = ((m.unsqueeze(-1) >> torch.arange(8, device=m.device)) & 1).reshape(B, H, 3, T, hd)
+    return bits.permute(0, 3, 2, 1, 4).reshape(B * T, 3 * D).bool()
