@@ -108,12 +108,6 @@ int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
                        int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream);
 
-/* qatvit_gemm_nt (f16 == 0: bf16 pair A) / qatvit_gemm_nt_f16 (f16 != 0: fp16 pair A) with the weight integers as int8 [N,ldb]: the kernel
- * widens them to the MFMA type in registers - bit-identical results, half the weight bytes on the L2 -> CU path that bounds the k-loop.
- * N % 384 == 0, K % 64 == 0, ldb % 16 == 0. */
-int qatvit_gemm_nt_w8(const void* A_hi, const void* A_lo, const void* B8, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
-                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int32_t f16, void* stream);
-
 /* qatvit_gemm_nt_f16 for an A operand that takes at most 256 distinct values (mlp.fc2: A = gelu(fq(fc1 output))): A8 uint8 [M,lda] = table
  * index per element (lda in bytes), lut[256] = the fp16 (hi | lo << 16) pair per index.  The kernel expands the codes through the table on their
  * way into LDS: bit-identical to qatvit_gemm_nt_f16 on the expanded planes, 1 B instead of 4 B of HBM traffic per A element.

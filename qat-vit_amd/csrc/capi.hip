@@ -99,15 +99,6 @@ int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, 
     return 0;
 }
 
-int qatvit_gemm_nt_w8(const void* A_hi, const void* A_lo, const void* B8, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
-                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int32_t f16, void* stream) {
-    QV_CHECK_ARG(A_hi && A_lo && B8 && C, "qatvit_gemm_nt_w8: null pointer argument");
-    QV_CHECK_ARG(N % 384 == 0 && K % 64 == 0 && ldb % 16 == 0, "qatvit_gemm_nt_w8: needs N % 384 == 0, K % 64 == 0, ldb % 16 == 0 (the tall split-A tile)");
-    if (launch_gemm_nt(A_hi, A_lo, B8, C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream, nullptr, nullptr, f16 != 0, B8)) return 1;
-    QV_CHECK_LAUNCH("qatvit_gemm_nt_w8");
-    return 0;
-}
-
 int qatvit_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
                          int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream) {
     QV_CHECK_ARG(A8 && lut && B16 && C, "qatvit_gemm_nt_codes: null pointer argument");

@@ -626,8 +626,7 @@ __global__ __launch_bounds__(64) void k_embed_bwd(const float* __restrict__ dx0,
 // wq[n][k] = q(W[n][k]) - zp (bf16), wqT[k][n] = same, transposed (dgrad's B operand)
 __device__ inline void wquant_body(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
                                    __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K, int bx, int by,
-                                   int8_t* __restrict__ w8 = nullptr, int32_t* __restrict__ wsum = nullptr, _Float16* __restrict__ w16 = nullptr,
-                                   int8_t* __restrict__ wT8 = nullptr) {
+                                   int8_t* __restrict__ w8 = nullptr, int32_t* __restrict__ wsum = nullptr, _Float16* __restrict__ w16 = nullptr) {
     // 32x32 tile transpose through LDS
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -656,10 +655,7 @@ __device__ inline void wquant_body(const float* __restrict__ W, const float* __r
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + ty + 8 * i, n = n0 + tx;
-            if (n < N && k < K) {
-                wqT[(int64_t)k * N + n] = (__bf16)tile[tx][ty + 8 * i];
-                if (wT8) wT8[(int64_t)k * N + n] = (int8_t)tile[tx][ty + 8 * i];
-            }
+            if (n < N && k < K) wqT[(int64_t)k * N + n] = (__bf16)tile[tx][ty + 8 * i];
         }
     }
 }
@@ -672,8 +668,7 @@ __global__ __launch_bounds__(256) void k_w_quant_all(const WQuantTab t) {
     while (wi + 1 < t.n && (int)blockIdx.x >= t.blk0[wi + 1]) ++wi;
     const int b = blockIdx.x - t.blk0[wi], kt = (t.K[wi] + 31) / 32;
     wquant_body(t.W[wi], t.qp[wi], t.per_channel, t.qmin, t.qmax, reinterpret_cast<__bf16*>(t.wq[wi]), reinterpret_cast<__bf16*>(t.wqT[wi]), t.N[wi],
-                t.K[wi], b % kt, b / kt, reinterpret_cast<int8_t*>(t.w8[wi]), t.wsum[wi], reinterpret_cast<_Float16*>(t.w16[wi]),
-                reinterpret_cast<int8_t*>(t.wT8[wi]));
+                t.K[wi], b % kt, b / kt, reinterpret_cast<int8_t*>(t.w8[wi]), t.wsum[wi], reinterpret_cast<_Float16*>(t.w16[wi]));
 }
 
 // ============================================================================ launchers

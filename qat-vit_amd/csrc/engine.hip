@@ -71,7 +71,6 @@ struct Plan {
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
     int64_t w8_off[64 * 4 + 8], wsum_off[64 * 4 + 8], wsum_base, wsum_bytes, imgq8, h1q8, h2q8;   // int8 operands of the forward grid x grid GEMMs
-    int64_t wT8_off[64 * 4 + 8];    // the transposed weight integers as int8 (B operand of the split-A dgrad GEMMs: half the L2 -> CU bytes of the bf16 copy)
     int64_t w16_off[64 * 4 + 8], O16_hi, O16_lo, G16_hi, G16_lo, scal16;   // fp16 operands of the forward float x grid GEMMs (proj, fc2): shared by all blocks
     int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo, tn_scratch;
     int64_t total, stats_words;
@@ -135,7 +134,6 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
         p->w8_off[wi] = take((int64_t)N * K);
         const int kind = (wi == 0 || wi == d.n_w - 1) ? -1 : (wi - 1) % WB_COUNT;
         p->w16_off[wi] = (kind == WB_PROJ || kind == WB_FC2) ? take((int64_t)N * K * 2) : -1;
-        p->wT8_off[wi] = kind >= 0 ? take((int64_t)N * K) : -1;
     }
     // the float A operands of the two forward GEMMs with a float operand, as fp16 (hi, lo) pairs: written and consumed inside one block's
     // forward, so ONE set serves every block (the bf16 pairs next to them stay per block: the weight-gradient GEMMs read them in the backward)
@@ -299,8 +297,7 @@ struct Ctx {
         const qatvit_fq& f = wfq[wi];
         ProfScope ps(prof, 1, 2.0 * M * N * K, st);
         return launch_gemm_nt(A16_hi, A16_lo, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
-                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, nullptr, nullptr, true,
-                              use_i8() && w_batched(d) ? at<void>(p.w8_off[wi]) : nullptr);
+                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, nullptr, nullptr, true);
     }
     // the same product with the A operand as uint8 table indices [M, K] + the 256-entry table of fp16 pairs (fc2: gelu(fq(.)) takes <= 256 values)
     int linear_fwd_codes(const void* A8, const uint32_t* lut, const float* pair_scale, int M, int wi, const float* bias, float* C, int ai_out) const {
@@ -335,7 +332,7 @@ struct Ctx {
         const qatvit_fq& f = wfq[wi];
         ProfScope ps(prof, !post ? 1 : post->mode == 8 ? 4 : 5, 2.0 * M * N * K, st);   // plain | + fused LayerNorm backward | + fused GELU' (fc2 dgrad)
         return launch_gemm_nt(dY_hi, dY_lo, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr,
-                              nullptr, nullptr, 1, st, nullptr, post, false, w_batched(d) && p.wT8_off[wi] >= 0 ? at<void>(p.wT8_off[wi]) : nullptr);
+                              nullptr, nullptr, 1, st, nullptr, post);
     }
     // wgrad: dW[N,K] += sum_m dY[m,N] X[m,K] * s_x, masked by the weight FQ; db[N] += sum_m dY
     int linear_wgrad(const void* dY_hi, const void* dY_lo, int M, int wi, const void* X_hi, const void* X_lo, const float* s_x, float* dW, float* db,
@@ -534,7 +531,6 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
             tw.wq[wi] = x.at<void>(p.w_off[wi]); tw.wqT[wi] = x.at<void>(p.wT_off[wi]);
             tw.w8[wi] = use_i8() ? x.at<void>(p.w8_off[wi]) : nullptr;
             tw.w16[wi] = x.f16_ok(wi) ? x.at<void>(p.w16_off[wi]) : nullptr;
-            tw.wT8[wi] = p.wT8_off[wi] >= 0 ? x.at<void>(p.wT8_off[wi]) : nullptr;
             tw.wsum[wi] = use_i8() ? x.at<int32_t>(p.wsum_off[wi]) : nullptr;
         }
         if (use_i8()) launch_zero_i32(x.at<int32_t>(p.wsum_base), p.wsum_bytes / 4, st);   // row sums are accumulated with integer atomics

@@ -706,32 +706,6 @@ __device__ inline void nt_keep_alive(const NTArgs& p, ACC (&acc)[TM][TNT]) {
     if (t == 1.2345e-30f) p.C[1 << 20] = t;
 }
 
-// 8 signed int8 -> 8 fp16 / bf16, exact.  fp16: halfword 0x6400 | b is 1024 + b (b = w + 128: one XOR per dword), so a byte permute builds two
-// values at once and one packed add takes 1152 off again.  bf16: the same through fp32 (0x4B000000 | b = 2^23 + b).
-__device__ inline f16x8 i8x8_to_f16(const uint2 v) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const uint32_t x[2] = {v.x ^ 0x80808080u, v.y ^ 0x80808080u};
-    const h2 off = {(_Float16)1152.0f, (_Float16)1152.0f};
-    f16x8 f;
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        const h2 a = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, x[d], 0x04010400u)) - off;
-        const h2 b = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, x[d], 0x04030402u)) - off;
-        f[4 * d] = a[0]; f[4 * d + 1] = a[1]; f[4 * d + 2] = b[0]; f[4 * d + 3] = b[1];
-    }
-    return f;
-}
-__device__ inline bf16x8 i8x8_to_bf16(const uint2 v) {
-    const uint32_t x[2] = {v.x ^ 0x80808080u, v.y ^ 0x80808080u};
-    bf16x8 f;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            f[4 * d + e] = (__bf16)(__builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, x[d], 0x07040400u + (uint32_t)e)) - 8388736.0f);
-    return f;
-}
-
 // LDS image of a BK = 32 tile: two 64-B tile rows share one 128-B LDS row; chunk index ((row & 1) * 4 + k-chunk) XOR (LDS row & 7).
 __device__ inline int nt_off32(int row, int chunk) {
     const int R = row >> 1;
@@ -743,11 +717,8 @@ __device__ inline int nt_off32(int row, int chunk) {
 // NWD: number of waves (the first NWD, the older wave of each SIMD pair) that issue the LDS-DMA pieces; 0 = all of them
 // F16: both operands hold fp16 bit patterns (a float A operand as an fp16 (hi, lo) pair pre-scaled by a power of two, the weight integers
 // as fp16): v_mfma_f32_16x16x32_f16 - same tile, same LDS images, same rate as the bf16 form, 2^-23 instead of 2^-17 per A element.
-// B8: the B operand (weight integers) comes in as int8 [N][ldb bytes] - half the bytes through the L2 -> CU path, which is what bounds the split-A k-loop
-// (12.7 B/cycle/CU of LDS-DMA + MFMA at 73 % on their own: tools/bench_gemm.py ablations, profiles/round2_nt_ingress.txt) - and is widened to the
-// MFMA type in registers when a wave reads its three B fragments of a k-step (exact: |w| <= 128).
 template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0, int PM = 0, bool I8 = false,
-          bool F16 = false, bool B8 = false>
+          bool F16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {   // two waves per SIMD (one 8-wave or two 4-wave workgroups)
     // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
     static_assert(BK == 64 || BK == 32, "BK");
@@ -756,13 +727,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     constexpr int WR = 16 * TM, WC = 16 * TNT;      // rows / columns per wave
     constexpr int BM = WR * WM, BN = WC * WN, NW = WN * WM;
     constexpr int IMGA = BM * BK * 2;               // bytes of one [BM][BK] bf16 image
-    static_assert(!B8 || (!I8 && TB == 1 && BK == 32 && TM > 4), "int8 B operand: tall split-A tiles only");
-    constexpr int IMGB = BN * BK * (B8 ? 1 : 2);
+    constexpr int IMGB = BN * BK * 2;
     constexpr int STAGE = TA * IMGA + TB * IMGB;
     constexpr int RPP = 512 / BK;                   // tile rows per 1-KiB DMA piece
-    constexpr int RPPB = B8 ? 2 * RPP : RPP;        // ... of the B image (int8: 32-B rows)
-    static_assert(BM % RPP == 0 && BN % RPPB == 0, "tile rows per piece");
-    constexpr int PAI = BM / RPP, PBI = BN / RPPB;  // pieces per A / B image
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows per piece");
+    constexpr int PAI = BM / RPP, PBI = BN / RPP;   // pieces per A / B image
     constexpr int NP = TA * PAI + TB * PBI;         // pieces per k-tile, dealt round-robin to the waves
     constexpr int NWD = NWD_ ? NWD_ : NW;
     constexpr int NDF = NP / NWD, NDX = NP % NWD;   // every issuing wave issues NDF, waves < NDX one more
@@ -782,7 +751,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
 
     const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(p.A0, (int64_t)p.M * p.lda * 2);
     const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(TA == 2 ? p.A1 : p.A0, (int64_t)p.M * p.lda * 2);
-    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, (int64_t)p.N * p.ldb * (B8 ? 1 : 2));   // (B8: ldb counts bytes)
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, (int64_t)p.N * p.ldb * 2);
     const __amdgpu_buffer_rsrc_t rB1 = make_rsrc(TB == 2 ? p.B1 : p.B, (int64_t)p.N * p.ldb * 2);
     // this lane's place inside a 1-KiB DMA piece: the destination is lane-linear (LDS row lane>>3, chunk lane&7), so the
     // swizzle is applied to the SOURCE: tile row `prow` of the piece, 8-element k-chunk `pk`
@@ -803,11 +772,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
         } else {
             const int pb = pc - TA * PAI;
             const int img = (TB == 2 && pb >= PBI) ? 1 : 0, q = pb - img * PBI;
-            if constexpr (B8) {   // 32 rows of 32 int8 per piece, lane-linear (row lane >> 1, 16-B half lane & 1): 8-B fragment reads of 16 rows are contiguous
-                const uint32_t off8 = (uint32_t)((int64_t)(n0 + q * 32 + (lane >> 1)) * p.ldb + k0 + (lane & 1) * 16);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(st + TA * IMGA + q * 1024), 16, off8, 0, 0, 0);
-                return;
-            }
             const uint32_t off = (uint32_t)(((int64_t)(n0 + q * RPP + prow) * p.ldb + k0 + pk * 8) * 2);
             if (img == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(st + TA * IMGA + q * 1024), 16, off, 0, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, (lds_void*)(st + TA * IMGA + IMGB + q * 1024), 16, off, 0, 0, 0);
@@ -831,23 +795,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (ABL != 2 && ABL != 6 && s < nk) issue(s);
 
-    // B8: the int8 B fragments of tile kt+1 are read and widened BETWEEN the MFMA groups of step kt (in front of the first MFMA of a step the ~50 VALU
-    // operations of both waves of a SIMD would run with the MFMA pipe idle: measured +6 % per launch).  Tile kt+1 therefore has to be visible one
-    // step early: one tile fewer may still be in flight at the barrier (four stages keep the prefetch distance of the three-stage ring).
-    static_assert(!B8 || NSTAGE == 4, "int8 B operand: four stages");
-    constexpr int YOUNG = B8 ? NSTAGE - 3 : NSTAGE - 2;   // issued tiles that may still be in flight at the top of a step
-    bf16x8 bpre[B8 ? TNT : 1];
-    auto widen = [&](const uint2 w8) {
-        if constexpr (F16) return __builtin_bit_cast(bf16x8, i8x8_to_f16(w8));
-        else return i8x8_to_bf16(w8);
-    };
     for (int kt = 0; kt < nk; ++kt) {
         uint64_t t0 = 0, t1 = 0, t2 = 0;
         if constexpr (ABL == 5 || ABL == 6) t0 = __builtin_amdgcn_s_memtime();
-        // tile kt (B8: and tile kt+1) has landed once at most the YOUNG younger tiles' DMAs are still outstanding
+        // tile kt has landed once at most the (NSTAGE-2) younger tiles' DMAs are still outstanding
         if (NSTAGE >= 3 && kt + NSTAGE - 2 < nk) {
-            if (NDX && wave < NDX) wait_vmcnt<YOUNG * (NDF + 1)>();
-            else wait_vmcnt<YOUNG * NDF>();
+            if (NDX && wave < NDX) wait_vmcnt<(NSTAGE - 2) * (NDF + 1)>();
+            else wait_vmcnt<(NSTAGE - 2) * NDF>();
         } else wait_vmcnt<0>();
         if constexpr (ABL == 5 || ABL == 6) t1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone left buffer (kt-1)%NSTAGE
@@ -873,11 +827,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
             bf16x8 bfrag[TNT], blo[TB == 2 ? TNT : 1];
 #pragma unroll
             for (int j = 0; j < TNT; ++j) {
-                if constexpr (B8) {
-                    if (kt == 0) bpre[j] = widen(*reinterpret_cast<const uint2*>(sB + (wn * WC + 16 * j + r) * 32 + g * 8));   // (the first tile only)
-                    bfrag[j] = bpre[j];
-                    continue;
-                }
                 bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + foff(wn * WC + 16 * j + r, kk));
                 if constexpr (TB == 2) blo[j] = *reinterpret_cast<const bf16x8*>(sB + IMGB + foff(wn * WC + 16 * j + r, kk));
             }
@@ -904,7 +853,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
                 // B fragments stay resident
                 constexpr int PF = 3;
                 bf16x8 af[PF][TA];
-                uint2 braw[B8 ? TNT : 1];
                 auto read_a = [&](int i) {
 #pragma unroll
                     for (int t = 0; t < TA; ++t) af[i % PF][t] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + foff(wm * WR + 16 * i + r, kk));
@@ -919,17 +867,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
                             if ((c * TM) / NPW == i) issue_piece(kt + NSTAGE - 1, c);
                     }
                     if (i + PF - 1 < TM) read_a(i + PF - 1);
-                    if constexpr (B8) {   // next tile's B fragments: raw read one group ahead of the widening, one fragment every three groups
-                        static_assert(TNT * 3 + 1 <= TM, "groups for the B prefetch");
-                        if (kt + 1 < nk) {
-                            const char* sBn = smem + ((kt + 1) % NSTAGE) * STAGE + TA * IMGA;
-#pragma unroll
-                            for (int j = 0; j < TNT; ++j) {
-                                if (i == 3 * j + 1) braw[j] = *reinterpret_cast<const uint2*>(sBn + (wn * WC + 16 * j + r) * 32 + g * 8);
-                                if (i == 3 * j + 2) bpre[j] = widen(braw[j]);
-                            }
-                        }
-                    }
 #pragma unroll
                     for (int t = 0; t < TA; ++t)
 #pragma unroll
@@ -1255,13 +1192,13 @@ static void allow_lds(K kernel, size_t bytes) {
 }
 
 // one kernel instantiation per epilogue variant (NTArgs::pm); the timing-only ablations exist for the plain epilogue only
-template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD, bool I8 = false, bool F16 = false, bool B8 = false>
+template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD, bool I8 = false, bool F16 = false>
 static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
-#define QV_PM(PM_)                                                                                                           \
-    do {                                                                                                                     \
-        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16, B8>, lds), true);   \
-        (void)once;                                                                                                          \
-        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16, B8><<<grid, WM * WN * 64, lds, st>>>(a);          \
+#define QV_PM(PM_)                                                                                                       \
+    do {                                                                                                                 \
+        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16>, lds), true);   \
+        (void)once;                                                                                                      \
+        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16><<<grid, WM * WN * 64, lds, st>>>(a);          \
     } while (0)
     if constexpr (ABL != 0) {
         QV_PM(0);
@@ -1324,11 +1261,7 @@ static void nt_br_launch(const NTArgs& a, int grid, hipStream_t st) {
 
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                   const void* B_lo, const NTPost* post, bool f16, const void* B8) {
-    // B8 (optional): the same weight integers as int8 [N][ldb]; the tall split-A launches read it instead of B (QATVIT_NT_B8=0: never)
-    static const int b8_on = getenv("QATVIT_NT_B8") ? atoi(getenv("QATVIT_NT_B8")) : 1;
-    const bool use_b8 = B8 && b8_on && A_lo && !B_lo && N % 384 == 0 && K % 32 == 0 && ldb % 16 == 0;
-    constexpr size_t kLdsB8 = 4 * (2 * 208 * 64 + 384 * 32);   // four stages of (A_hi, A_lo [208 x 32] bf16, B [384 x 32] int8) = 152 KiB
+                   const void* B_lo, const NTPost* post, bool f16) {
     if (f16 && (!A_lo || B_lo || (post && post->mode != 6) || N % 384 != 0 || K % 32 != 0)) {
         set_error("gemm_nt: the fp16 form takes a split A operand, N %% 384 == 0, the plain or the residual (mode 6) epilogue (N=%d K=%d)", N, K);
         return 1;
@@ -1360,10 +1293,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                 return 1;
             }
             constexpr size_t lds8 = 160 * 1024;   // ring 150 KiB; the epilogue's 96-row slab + row operands need 156 KiB
-            if (use_b8) {
-                a.B = reinterpret_cast<const __bf16*>(B8);
-                nt_launch<2, 4, 1, 13, 1, 0, 8, 3, 32, 0, false, false, true>(a, cdiv(M, 208), lds8, st);
-            } else nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208), lds8, st);
+            nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208), lds8, st);
             return 0;
         }
         const bool ok6 = post->mode == 6 && f16 && a.post_qp && a.resid && C;
@@ -1429,11 +1359,6 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     constexpr int kLdsBr2 = 150 * 1024, kLdsBr1 = 100 * 1024;
     if (f16) {
         if (nt_breg() && K % 64 == 0 && a.pm == 0) { nt_br_launch<2, 4, false, true, kLdsBr2>(a, cdiv(M, 208) * (N / 384), st); return 0; }
-        if (use_b8) {
-            a.B = reinterpret_cast<const __bf16*>(B8);
-            nt_launch<2, 4, 1, 13, 1, 0, 8, 3, 32, 0, false, true, true>(a, cdiv(M, 208) * (N / 384), kLdsB8, st);
-            return 0;
-        }
         constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
         nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);
         return 0;
@@ -1454,11 +1379,6 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                 nt_launch<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), lds, st);     \
             }                                                                                                 \
         } while (0)
-        if (use_b8 && tabl == 0 && tall == 1) {
-            a.B = reinterpret_cast<const __bf16*>(B8);
-            nt_launch<2, 4, 1, 13, 1, 0, 8, 3, 32, 0, false, false, true>(a, cdiv(M, 208) * (N / 384), kLdsB8, st);
-            return 0;
-        }
         if (tabl == 1) QV_TALL(1);
         else if (tabl == 2) QV_TALL(2);
         else if (tabl == 3) QV_TALL(3);

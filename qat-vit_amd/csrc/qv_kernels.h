@@ -79,8 +79,7 @@ struct NTPost {
 // ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                   const void* B_lo = nullptr, const NTPost* post = nullptr, bool f16 = false,    // f16: A_hi / A_lo / B hold fp16 bit patterns
-                   const void* B8 = nullptr);   // optional: the B integers once more as int8 [N, ldb] - read instead of B by the tall split-A launches
+                   const void* B_lo = nullptr, const NTPost* post = nullptr, bool f16 = false);   // f16: A_hi / A_lo / B hold fp16 bit patterns
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
                       hipStream_t st, const NTPost* post = nullptr);
@@ -134,7 +133,6 @@ struct WQpTab {
 struct WQuantTab {
     const float* W[kMaxW]; const float* qp[kMaxW]; void* wq[kMaxW]; void* wqT[kMaxW]; void* w8[kMaxW]; int32_t* wsum[kMaxW];   // w8 / wsum optional (int8 copies + row sums)
     void* w16[kMaxW];   // optional: the same integers as fp16 (B operand of the fp16-pair forward GEMMs: proj, fc2)
-    void* wT8[kMaxW];   // optional: the transposed integers as int8 (B operand of the split-A dgrad GEMMs)
     int N[kMaxW], K[kMaxW], blk0[kMaxW + 1]; int n, per_channel, qmin, qmax;
 };
 int launch_w_observe_all(WObsTab& t, hipStream_t st);      // fills blk0

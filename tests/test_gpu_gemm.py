@@ -257,41 +257,3 @@ def test_gemm_nt_codes_equals_planes(native_lib, M, N, K):
     assert not torch.isnan(Cb).any()
     assert torch.equal(Ca, Cb)
     assert torch.equal(st_a, st_b)
-
-
-@pytest.mark.parametrize("f16", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(1576, 384, 384), (300, 384, 1536), (50432, 384, 1152), (1000, 768, 3072), (207, 384, 64)])
-def test_gemm_nt_int8_weights_equal_wide_weights(native_lib, M, N, K, f16):
-    """The tall split-A kernels with their B operand as int8 (widened to bf16 / fp16 in registers, four LDS stages) against the same product with the
-    bf16 / fp16 weight copy: the same fragments through the same MFMAs - the same bits, incl. the min/max accumulator."""
-    torch.manual_seed(M + N + K + f16)
-    dev = "cuda"
-    A = torch.randn(M, K, device=dev) * 3
-    W = torch.randint(-128, 128, (N, K), device=dev)
-    W[0, :4] = torch.tensor([-128, 127, 0, -1], device=dev)
-    if f16:
-        Ah, Al = split_h(A)
-        Bw = W.float().to(torch.float16)
-    else:
-        Ah, Al = split(A)
-        Bw = W.float().to(torch.bfloat16)
-    B8 = W.to(torch.int8)
-    s1 = torch.tensor([0.0123], device=dev)
-    cs = torch.rand(N, device=dev) + 0.5
-    bias = torch.randn(N, device=dev)
-
-    def fresh():
-        return torch.tensor([0xFF800000 - (1 << 32), 0x007FFFFF], dtype=torch.int32, device=dev)
-
-    st_a, st_b = fresh(), fresh()
-    Ca = torch.full((M, N), float("nan"), device=dev)
-    Cb = torch.full((M, N), float("nan"), device=dev)
-    fn = native_lib.qatvit_gemm_nt_f16 if f16 else native_lib.qatvit_gemm_nt
-    assert fn(Ah.data_ptr(), Al.data_ptr(), Bw.data_ptr(), Ca.data_ptr(), M, N, K, K, K, N, s1.data_ptr(), None, cs.data_ptr(), bias.data_ptr(),
-              st_a.data_ptr(), _st()) == 0, native_lib.qatvit_last_error()
-    assert native_lib.qatvit_gemm_nt_w8(Ah.data_ptr(), Al.data_ptr(), B8.data_ptr(), Cb.data_ptr(), M, N, K, K, K, N, s1.data_ptr(), None, cs.data_ptr(),
-                                        bias.data_ptr(), st_b.data_ptr(), f16, _st()) == 0, native_lib.qatvit_last_error()
-    torch.cuda.synchronize()
-    assert not torch.isnan(Cb).any()
-    assert torch.equal(Ca, Cb)
-    assert torch.equal(st_a, st_b)
