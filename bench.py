@@ -314,10 +314,14 @@ def main():
     KINDS = {1: "k_gemm_nt split-A, plain epilogue (proj / fc2 forward on fp16 pairs, proj dgrad on bf16 pairs)",
              4: "k_gemm_nt split-A dgrad + LayerNorm backward fused into the epilogue (fc1 / qkv dgrad, mode 8)",
              5: "k_gemm_nt split-A fc2 dgrad + GELU backward fused into the epilogue (mode 5)",
-             2: "k_gemm_nt grid A on int8 MFMA (patch-embed, qkv, fc1 forward)",
+             2: "k_gemm_nt grid A on int8 MFMA, plain epilogue (patch embedding; qkv when it runs once)",
+             7: "k_gemm_nt grid A on int8 MFMA, statistics-only pass (mode 3: qkv and fc1 first passes)",
+             8: "k_gemm_nt grid A on int8 MFMA, fc1 storing pass (mode 4: gelu(fq(.)) as codes + bf16 pair)",
+             9: "k_gemm_nt grid A on int8 MFMA, qkv code pass (mode 7: uint8 codes + STE mask bits in the attention layout)",
              3: "k_gemm_tn<1,..> + k_tn_reduce: weight gradients with grid X (qkv / fc1 / patch-embed; split dY: 2 bf16 passes issued)",
              6: "k_gemm_tn<2,..> + k_tn_reduce: weight gradients with split X (proj / fc2; 3 bf16 passes issued)"}
-    SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_forward", 3: "tn_grid_x", 6: "tn_split_x"}
+    SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_plain", 7: "nt_int8_stats_pass",
+             8: "nt_int8_fc1_store_pass", 9: "nt_int8_qkv_code_pass", 3: "tn_grid_x", 6: "tn_split_x"}
     prof = {}
     nprof = 0 if (args.graph or args.no_kernel_legs) else 3
     for kind in KINDS:
@@ -344,10 +348,10 @@ def main():
                       + (Mr * Dm * 4 + Dm * Dm * 2 + Mr * Dm * 4)),                              # proj dgrad: bf16 pair in, fp32 out
             4: dep * ((Mr * Hd * 4 + Dm * Hd * 2 + lnb) + (Mr * 3 * Dm * 4 + 3 * Dm * Dm * 2 + lnb)),   # fc1 dgrad, qkv dgrad (+ LayerNorm backward)
             5: dep * (Mr * Dm * 4 + Dm * Hd * 2 + Mr * Hd * 2 + Mr * Hd * 4),                    # fc2 dgrad: pair in, uint16 codes in, pair out
-            2: (Mpe * Kpe + Dm * Kpe + Mpe * Dm * 4)
-               + dep * ((2 * (Mr * Dm + 3 * Dm * Dm) + Mr * 3 * Dm * 9 // 8 if qkv2 else Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 4)   # qkv forward: statistics pass + code pass (1 B + 1 bit out), or one pass with fp32 out
-                        + (Mr * Dm + Hd * Dm)                                                    # fc1 statistics pass: nothing stored
-                        + (Mr * Dm + Hd * Dm + Mr * Hd * ((1 if codes else 4) + 2 + 4))),        # fc1 storing pass: codes (or fp16 pair) + uint16 code + bf16 pair
+            2: (Mpe * Kpe + Dm * Kpe + Mpe * Dm * 4) + (0 if qkv2 else dep * (Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 4)),   # patch embedding (+ one-pass qkv: fp32 out)
+            7: dep * ((Mr * Dm + Hd * Dm) + ((Mr * Dm + 3 * Dm * Dm) if qkv2 else 0)),          # statistics passes: operands in, nothing stored
+            8: dep * (Mr * Dm + Hd * Dm + Mr * Hd * ((1 if codes else 4) + 2 + 4)),             # fc1 storing pass: codes (or fp16 pair) + uint16 code + bf16 pair
+            9: dep * (Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 9 // 8),                            # qkv code pass: 1 B + 1 bit per element out
             3: (Mpe * Dm * 4 + Mpe * Kpe * 2 + Dm * Kpe * 4)
                + dep * ((Mr * 3 * Dm * 4 + Mr * Dm * 2 + 3 * Dm * Dm * 4) + (Mr * Hd * 4 + Mr * Dm * 2 + Hd * Dm * 4)),   # qkv, fc1 wgrad
             6: dep * ((Mr * Dm * 4 + Mr * Dm * 4 + Dm * Dm * 4) + (Mr * Dm * 4 + Mr * Hd * 4 + Hd * Dm * 4)),             # proj, fc2 wgrad
@@ -357,7 +361,7 @@ def main():
             if ms <= 0 or cnt == 0:
                 continue
             rate = fl / (ms * 1e-3) / 1e12
-            peak = I8_PEAK_TOPS if kind == 2 else BF16_PEAK_TFLOPS
+            peak = I8_PEAK_TOPS if kind in (2, 7, 8, 9) else BF16_PEAK_TFLOPS
             lps = cnt / nprof
             by = step_bytes[kind] / lps if (args.student in ("vit_small", "vit_base") and lps > 0) else None
             g = {"kernel": KINDS[kind], "ms_per_step": round(ms / nprof, 3), "launches_per_step": round(lps, 1),
@@ -370,8 +374,8 @@ def main():
                           "flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(peak * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
                           "roofline_bound": "hbm" if ai < peak * 1e12 / (HBM_PEAK_GBS * 1e9) else "mfma"})
             gemms[kind] = g
-        if 2 in gemms:
-            gemms[2]["note"] = "fc1 and qkv run twice (statistics-only pass + storing pass): both launches are timed, only one counts as algorithmic work"
+        if 7 in gemms:
+            gemms[7]["note"] = "fc1 and qkv run twice (statistics-only pass + storing pass): the statistics passes count as time, not as algorithmic work"
         for k in (3, 6):
             if k in gemms:
                 gemms[k]["note"] = "the bracket holds k_gemm_tn and its k_tn_reduce (ordered second-phase reduction of the split partials)"
@@ -391,7 +395,7 @@ def main():
             "kernel": "qv::" + g["kernel"] + " - the GEMM kernel with the largest share of the step (208x384 tiles)",
             "achieved": g["algorithmic_GBps"] if hbm_bound else g["algorithmic_T(FL)OPs"],
             "peak": HBM_PEAK_GBS if hbm_bound else g["peak"],
-            "unit": "GB/s" if hbm_bound else ("TOP/s" if dom == 2 else "TFLOP/s"),
+            "unit": "GB/s" if hbm_bound else ("TOP/s" if dom in (2, 7, 8, 9) else "TFLOP/s"),
             "frac": g["frac_of_hbm_peak"] if hbm_bound else g["frac_of_peak"],
             "traffic": traffic, "traffic_note": traffic_note, "launches": int(g["launches_per_step"] * nprof), "avg_us_per_launch": g["avg_us_per_launch"],
             "flop_per_byte": g.get("flop_per_byte"), "ridge_flop_per_byte": g.get("ridge_flop_per_byte"),
@@ -426,6 +430,25 @@ def main():
             del st2, _m, _x, _y, t_only
             eng2.workspace = None
             del eng2
+            torch.cuda.empty_cache()
+        if world == 1:
+            # the exported integer network (Int8Student: int8 MFMA, frozen qparams) next to the fake-quant forward it equals bit for bit
+            from torch.ao.quantization import disable_observer
+
+            mi = build_model(qat_vit_amd, "vit_small", "qnnpack", dev)
+            xi = torch.randn(256, 3, 224, 224, device=dev)
+            with torch.no_grad():
+                mi(xi)                                         # one observation so that every quantizer has a range
+                mi.apply(disable_observer)
+                mi.eval()
+                infer = qat_vit_amd.Int8Student(qat_vit_amd.export_int8(mi))
+                d_fq = timed_steps(lambda: mi(xi), 20, 3, 1, dev)
+                d_i8 = timed_steps(lambda: infer(xi), 20, 3, 1, dev)
+                same = bool(torch.equal(mi(xi), infer(xi)))
+            extras["INT8_INFERENCE"] = {"value": round(256 * 20 / d_i8, 2), "unit": "images/sec", "ms_per_forward": round(1e3 * d_i8 / 20, 3),
+                                        "fake_quant_forward_ms": round(1e3 * d_fq / 20, 3), "logits_bit_identical_to_fake_quant_forward": same,
+                                        "workload": "vit_small_patch16_224 exported to int8 (Int8Student), batch 256, forward only"}
+            del mi, infer, xi
             torch.cuda.empty_cache()
         if rank == 0:
             res["extra_configs"] = extras

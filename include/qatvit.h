@@ -155,7 +155,9 @@ int qatvit_attn_forward_f16(const float* qkv, const float* qp, int32_t qmin, int
 /* qkv_codes / qkv_mask (optional, both or neither): the forward also saves the quantised qkv it computed on load, in per-head slices (every
  * workgroup's accesses are whole contiguous runs): codes[b][h][which][t][d] = clamp(q) - qmin as uint8 (which = 0 q / 1 k / 2 v, d < D / H;
  * B*T*3*D bytes) and the STE mask, bit (d & 7) of byte mask[b][h][which][t][d >> 3] (B*T*3*D/8 bytes).  Given them the backward reads 1.125
- * bytes per element instead of re-quantising the 4-byte pre-fake-quant tensor twice (its `qkv` argument may then be NULL).  Bit-identical results. */
+ * bytes per element instead of re-quantising the 4-byte pre-fake-quant tensor twice (its `qkv` argument may then be NULL).  Bit-identical results.
+ * qkv == NULL in the FORWARD: qkv_codes is its INPUT (written by the qkv GEMM's second pass - the whole-step engine's form, and the inference
+ * forward's): the pre-fake-quant tensor is not read and need not exist. */
 int qatvit_attn_backward(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H,
                          int32_t D, const void* O_hi, const void* O_lo, const float* lse, float* delta, const float* dO,
                          void* dqkv_hi, void* dqkv_lo, const float* col_scale, const void* qkv_codes, const void* qkv_mask, void* stream);
@@ -288,8 +290,8 @@ int qatvit_optim_adamw(const void* param_ptrs, const void* grad_ptrs, const void
 
 /* Measurement hooks (bench.py): bracket every launch of one GEMM class inside the steps of ONE engine - identified by its workspace
  * pointer, so engines in the same process do not see each other's sessions - with HIP events on the launch stream.
- * kind: 1 = NT with split (hi+lo) A operand and the plain epilogue (proj / fc2 forward, proj dgrad), 2 = NT with grid A operand (int8 forward
- * GEMMs), 3 = TN (wgrad) with grid X operand (qkv / fc1 / patch-embed; the bracket holds k_gemm_tn + k_tn_reduce), 6 = TN with split X operand (proj / fc2), 4 = NT split-A dgrad with the LayerNorm backward fused into its epilogue (fc1 / qkv dgrad), 5 = fc2 dgrad with
+ * kind: 1 = NT with split (hi+lo) A operand and the plain epilogue (proj / fc2 forward, proj dgrad), 2 = NT with grid A operand on int8 MFMA, plain
+ * epilogue (patch embedding; qkv when it runs once), 7 = its statistics-only passes (qkv, fc1), 8 = the fc1 storing pass, 9 = the qkv code pass, 3 = TN (wgrad) with grid X operand (qkv / fc1 / patch-embed; the bracket holds k_gemm_tn + k_tn_reduce), 6 = TN with split X operand (proj / fc2), 4 = NT split-A dgrad with the LayerNorm backward fused into its epilogue (fc1 / qkv dgrad), 5 = fc2 dgrad with
  * the GELU backward fused into its epilogue.
  * stop() synchronises on the recorded events and returns the summed kernel time, launch count and the summed
  * algorithmic FLOPs (2*M*N*K per launch, one pass). */

@@ -143,7 +143,7 @@ int qatvit_attn_forward(const float* qkv, const float* qp, int32_t qmin, int32_t
 
 int qatvit_attn_forward_f16(const float* qkv, const float* qp, int32_t qmin, int32_t qmax, int32_t B, int32_t T, int32_t H, int32_t D, void* O_hi,
                             void* O_lo, float* lse, void* O16_hi, void* O16_lo, float* o16_scale, void* qkv_codes, void* qkv_mask, void* stream) {
-    QV_CHECK_ARG(qkv && qp && O_hi && O_lo && lse && O16_hi && O16_lo && o16_scale, "qatvit_attn_forward_f16: null pointer argument");
+    QV_CHECK_ARG((qkv || qkv_codes) && qp && O_hi && O_lo && lse && O16_hi && O16_lo && o16_scale, "qatvit_attn_forward_f16: null pointer argument");
     QV_CHECK_ARG(B >= 1 && T >= 1 && H >= 1, "qatvit_attn_forward_f16: empty shape");
     if (launch_attn_fwd(qkv, qp, qmin, qmax, B, T, H, D, O_hi, O_lo, lse, (hipStream_t)stream, O16_hi, O16_lo, o16_scale, qkv_codes, qkv_mask)) return 1;
     QV_CHECK_LAUNCH("qatvit_attn_forward_f16");

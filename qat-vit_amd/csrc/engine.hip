@@ -319,7 +319,7 @@ struct Ctx {
         int N, K; wshape(d, wi, &N, &K);
         if (!use_i8() || N % 384 != 0 || K % 64 != 0) return linear_fwd(A16, nullptr, M, wi, a_qp, bias, C, ai_out, post, with_stats);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(prof, 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);
+        ProfScope ps(prof, !post ? 2 : post->mode == 3 ? 7 : post->mode == 4 ? 8 : post->mode == 7 ? 9 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);
         return launch_gemm_nt_i8(A8, at<void>(p.w8_off[wi]), at<int32_t>(p.wsum_off[wi]), a_qp, center(), C, M, N, K, K, K, N, a_qp,
                                  c.w_per_channel ? nullptr : f.scale, c.w_per_channel ? f.scale : nullptr, bias,
                                  with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, post);
@@ -779,7 +779,7 @@ int qatvit_student_backward_stages(const qatvit_cfg* cfg, void* const* params, c
 
 // bench.py: time every launch of one GEMM class of ONE engine (identified by its workspace) with HIP events on the stream it is launched on
 int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launches) {
-    QV_CHECK_ARG(workspace && kind >= 1 && kind <= 6 && max_launches > 0, "qatvit_profile_start: bad arguments");
+    QV_CHECK_ARG(workspace && kind >= 1 && kind <= 9 && max_launches > 0, "qatvit_profile_start: bad arguments");
     Prof* pr = new Prof();
     pr->ev.assign((size_t)max_launches * 2, nullptr);
     for (auto& e : pr->ev)

@@ -122,6 +122,15 @@ def test_attention_backward_from_saved_codes(native_lib, B, T, H, D, qmin, qmax,
     bits = ((t >= qmin) & (t <= qmax)).view(B, H, 3, T, hd // 8, 8).to(torch.uint8)
     want = (bits << torch.arange(8, device=dev, dtype=torch.uint8)).sum(-1).to(torch.uint8)
     assert torch.equal(cmask.view(B, H, 3, T, hd // 8), want)
+    # the forward FROM the code plane (qkv == NULL: how the step runs it, the qkv GEMM's second pass having written the plane): the same bits
+    Oh2 = torch.full_like(Oh, float("nan")); Ol2 = torch.full_like(Ol, float("nan"))
+    O16h2 = torch.full_like(O16h, float("nan")); O16l2 = torch.full_like(O16l, float("nan"))
+    lse2 = torch.zeros_like(lse)
+    assert native_lib.qatvit_attn_forward_f16(None, qp.data_ptr(), qmin, qmax, B, T, H, D, Oh2.data_ptr(), Ol2.data_ptr(), lse2.data_ptr(),
+                                              O16h2.data_ptr(), O16l2.data_ptr(), osc.data_ptr(), codes.data_ptr(), cmask.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+    for a, b in ((Oh, Oh2), (Ol, Ol2), (O16h, O16h2), (O16l, O16l2)):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert torch.equal(lse, lse2)
     dO = torch.randn(B * T, D, device=dev)
     outs = []
     for use_codes in (False, True):

@@ -32,6 +32,9 @@ def timeit(fn):
 
 fwd = lambda: L.qatvit_attn_forward_f16(qkv.data_ptr(), qp.data_ptr(), 0, 255, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(), O16h.data_ptr(), O16l.data_ptr(), osc.data_ptr(), cp, mp, st)
 bwd = lambda: L.qatvit_attn_backward(qkv.data_ptr(), qp.data_ptr(), 0, 255, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(), delta.data_ptr(), dO.data_ptr(), gh.data_ptr(), gl.data_ptr(), None, cp, mp, st)
+if CODES and int(os.environ.get("BENCH_FROM_CODES", 1)):   # the step's form: the qkv GEMM's second pass wrote the code plane, the forward reads 1 B per element
+    fwd()                                                   # (fills codes / cmask from the fp32 tensor once)
+    fwd = lambda: L.qatvit_attn_forward_f16(None, qp.data_ptr(), 0, 255, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(), O16h.data_ptr(), O16l.data_ptr(), osc.data_ptr(), cp, mp, st)
 tf, tb = timeit(fwd), timeit(bwd)
 gf = 4.0 * B * H * T * T * 64 / 1e9          # QK^T + PV
 print(f"attention B={B} codes={CODES}: fwd {tf:.1f} us ({gf / tf * 1e3:.0f} TF/s algorithmic), bwd (dQ + dKV) {tb:.1f} us ({2.5 * gf / tb * 1e3:.0f} TF/s)")

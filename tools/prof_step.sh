@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the default bench workload (C2): tools/prof_step.sh <tag> [extra bench args]
-# writes gpurun_out/prof_<tag>/ and prints per-kernel time per STEP (29 steps in the trace: 5 warm-up + 15 timed + 9 per-kernel legs)
+# writes gpurun_out/prof_<tag>/ and prints per-kernel time per STEP (steps in the trace = launches of k_kd_ce: warm-up + timed + per-class legs)
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
@@ -12,7 +12,8 @@ python3 - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-steps = 29.0
+steps = float(sum(int(r["Calls"]) for r in rows if "k_kd_ce" in r["Name"]) or 29)
+print(f"steps in the trace: {steps:.0f}")
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total GPU kernel time per step: {tot/steps/1e6:.3f} ms   ({f})")
 for r in rows[:32]:
