@@ -494,8 +494,10 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         const int64_t eo = ((((int64_t)bb * Hh + hh) * 3 + which) * p.code_T + tt) * p.code_hd + d;
                         // 8 consecutive lanes hold 32 consecutive features of one row: the first of them stores their 32 mask bits (the shuffles run
                         // unconditionally: a group shares `row`, so it is valid or invalid as a whole)
-#pragma unroll
-                        for (int k = 1; k < 8; ++k) mk |= ((uint32_t)__shfl_down((int)(mk & 0xfu), k, 64) & 0xfu) << (4 * k);
+                        // (three DPP row shifts - lane i reads lane i + 1 / 2 / 4 of its 16-lane row - instead of seven LDS permutes)
+                        mk |= ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)mk, 0x101, 0xf, 0xf, true) & 0xfu) << 4;
+                        mk |= ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)mk, 0x102, 0xf, 0xf, true) & 0xffu) << 8;
+                        mk |= ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)mk, 0x104, 0xf, 0xf, true) & 0xffffu) << 16;
                         if (ok[u]) {
                             *reinterpret_cast<uint32_t*>(p.out8 + eo) = pk;
                             if (p.out8_mask && (lane & 7) == 0) *reinterpret_cast<uint32_t*>(p.out8_mask + (eo >> 3)) = mk;
