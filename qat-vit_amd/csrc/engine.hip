@@ -65,6 +65,7 @@ static int wparam(const Dims& d, int wi) {  // index of the weight tensor in par
 
 struct Plan {
     // byte offsets into the workspace
+    int64_t qp_cnt;   // one ticket counter per activation quantizer (producer tails)
     int64_t stats, qp_act, qp_w, imgq, Y0, meanF, rstdF, hq, logits_pre;
     int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2, qkv8, qkvm, G8, glut;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
     int64_t blk_stride;
@@ -99,6 +100,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->stats = take(p->stats_words * 4);
     p->qp_act = take((int64_t)d.n_act * 4 * 4);
     p->qp_w = take(wqp_floats * 4);
+    p->qp_cnt = take((int64_t)d.n_act * 4);
     p->imgq = take((int64_t)d.B * d.np * d.Kpe * 2);
     p->Y0 = take((int64_t)d.B * d.np * D * 4);
     p->meanF = take(M * 4); p->rstdF = take(M * 4);
@@ -247,6 +249,15 @@ static bool qkv_2pass(const qatvit_cfg& c) {
     return on != 0 && attn_codes(c) && use_i8() && (3 * c.embed_dim) % 384 == 0 && c.embed_dim % 64 == 0 && hd % 32 == 0;
 }
 
+// QATVIT_QP_TAIL=1: the observer / qparams update of an activation quantizer inside the producer of its statistics (its last workgroup runs it:
+// qv_qparams.h) instead of as a single-wave launch of its own right behind that producer (74 per step, 4.9 us each).  Default 0: measured
+// 24.14 vs 23.84 ms - the returning atomics + ticket at the end of EVERY workgroup and the double-precision qparams arithmetic in the last one cost
+// what the launch costs (and a release fence in front of the ticket, an L2 write-back per workgroup on this multi-XCD part, cost 40 us per launch)
+static bool qp_tail() {
+    static const int on = getenv("QATVIT_QP_TAIL") ? atoi(getenv("QATVIT_QP_TAIL")) : 0;
+    return on != 0;
+}
+
 // QATVIT_LNB_FUSE=0: the LayerNorm backward as its own kernel behind the fc1 / qkv dgrad GEMM (re-reads the fp32 gradient those wrote) instead
 // of inside their epilogue (embed_dim 384 only: the 208 x 384 tile holds whole rows)
 static bool lnb_fuse() {
@@ -275,6 +286,26 @@ struct Ctx {
     int a_norm() const { return A_BLOCK0 + AB_COUNT * d.depth; }
     int a_head() const { return a_norm() + 1; }
     int widx(int blk_i, int k) const { return 1 + WB_COUNT * blk_i + k; }
+    // the observer / qparams update of activation quantizer ai as the tail of the producer of its statistics
+    QpTail tail(int ai) const {
+        const qatvit_fq& f = act[ai];
+        return QpTail{at<uint32_t>(p.qp_cnt) + ai, f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const,
+                      c.act_qmin, c.act_qmax, act_qp(ai)};
+    }
+    // ... or as its own launch right behind that producer (QATVIT_QP_TAIL=0, and producers without a tail)
+    void qparams_after(int ai, bool produced_stats) const {
+        if (produced_stats && !qp_tail()) qparams_act(ai);
+    }
+    // launch_resid_fq_lnstats with the LayerNorm-output quantizer ai_stats updated behind it (tail or own launch)
+    int resid_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, const float* cls, const float* pos, float* x_new, float* mean,
+                      float* rstd, const float* gamma, const float* beta, int ai_stats, void* maskbits = nullptr) const {
+        const QpTail tl = tail(ai_stats);
+        if (launch_resid_fq_lnstats(mode, x_prev, Y, qpY, c.act_qmin, c.act_qmax, cls, pos, x_new, mean, rstd, gamma, beta, c.ln_eps, act_stats(ai_stats),
+                                    kStatSlots, d.M, d.D, d.T, st, maskbits, qp_tail() ? &tl : nullptr))
+            return 1;
+        qparams_after(ai_stats, true);
+        return 0;
+    }
     void qparams_act(int ai) const {
         const qatvit_fq& f = act[ai];
         launch_qparams(act_stats(ai), f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const,
@@ -286,26 +317,45 @@ struct Ctx {
                    const NTPost* post = nullptr, bool with_stats = true) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(prof, A_lo ? 1 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);   // a statistics-only pass is issued, not algorithmic, work
-        return launch_gemm_nt(A_hi, A_lo, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
-                              c.w_per_channel ? f.scale : nullptr, bias, with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, nullptr, post);
+        const QpTail tl = tail(ai_out);
+        {
+            ProfScope ps(prof, A_lo ? 1 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);   // a statistics-only pass is issued, not algorithmic, work
+            if (launch_gemm_nt(A_hi, A_lo, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
+                               c.w_per_channel ? f.scale : nullptr, bias, with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, nullptr, post, false,
+                               with_stats && qp_tail() ? &tl : nullptr))
+                return 1;
+        }
+        qparams_after(ai_out, with_stats);
+        return 0;
     }
     // the same product with the float A operand as an fp16 (hi, lo) pair scaled by *pair_scale (a device scalar its producer wrote) and the
     // weight integers as fp16
     int linear_fwd_f16(const void* A16_hi, const void* A16_lo, const float* pair_scale, int M, int wi, const float* bias, float* C, int ai_out) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(prof, 1, 2.0 * M * N * K, st);
-        return launch_gemm_nt(A16_hi, A16_lo, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
-                              c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, nullptr, nullptr, true);
+        const QpTail tl = tail(ai_out);
+        {
+            ProfScope ps(prof, 1, 2.0 * M * N * K, st);
+            if (launch_gemm_nt(A16_hi, A16_lo, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
+                               c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, nullptr, nullptr, true, qp_tail() ? &tl : nullptr))
+                return 1;
+        }
+        qparams_after(ai_out, true);
+        return 0;
     }
     // the same product with the A operand as uint8 table indices [M, K] + the 256-entry table of fp16 pairs (fc2: gelu(fq(.)) takes <= 256 values)
     int linear_fwd_codes(const void* A8, const uint32_t* lut, const float* pair_scale, int M, int wi, const float* bias, float* C, int ai_out) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(prof, 1, 2.0 * M * N * K, st);
-        return launch_gemm_nt_codes(A8, lut, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
-                                    c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st);
+        const QpTail tl = tail(ai_out);
+        {
+            ProfScope ps(prof, 1, 2.0 * M * N * K, st);
+            if (launch_gemm_nt_codes(A8, lut, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
+                                     c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, qp_tail() ? &tl : nullptr))
+                return 1;
+        }
+        qparams_after(ai_out, true);
+        return 0;
     }
     bool f16_ok(int wi) const {
         int N, K; wshape(d, wi, &N, &K);
@@ -319,10 +369,16 @@ struct Ctx {
         int N, K; wshape(d, wi, &N, &K);
         if (!use_i8() || N % 384 != 0 || K % 64 != 0) return linear_fwd(A16, nullptr, M, wi, a_qp, bias, C, ai_out, post, with_stats);
         const qatvit_fq& f = wfq[wi];
-        ProfScope ps(prof, !post ? 2 : post->mode == 3 ? 7 : post->mode == 4 ? 8 : post->mode == 7 ? 9 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);
-        return launch_gemm_nt_i8(A8, at<void>(p.w8_off[wi]), at<int32_t>(p.wsum_off[wi]), a_qp, center(), C, M, N, K, K, K, N, a_qp,
-                                 c.w_per_channel ? nullptr : f.scale, c.w_per_channel ? f.scale : nullptr, bias,
-                                 with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, post);
+        const QpTail tl = tail(ai_out);
+        {
+            ProfScope ps(prof, !post ? 2 : post->mode == 3 ? 7 : post->mode == 4 ? 8 : post->mode == 7 ? 9 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);
+            if (launch_gemm_nt_i8(A8, at<void>(p.w8_off[wi]), at<int32_t>(p.wsum_off[wi]), a_qp, center(), C, M, N, K, K, K, N, a_qp,
+                                  c.w_per_channel ? nullptr : f.scale, c.w_per_channel ? f.scale : nullptr, bias,
+                                  with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, post, with_stats && qp_tail() ? &tl : nullptr))
+                return 1;
+        }
+        qparams_after(ai_out, with_stats);
+        return 0;
     }
     // the per-channel weight scale of layer wi, which its dY producer folds in (nullptr for per-tensor)
     const float* dy_colscale(int wi) const { return c.w_per_channel ? wfq[wi].scale : nullptr; }
@@ -358,8 +414,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
     {
         float* xin = x.blk<float>(p.x_in, i);
         float* xmid = x.blk<float>(p.x_mid, i);
-        if (parts & 1) {   // ---- part 0: norm1 -> qkv
-        x.qparams_act(x.aidx(i, AB_N1));
+        if (parts & 1) {   // ---- part 0: norm1 -> qkv   (every quantizer's observer / qparams update runs behind the producer of its statistics)
         launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
                               qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h1q8, i) : nullptr, x.center());
         if (qkv_2pass(c)) {
@@ -367,7 +422,6 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
             if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
                                   x.aidx(i, AB_QKV), &p1))
                 return 1;
-            x.qparams_act(x.aidx(i, AB_QKV));
             NTPost p2{};
             p2.mode = 7; p2.qp = x.act_qp(x.aidx(i, AB_QKV)); p2.qmin = qa; p2.qmax = qb;
             p2.out8 = x.blk<void>(p.qkv8, i); p2.out8_mask = x.blk<void>(p.qkvm, i); p2.code_T = (int)d.T; p2.code_hd = (int)(d.D / d.H);
@@ -383,7 +437,6 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         float* const scal16 = x.at<float>(p.scal16);
         if (parts & 2) {   // ---- part 1: attention -> proj -> residual (+ statistics of norm2)
         const bool from_codes = qkv_2pass(c) && !qkv_injected;   // part 0 left the code plane (and ran the observer); an injected fp32 qkv takes the one-pass route
-        if (!from_codes) x.qparams_act(x.aidx(i, AB_QKV));
         if (launch_attn_fwd(from_codes ? nullptr : x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
                             x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), st, proj16 ? x.at<void>(p.O16_hi) : nullptr,
                             proj16 ? x.at<void>(p.O16_lo) : nullptr, proj16 ? scal16 : nullptr, attn_codes(x.c) ? x.blk<void>(p.qkv8, i) : nullptr,
@@ -396,13 +449,11 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         } else if (x.linear_fwd(x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), M, x.widx(i, WB_PROJ), nullptr, x.bprm(i, B_PROJB),
                                 x.blk<float>(p.Yproj, i), x.aidx(i, AB_PROJ)))
             return 1;
-        x.qparams_act(x.aidx(i, AB_PROJ));
-        launch_resid_fq_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, nullptr, nullptr, xmid,
-                                x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B), c.ln_eps,
-                                x.act_stats(x.aidx(i, AB_N2)), kStatSlots, d.M, d.D, d.T, st, x.blk<void>(p.mproj, i));
+        if (x.resid_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), nullptr, nullptr, xmid, x.blk<float>(p.mean2, i),
+                            x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B), x.aidx(i, AB_N2), x.blk<void>(p.mproj, i)))
+            return 1;
         }
         if (parts & 4) {   // ---- part 2: norm2 -> fc1 (both passes) -> GELU
-        x.qparams_act(x.aidx(i, AB_N2));
         launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
                               x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h2q8, i) : nullptr,
                               x.center());
@@ -415,7 +466,6 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
             if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
                              x.aidx(i, AB_FC1), &p1))
                 return 1;
-            x.qparams_act(x.aidx(i, AB_FC1));
             NTPost p2{nullptr, x.act_qp(x.aidx(i, AB_FC1)), qa, qb, nullptr, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), 4,
                       x.blk<void>(p.Y1, i)};
             if (fc2_c) { p2.out8 = x.blk<void>(p.G8, i); p2.lut_out = x.blk<uint32_t>(p.glut, i); p2.out16_scale = scal16 + 1; }
@@ -427,7 +477,6 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
             if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B),
                              x.blk<float>(p.Y1, i), x.aidx(i, AB_FC1)))
                 return 1;
-            x.qparams_act(x.aidx(i, AB_FC1));
             launch_fq_gelu(x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), d.M * d.Hd, st);
         }
         }
@@ -443,16 +492,15 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         } else if (x.linear_fwd(x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), M, x.widx(i, WB_FC2), nullptr, x.bprm(i, B_FC2B), x.blk<float>(p.Y2, i),
                                 x.aidx(i, AB_FC2)))
             return 1;
-        x.qparams_act(x.aidx(i, AB_FC2));
         // residual + statistics of the NEXT LayerNorm (block i+1's norm1, or the final norm)
         const bool last = (i + 1 == d.depth);
         const float* g = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth) : x.bprm(i + 1, B_N1W);
         const float* bt = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth + 1) : x.bprm(i + 1, B_N1B);
         float* mean = last ? x.at<float>(p.meanF) : x.blk<float>(p.mean1, i + 1);
         float* rstd = last ? x.at<float>(p.rstdF) : x.blk<float>(p.rstd1, i + 1);
-        launch_resid_fq_lnstats(1, xmid, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, nullptr, nullptr, x.blk<float>(p.x_in, i + 1),
-                                mean, rstd, g, bt, c.ln_eps, x.act_stats(last ? x.a_norm() : x.aidx(i + 1, AB_N1)), kStatSlots, d.M, d.D, d.T, st,
-                                x.blk<void>(p.m2, i));
+        if (x.resid_lnstats(1, xmid, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), nullptr, nullptr, x.blk<float>(p.x_in, i + 1), mean, rstd, g, bt,
+                            last ? x.a_norm() : x.aidx(i + 1, AB_N1), x.blk<void>(p.m2, i)))
+            return 1;
         }
         return 0;
     }
@@ -463,8 +511,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
 // and the min/max of the LayerNorm output that the consumer's first fake-quant observes.
 static int inject_ln_stats_of(const Ctx& x, const float* tensor, const float* g, const float* bt, float* mean, float* rstd, int ai) {
     launch_ws_init(x.act_stats(ai), kStatSlots * kStatStride / 2, x.st);   // whatever an earlier, unconsumed producer accumulated is stale
-    return launch_resid_fq_lnstats(2, tensor, nullptr, x.act_qp(0), x.c.act_qmin, x.c.act_qmax, nullptr, nullptr, nullptr, mean, rstd, g, bt, x.c.ln_eps,
-                                   x.act_stats(ai), kStatSlots, x.d.M, x.d.D, x.d.T, x.st);
+    return x.resid_lnstats(2, tensor, nullptr, x.act_qp(0), nullptr, nullptr, nullptr, mean, rstd, g, bt, ai);
 }
 static int inject_ln_stats(const Ctx& x, int i) {
     const Dims& d = x.d;
@@ -489,6 +536,7 @@ static int fwd_part(const Ctx& x, int block, int part, bool inject) {
             const int ai = x.aidx(block, AB_QKV);
             launch_ws_init(x.act_stats(ai), kStatSlots * kStatStride / 2, x.st);
             launch_minmax(x.blk<float>(p.qkv, block), 1, d.M * 3 * d.D, 0, x.act_stats(ai), kStatSlots, x.st);
+            x.qparams_act(ai);
         } else if (part == 2) {
             if (inject_ln_stats_of(x, x.blk<float>(p.x_mid, block), x.bprm(block, B_N2W), x.bprm(block, B_N2B), x.blk<float>(p.mean2, block),
                                    x.blk<float>(p.rstd2, block), x.aidx(block, AB_N2)))
@@ -556,17 +604,14 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
                            use_i8() ? x.at<void>(p.imgq8) : nullptr, x.center()))
         return 1;
     if (x.linear_fwd_grid(x.at<void>(p.imgq), x.at<void>(p.imgq8), d.B * d.np, 0, x.act_qp(A_IN), x.prm(P_PE_B), x.at<float>(p.Y0), A_PE)) return 1;
-    x.qparams_act(A_PE);
-    if (launch_resid_fq_lnstats(0, nullptr, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, x.prm(P_CLS), x.prm(P_POS), x.blk<float>(p.x_in, 0),
-                                x.blk<float>(p.mean1, 0), x.blk<float>(p.rstd1, 0), x.bprm(0, B_N1W), x.bprm(0, B_N1B), c.ln_eps,
-                                x.act_stats(x.aidx(0, AB_N1)), kStatSlots, d.M, d.D, d.T, st))
+    if (x.resid_lnstats(0, nullptr, x.at<float>(p.Y0), x.act_qp(A_PE), x.prm(P_CLS), x.prm(P_POS), x.blk<float>(p.x_in, 0), x.blk<float>(p.mean1, 0),
+                        x.blk<float>(p.rstd1, 0), x.bprm(0, B_N1W), x.bprm(0, B_N1B), x.aidx(0, AB_N1)))
         return 1;
     }   // stage 0
     for (int i = (s_from < 1 ? 0 : s_from - 1); i < d.depth && i + 1 <= s_to; ++i)
         if (fwd_block(x, i, 15)) return 1;
     if (s_to < d.depth + 1) return 0;
-    // ---- final norm (observer saw all tokens), cls pooling, head
-    x.qparams_act(x.a_norm());
+    // ---- final norm (observer saw all tokens: updated behind the last block's residual kernel), cls pooling, head
     const int base = P_BLOCK0 + B_COUNT * d.depth;
     const int wh = d.n_w - 1;
     launch_head_fwd(x.blk<float>(p.x_in, d.depth), x.at<float>(p.meanF), x.at<float>(p.rstdF), x.prm(base), x.prm(base + 1), x.act_qp(x.a_norm()),
@@ -708,6 +753,7 @@ int qatvit_student_init(const qatvit_cfg* cfg, void* workspace, void* stream) {
     Plan p;
     if (make_plan(*cfg, &p)) return 1;
     launch_ws_init(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + p.stats), p.stats_words / 2, (hipStream_t)stream);
+    launch_zero_i32(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + p.qp_cnt), dims_of(*cfg).n_act, (hipStream_t)stream);   // tail tickets
     QV_CHECK_LAUNCH("qatvit_student_init");
     return 0;
 }

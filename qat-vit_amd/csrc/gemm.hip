@@ -22,6 +22,7 @@
 
 #include "qv_common.h"
 #include "qv_kernels.h"
+#include "qv_qparams.h"
 
 namespace qv {
 
@@ -147,6 +148,8 @@ struct NTArgs {
     // mode 7 (optional, training): the STE mask bit of every element (t = rint(v / s) + zp inside [qmin, qmax]) next to the codes, one bit per
     // element in the same [b][h][which][t][d] order (bit d % 8 of byte (... * hd + d) / 8) - what the attention forward writes when it quantises itself
     uint8_t* out8_mask;
+    // with stats: the last workgroup of the launch also runs the observer / qparams update of the output's quantizer (qv_qparams.h)
+    QpTail tail;
 };
 
 constexpr int kStandIn = 512;
@@ -689,10 +692,15 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
         float* smx = smn + NW;
         if (lane == 0) { smn[wave] = mn; smx[wave] = mx; }
         lds_barrier();
+        bool tailed = false;
+        if constexpr (PM == 0 || PM == 3) tailed = p.tail.counter != nullptr;   // (uniform)
         if (tid == 0) {
 #pragma unroll
             for (int w = 1; w < NW; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); }
-            stat_atomic(p.stats, p.stat_slots, mn, mx);
+            if (!tailed) stat_atomic(p.stats, p.stat_slots, mn, mx);
+        }
+        if constexpr (PM == 0 || PM == 3) {
+            if (tailed) qparams_tail(p.tail, p.stats, p.stat_slots, gridDim.x, reinterpret_cast<uint32_t*>(smem) + 2 * NW, mn, mx);
         }
     }
 }
@@ -1263,7 +1271,7 @@ static void nt_br_launch(const NTArgs& a, int grid, hipStream_t st) {
 
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                   const void* B_lo, const NTPost* post, bool f16) {
+                   const void* B_lo, const NTPost* post, bool f16, const QpTail* tail) {
     if (f16 && (!A_lo || B_lo || (post && post->mode != 6) || N % 384 != 0 || K % 32 != 0)) {
         set_error("gemm_nt: the fp16 form takes a split A operand, N %% 384 == 0, the plain or the residual (mode 6) epilogue (N=%d K=%d)", N, K);
         return 1;
@@ -1277,6 +1285,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
              reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
              0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
              nullptr, nullptr};
+    if (tail && stats) a.tail = *tail;
     if (post && post->mode >= 3) {
         a.post_mode = post->mode;
         a.pm = post->mode;
@@ -1439,7 +1448,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 
 // fc2 forward from codes: A8 [M, lda] uint8 grid indices, lut[256] packed fp16 (hi | lo << 16) pairs, B16 [N, ldb] the weight integers as fp16
 int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st) {
+                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st, const QpTail* tail) {
     if (M < 1 || N % 384 != 0 || K % 64 != 0 || lda % 16 != 0 || ldb % 8 != 0 || ldc % 4 != 0 || !A8 || !lut || !B16 || !C) {
         set_error("gemm_nt_codes: unsupported arguments M=%d N=%d K=%d lda=%d ldb=%d ldc=%d (need N%%384==0, K%%64==0, lda%%16==0)", M, N, K, lda, ldb, ldc);
         return 1;
@@ -1449,6 +1458,7 @@ int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, f
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.s1 = s1; a.s2 = s2; a.col_scale = col_scale; a.bias = bias; a.stats = stats; a.stat_slots = stat_slots < 1 ? 1 : stat_slots;
     a.a_lut = lut;
+    if (tail && stats) a.tail = *tail;
     constexpr int kLds = 3 * (2 * 208 + 384) * 64 + 1024;   // 151 KiB
     static bool once = (allow_lds(k_gemm_nt_ac<3, 0, kLds>, (size_t)kLds), true);
     (void)once;
@@ -1461,7 +1471,7 @@ int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, f
 // bit for bit (both accumulate the same integers exactly).  Tall 208 x 384 tiles only: N % 384 == 0, K % 64 == 0.
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
-                      hipStream_t st, const NTPost* post) {
+                      hipStream_t st, const NTPost* post, const QpTail* tail) {
     if (M < 1 || N % 384 != 0 || K % 64 != 0 || lda % 16 != 0 || ldb % 16 != 0 || ldc % 4 != 0 || !wsum || !a_qp) {
         set_error("gemm_nt_i8: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d (need N%%384==0, K%%64==0, ld%%16==0)", M, N, K, lda, ldb);
         return 1;
@@ -1469,6 +1479,7 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
     NTArgs a{reinterpret_cast<const __bf16*>(A8), nullptr, reinterpret_cast<const __bf16*>(B8), nullptr, C, M, N, K / 2, lda / 2, ldb / 2, ldc, s1, s2,
              col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, 0, 0, wsum, a_qp, center, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr,
              nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (tail && stats) a.tail = *tail;
     if (post) {
         if (post->mode != 3 && post->mode != 4 && post->mode != 6 && post->mode != 7) { set_error("gemm_nt_i8: epilogue mode %d not available", post->mode); return 1; }
         a.post_mode = a.pm = post->mode;
