@@ -1239,7 +1239,7 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
 }
 
 // QATVIT_NT_BREG=1: the tall NT launches take their B operand through registers (k_gemm_nt_br).  Default 0 (both operands through LDS): measured
-// equal within +-3 % on every shape of the step (profiles/round2_nt_breg_ab.txt) - the LDS-DMA fill rate is NOT what bounds these kernels
+// equal within +-3 % on every shape of the step (profiles/round2_gemm_structure_experiments.txt) - the LDS-DMA fill rate is NOT what bounds these kernels
 static int nt_breg() {
     static const int on = getenv("QATVIT_NT_BREG") ? atoi(getenv("QATVIT_NT_BREG")) : 0;
     return on;
