@@ -108,6 +108,14 @@ int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
                        int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream);
 
+/* The statistics-only first pass of a two-pass GEMM (qkv, fc1): the product of qatvit_gemm_nt_i8 is formed for its minimum / maximum only, which
+ * go into stats[0] / stats[1] as order-preserving uint32 (atomicMin / atomicMax on the caller-initialised pair {0xff800000, 0x007fffff}).  strip != 0:
+ * the A-stationary kernel (K == 384; N % 1152 == 0 or N % 1536 == 0: one workgroup per 208-row strip keeps its A rows in LDS and streams the weight);
+ * strip == 0: the general tiled kernel.  Both return the same bits. */
+int qatvit_gemm_nt_i8_minmax(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N, int32_t K,
+                             int32_t lda, int32_t ldb, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats,
+                             int32_t strip, void* stream);
+
 /* qatvit_gemm_nt_f16 for an A operand that takes at most 256 distinct values (mlp.fc2: A = gelu(fq(fc1 output))): A8 uint8 [M,lda] = table
  * index per element (lda in bytes), lut[256] = the fp16 (hi | lo << 16) pair per index.  The kernel expands the codes through the table on their
  * way into LDS: bit-identical to qatvit_gemm_nt_f16 on the expanded planes, 1 B instead of 4 B of HBM traffic per A element.

@@ -99,6 +99,18 @@ int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, 
     return 0;
 }
 
+int qatvit_gemm_nt_i8_minmax(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N, int32_t K,
+                             int32_t lda, int32_t ldb, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats,
+                             int32_t strip, void* stream) {
+    QV_CHECK_ARG(A8 && B8 && wsum && a_qp && stats, "qatvit_gemm_nt_i8_minmax: null pointer argument");
+    NTPost post{};
+    post.mode = 3;
+    post.stats_strip = strip ? 1 : 0;
+    if (launch_gemm_nt_i8(A8, B8, wsum, a_qp, center, nullptr, M, N, K, lda, ldb, N, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream, &post)) return 1;
+    QV_CHECK_LAUNCH("qatvit_gemm_nt_i8_minmax");
+    return 0;
+}
+
 int qatvit_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
                          int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream) {
     QV_CHECK_ARG(A8 && lut && B16 && C, "qatvit_gemm_nt_codes: null pointer argument");

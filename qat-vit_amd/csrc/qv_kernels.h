@@ -74,6 +74,8 @@ struct NTPost {
     // mode 4, optional: out8 = the grid index (q - qmin) of every element as uint8 [M, ldc] and lut_out[256] = packed fp16 (hi | lo << 16) pair of
     // 2^k * gelu(grid value) per index (with out16_scale): the A operand of launch_gemm_nt_codes - fc2 forward from 1 B per element
     uint32_t* lut_out = nullptr;
+    // mode 3 on the int8 kernel: -1 = the A-stationary strip kernel when the shape allows it (K == 384) unless QATVIT_I8_STATS_STRIP=0; 0 / 1 = force
+    int stats_strip = -1;
     // mode 7, optional (training): the STE mask bit of every element in the same order as the codes, one bit per element (head_dim % 32 == 0)
     void* out8_mask = nullptr;
     // mode 8 (split-A dgrad whose output rows are whole LayerNorm rows, N == 384): the LayerNorm backward fused into the epilogue -

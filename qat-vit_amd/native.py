@@ -31,6 +31,7 @@ SIGNATURES = {
     "qatvit_optim_adamw": (c_int, [c_void_p] * 7 + [c_int32, c_int64] + [c_double] * 5 + [c_int64, c_void_p, c_void_p]),
     "qatvit_gemm_nt": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_nt_f16": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
+    "qatvit_gemm_nt_i8_minmax": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 5 + [c_int32, c_void_p]),
     "qatvit_gemm_nt_codes": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_nt_i8": (c_int, [c_void_p] * 4 + [c_int32, c_void_p] + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_tn_scratch_bytes": (c_int64, []),

@@ -257,3 +257,49 @@ def test_gemm_nt_codes_equals_planes(native_lib, M, N, K):
     assert not torch.isnan(Cb).any()
     assert torch.equal(Ca, Cb)
     assert torch.equal(st_a, st_b)
+
+
+@pytest.mark.parametrize("per_channel", [0, 1])
+@pytest.mark.parametrize("M,N", [(1576, 1152), (1576, 1536), (50432, 1536), (50432, 1152), (209, 2304), (40, 3072)])
+def test_gemm_i8_statistics_pass_strip_kernel(native_lib, M, N, per_channel):
+    """The statistics-only first pass of the two-pass GEMMs (qkv, fc1: K = 384): the A-stationary strip kernel against the general tiled kernel and
+    against the min / max of the tensor qatvit_gemm_nt_i8 stores - the same bits (the observer, hence every code downstream, depends on them)."""
+    K = 384
+    torch.manual_seed(M + N + per_channel)
+    dev = "cuda"
+    zp, center = 131, 128
+    q = torch.randint(0, 256, (M, K), device=dev)
+    W = torch.randint(-128, 128, (N, K), device=dev)
+    A8 = (q - center).to(torch.int8)
+    B8 = W.to(torch.int8)
+    wsum = W.sum(1).to(torch.int32)
+    aqp = torch.tensor([0.0173, 1 / 0.0173, float(zp), 1.0], device=dev)
+    s1 = torch.tensor([0.0173], device=dev)
+    s2 = torch.tensor([0.0041], device=dev)
+    cs = (torch.rand(N, device=dev) * 0.01 + 0.001) if per_channel else None
+    bias = torch.randn(N, device=dev)
+
+    def fresh():
+        return torch.tensor([0xFF800000 - (1 << 32), 0x007FFFFF], dtype=torch.int32, device=dev)
+
+    C = torch.empty(M, N, device=dev)
+    st_full = fresh()
+    assert native_lib.qatvit_gemm_nt_i8(A8.data_ptr(), B8.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), center, C.data_ptr(), M, N, K, K, K, N, s1.data_ptr(),
+                                        None if per_channel else s2.data_ptr(), cs.data_ptr() if per_channel else None, bias.data_ptr(), st_full.data_ptr(),
+                                        _st()) == 0, native_lib.qatvit_last_error()
+    out = []
+    for strip in (0, 1):
+        st = fresh()
+        assert native_lib.qatvit_gemm_nt_i8_minmax(A8.data_ptr(), B8.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), center, M, N, K, K, K, s1.data_ptr(),
+                                                   None if per_channel else s2.data_ptr(), cs.data_ptr() if per_channel else None, bias.data_ptr(),
+                                                   st.data_ptr(), strip, _st()) == 0, native_lib.qatvit_last_error()
+        out.append(st)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], st_full) and torch.equal(out[1], st_full)
+
+    def ord2f(k):   # qv_common.h: order-preserving uint32 -> float
+        k = int(k) & 0xFFFFFFFF
+        u = (k & 0x7FFFFFFF) if (k & 0x80000000) else (~k & 0xFFFFFFFF)
+        return np.frombuffer(np.uint32(u).tobytes(), dtype=np.float32)[0]
+
+    assert ord2f(out[1][0]) == C.min().item() and ord2f(out[1][1]) == C.max().item()
