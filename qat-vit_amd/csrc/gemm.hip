@@ -1435,6 +1435,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         a.post_code = reinterpret_cast<uint16_t*>(post->code);
         a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
         a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
+        a.lut_out = post->lut_out; a.out8_mask = reinterpret_cast<uint8_t*>(post->out8_mask);
         a.lnb_x = post->lnb_x; a.lnb_mean = post->lnb_mean; a.lnb_rstd = post->lnb_rstd; a.lnb_gamma = post->lnb_gamma; a.lnb_beta = post->lnb_beta;
         a.lnb_dx_in = post->lnb_dx_in; a.lnb_dgamma = post->lnb_dgamma; a.lnb_dbeta = post->lnb_dbeta;
         a.lnb_nmask = reinterpret_cast<const unsigned long long*>(post->lnb_nmask);

@@ -197,6 +197,8 @@ def _run(backend, seed, teacher, golden_tag):
               tr.codes(f"model.patch_embed.proj.{A}").permute(0, 2, 3, 1).reshape(-1, D))
     tab.close("embed", "x_in[0] (cls, pos added)", eng.tensor("x_in", 0, (M, D)), tr.block_in[0].reshape(M, D))
     Hd = c.mlp_hidden
+    if os.environ.get("QATVIT_FC1_RECOMPUTE", "1") == "0" or os.environ.get("QATVIT_ATTN_CODES", "1") == "0":
+        pytest.skip("diagnostic knob set: the per-tensor checks below read the code planes of the default path (uint16 fc1 codes, qkv codes)")
     f16 = os.environ.get("QATVIT_F16", "1") != "0"
     fc2_codes = f16 and os.environ.get("QATVIT_FC2_CODES", "1") != "0"
     qkv_2pass = os.environ.get("QATVIT_QKV_2PASS", "1") != "0" and os.environ.get("QATVIT_ATTN_CODES", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0" and qb - qa <= 255

@@ -60,6 +60,12 @@ def qkv_ints(eng, block, fq_mod):
     """The fake-quantised qkv of one block as integers q - zp, [tokens, 3 * embed_dim] in the module's column order, from the uint8 code plane
     (q - qmin, layout [image][head][q|k|v][token][d]) that the qkv GEMM's second pass - or, with QATVIT_QKV_2PASS=0, the attention forward -
     left in the workspace.  The fp32 pre-fake-quant qkv tensor does not exist in the two-pass form."""
+    import os
+
+    import pytest
+
+    if os.environ.get("QATVIT_ATTN_CODES", "1") == "0":
+        pytest.skip("QATVIT_ATTN_CODES=0 (diagnostic knob): no code plane is written; this check reads it")
     c = eng.cfg
     B, H, D = c.batch, c.num_heads, c.embed_dim
     T = (c.img_size // c.patch_size) ** 2 + 1
