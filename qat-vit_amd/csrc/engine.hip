@@ -67,7 +67,7 @@ struct Plan {
     // byte offsets into the workspace
     int64_t qp_cnt;   // one ticket counter per activation quantizer (producer tails)
     int64_t stats, qp_act, qp_w, imgq, Y0, meanF, rstdF, hq, logits_pre;
-    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2, qkv8, qkvm, G8, glut;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2, qkv8, qkvm, G8, glut, Y1m;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
     int64_t blk_stride;
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
@@ -123,7 +123,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->h1q8 = take(M * D); p->h2q8 = take(M * D);
     p->mproj = take(ln_maskbits_bytes(M, (int)D)); p->m2 = take(ln_maskbits_bytes(M, (int)D));
     p->qkv8 = take(M * 3 * D); p->qkvm = take(M * 3 * D / 8);   // the quantised qkv as the attention forward saw it (codes + STE mask bits), for its backward
-    p->G8 = take(M * Hd); p->glut = take(256 * 4);   // gelu(fq(fc1 output)) as one byte per element + the 256-entry table of fp16 pairs (fc2 forward from codes)
+    p->G8 = take(M * Hd); p->glut = take(256 * 4); p->Y1m = take(M * Hd / 8);   // (Y1m: the STE mask bits of fc1's fake-quant)   // gelu(fq(fc1 output)) as one byte per element + the 256-entry table of fp16 pairs (fc2 forward from codes)
     p->blk_stride = o - b0;
     o = b0 + p->blk_stride * d.depth;
     // x_in[depth] (input of the final norm) lives where block `depth` would start
@@ -224,6 +224,13 @@ static bool use_f16() {
 // one byte per element expanded through a 256-entry table inside the GEMM (k_gemm_nt_ac) - the same bits either way
 static bool fc2_codes() {
     static const int on = getenv("QATVIT_FC2_CODES") ? atoi(getenv("QATVIT_FC2_CODES")) : 1;
+    return on != 0;
+}
+
+// QATVIT_FC1_BITS=0: the backward's fc1 codes as the uint16 plane (grid index | in-range bit << 15: 2 B per element written by fc1's storing pass and
+// read by the fc2 dgrad epilogue) instead of the byte plane fc2's forward reads anyway + one STE mask bit per element (1.125 B read, 0.125 B written)
+static bool fc1_bits() {
+    static const int on = getenv("QATVIT_FC1_BITS") ? atoi(getenv("QATVIT_FC1_BITS")) : 1;
     return on != 0;
 }
 
@@ -404,6 +411,12 @@ struct Ctx {
 // One transformer block of the forward, in four parts that each start where the stage-level parity tests inject the oracle's tensor (behind
 // a fake-quantizer that would otherwise amplify upstream one-step flips): 0 = norm1 -> qkv GEMM; 1 = attention -> proj -> residual;
 // 2 = norm2 -> fc1 -> GELU; 3 = fc2 -> residual.
+// fc1's codes for the backward as the uint8 plane + mask bits (needs the forward's fc2-from-codes form, the int8 storing pass, the tall dgrad tile)
+static bool fc1_code_bits(const Ctx& x, int i) {
+    const Dims& d = x.d;
+    return fc1_bits() && fc1_recompute() && use_i8() && fc2_codes() && x.f16_ok(x.widx(i, WB_FC2)) && d.Hd % 384 == 0 && d.D % 64 == 0 && d.Hd % 128 == 0 &&
+           x.c.act_qmax - x.c.act_qmin <= 255;
+}
 static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) {
     const Dims& d = x.d;
     const Plan& p = x.p;
@@ -434,6 +447,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         }
         const bool proj16 = x.f16_ok(x.widx(i, WB_PROJ)), fc2_16 = x.f16_ok(x.widx(i, WB_FC2)) && fc1_recompute();
         const bool fc2_c = fc2_16 && fc2_codes() && d.Hd % 64 == 0 && c.act_qmax - c.act_qmin <= 255;
+        const bool fc1_b = fc2_c && fc1_code_bits(x, i);   // the backward reads the byte plane + mask bits: no uint16 plane is written
         float* const scal16 = x.at<float>(p.scal16);
         if (parts & 2) {   // ---- part 1: attention -> proj -> residual (+ statistics of norm2)
         const bool from_codes = qkv_2pass(c) && !qkv_injected;   // part 0 left the code plane (and ran the observer); an injected fp32 qkv takes the one-pass route
@@ -469,6 +483,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
             NTPost p2{nullptr, x.act_qp(x.aidx(i, AB_FC1)), qa, qb, nullptr, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), 4,
                       x.blk<void>(p.Y1, i)};
             if (fc2_c) { p2.out8 = x.blk<void>(p.G8, i); p2.lut_out = x.blk<uint32_t>(p.glut, i); p2.out16_scale = scal16 + 1; }
+            if (fc1_b) { p2.code = nullptr; p2.out8_mask = x.blk<void>(p.Y1m, i); }
             else if (fc2_16) { p2.out16_hi = x.at<void>(p.G16_hi); p2.out16_lo = x.at<void>(p.G16_lo); p2.out16_scale = scal16 + 1; }
             if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
                              x.aidx(i, AB_FC1), &p2, false))
@@ -669,6 +684,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 NTPost post{x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), x.at<void>(p.dY1_hi),
                             x.at<void>(p.dY1_lo)};
                 if (fc1_recompute()) { post.Y = nullptr; post.mode = 5; post.code = x.blk<void>(p.Y1, i); }   // the Y1 slot holds the uint16 codes
+                if (fc1_code_bits(x, i)) { post.mode = 9; post.code = nullptr; post.code8 = x.blk<void>(p.G8, i); post.code_mask = x.blk<void>(p.Y1m, i); }
                 if (x.linear_dgrad(dYh, dYl, M, w_fc2, nullptr, &post)) return 1;
             }
             if (x.linear_wgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.blk<void>(p.h2q, i), nullptr, x.act_qp(x.aidx(i, AB_N2)),
@@ -882,7 +898,7 @@ int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, in
         {"Y1", p.Y1, true}, {"G_hi", p.G_hi, true}, {"G_lo", p.G_lo, true}, {"Y2", p.Y2, true}, {"dxA", p.dxA, false}, {"dqkv_hi", p.dqkv_hi, false},
         {"dqkv_lo", p.dqkv_lo, false}, {"dO", p.dO, false},
         {"dH", p.dH, false}, {"lse", p.lse, true}, {"O16_hi", p.O16_hi, false}, {"O16_lo", p.O16_lo, false}, {"G16_hi", p.G16_hi, false},
-        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false}, {"G8", p.G8, true}, {"glut", p.glut, true}, {"qkv8", p.qkv8, true}, {"qkvm", p.qkvm, true},
+        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false}, {"G8", p.G8, true}, {"glut", p.glut, true}, {"Y1m", p.Y1m, true}, {"qkv8", p.qkv8, true}, {"qkvm", p.qkvm, true},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) return t.off + (t.per_block ? p.blk_stride * block : 0);

@@ -150,6 +150,11 @@ struct NTArgs {
     uint8_t* out8_mask;
     // with stats: the last workgroup of the launch also runs the observer / qparams update of the output's quantizer (qv_qparams.h)
     QpTail tail;
+    // mode 9 = mode 5 with the fc1 codes as ONE byte per element (the plane fc2's forward reads: post_code8 [M, ldc]) + the STE mask as one bit per
+    // element (post_mask: bit c % 8 of byte (row * ldc + c) / 8) instead of the uint16 plane: 1.125 instead of 2 B per element read here, and the
+    // fc1 storing pass (mode 4 with out8_mask) writes 0.125 instead of 2 B per element for the backward
+    const uint8_t* post_code8;
+    const uint8_t* post_mask;
 };
 
 constexpr int kStandIn = 512;
@@ -181,16 +186,18 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     // fused GELU backward: fq(Y) only takes qmax-qmin+1 (<= 256) values, so gelu'(fq(Y)) is a table (no erf/exp per element)
     float* sLut = sC + SLAB * LDC;
     bool use_lut = false;
-    if constexpr (PM == 1 || PM == 5) {
-        use_lut = PM == 5 || (p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256);
+    constexpr bool P5 = PM == 5 || PM == 9;   // fc2 dgrad + GELU backward; 9: codes as uint8 + mask bits
+    if constexpr (PM == 1 || P5) {
+        use_lut = P5 || (p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256);
         if (use_lut && tid <= p.post_qmax - p.post_qmin) sLut[tid] = gelu_bwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
         // (published by the __syncthreads() between staging and the store loop below)
     }
     uint32_t* sLutF = reinterpret_cast<uint32_t*>(sLut);   // mode 4: packed (hi | lo << 16) bf16 pair of gelu(grid value)
     // mode 5: the slab's uint16 codes come in by LDS-DMA next to the staged tile while the accumulators are being staged (a global load
     // per store-loop iteration is a load-use chain at 8 waves per CU: fc2 dgrad took 296 us against 160 us for the plain store)
-    constexpr int CODE_BYTES = SLAB * BN * 2;
-    constexpr bool CODE_LDS = PM == 5 && RING >= SLAB * LDC * 4 + 1024 + CODE_BYTES && CODE_BYTES % 1024 == 0;
+    constexpr int CODE_BYTES = PM == 9 ? SLAB * BN + SLAB * BN / 8 : SLAB * BN * 2;   // (mode 9: the slab's codes, then its mask bits)
+    constexpr bool CODE_LDS = P5 && RING >= SLAB * LDC * 4 + 1024 + CODE_BYTES && CODE_BYTES % 1024 == 0;
+    static_assert(PM != 9 || (CODE_LDS && (SLAB * BN) % 1024 == 0 && (SLAB * BN / 8) % 1024 == 0), "mode 9: whole 1-KiB pieces of codes and of mask bits");
     // two code buffers when they fit: slab h + 1's codes are requested before slab h is staged and arrive under its store loop (one
     // buffer exposes most of a 37-49 KB fetch per slab: a CU fills at ~20-30 GB/s)
     constexpr bool CODE_DB = CODE_LDS && RING >= SLAB * LDC * 4 + 1024 + 2 * CODE_BYTES;
@@ -198,14 +205,31 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     char* sCode = smem + SLAB * LDC * 4 + 1024;
     // mode 5: the per-column scale through LDS as well.  A conditional global load inside the store loop makes the compiler wait for
     // vmcnt(0) at the merge point in EVERY iteration - which also drains the previous iteration's stores and the code DMA running ahead.
-    constexpr bool CS_LDS = PM == 5 && CODE_LDS && RING >= SLAB * LDC * 4 + 1024 + (CODE_DB ? 2 : 1) * CODE_BYTES + BN * 4;
+    constexpr bool CS_LDS = P5 && CODE_LDS && RING >= SLAB * LDC * 4 + 1024 + (CODE_DB ? 2 : 1) * CODE_BYTES + BN * 4;
     float* sCs = reinterpret_cast<float*>(sCode + (CODE_DB ? 2 : 1) * CODE_BYTES);
     if constexpr (CS_LDS) {
         for (int c = tid; c < BN; c += NW * 64) sCs[c] = p.post_colscale ? p.post_colscale[n0 + c] : 1.f;   // (published by the barrier before the first store loop)
     }
     auto code_dma = [&](int h, char* dst) -> int {   // returns the number of DMA instructions this wave issued
-        const __amdgpu_buffer_rsrc_t rCode = make_rsrc(p.post_code, (int64_t)p.M * p.ldc * 2);
         int n = 0;
+        if constexpr (PM == 9) {
+            const __amdgpu_buffer_rsrc_t rC8 = make_rsrc(p.post_code8, (int64_t)p.M * p.ldc);
+            const __amdgpu_buffer_rsrc_t rMk = make_rsrc(p.post_mask, (int64_t)p.M * p.ldc / 8);
+            constexpr int PC = SLAB * BN / 1024, PMK = SLAB * BN / 8 / 1024;
+            for (int pc = wave; pc < PC + PMK; pc += NW, ++n) {
+                if (pc < PC) {
+                    const int f = pc * 1024 + lane * 16;    // flat code index inside the slab, 16 codes (16 B) per lane, never across a row
+                    const uint32_t voff = (uint32_t)((int64_t)(m0 + SLAB * h + f / BN) * p.ldc + n0 + f % BN);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rC8, (lds_void*)(dst + pc * 1024), 16, voff, 0, 0, 0);
+                } else {
+                    const int q = (pc - PC) * 64 + lane;    // 16-B chunk of mask bits: BN / 128 = 3 per row
+                    const uint32_t voff = (uint32_t)(((int64_t)(m0 + SLAB * h + q / (BN / 128)) * p.ldc + n0) / 8 + (q % (BN / 128)) * 16);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rMk, (lds_void*)(dst + pc * 1024), 16, voff, 0, 0, 0);
+                }
+            }
+            return n;
+        }
+        const __amdgpu_buffer_rsrc_t rCode = make_rsrc(p.post_code, (int64_t)p.M * p.ldc * 2);
         for (int pc = wave; pc < CODE_BYTES / 1024; pc += NW, ++n) {
             const int f = pc * 512 + lane * 8;          // flat code index inside the slab, 8 codes (16 B) per lane, never across a row
             const uint32_t voff = (uint32_t)(((int64_t)(m0 + SLAB * h + f / BN) * p.ldc + n0 + f % BN) * 2);
@@ -214,7 +238,8 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
         return n;
     };
     uint32_t* sLutH = sLutF + 256;   // mode 4: packed fp16 (hi | lo << 16) pair of 2^k * gelu(grid value)
-    if constexpr (PM == 4) {
+    constexpr bool P4 = PM == 4 || PM == 10;   // fc1 storing pass; 10: the form that also (or only) writes the fp16 (hi, lo) planes
+    if constexpr (P4) {
         static_assert(RING == 0 || RING >= SLAB * LDC * 4 + 2048, "ring too small for the two mode-4 tables");
         // |gelu(x)| <= |x|, so the largest grid magnitude bounds the table: 2^k maps it into [2^13, 2^14) - inside fp16's range with
         // eleven bits to spare below for the lo part (every thread computes the same k from the same device scalars)
@@ -409,11 +434,11 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
 #ifndef QV_EPI_U
 #define QV_EPI_U 4
 #endif
-        if constexpr ((PM == 0 || PM == 4 || PM == 5 || PM == 7) && QV_EPI_U > 1) {
+        if constexpr ((PM == 0 || P4 || P5 || PM == 7) && QV_EPI_U > 1) {
             // Software-pipelined store loop: U iterations' LDS reads (staged values, codes), then their table lookups, then the stores.
             // The rolled loop below is one LDS round trip (two with a table) per 16 B stored at two waves per SIMD; the row guard moves
             // onto the stores so that no branch separates the reads.
-            constexpr int U = QV_EPI_U, NT_ = NW * 64;
+            constexpr int U = PM == 10 ? 2 : QV_EPI_U, NT_ = NW * 64;   // (the fp16-plane form keeps three lookups per element live: four iterations in flight spill)
             const int limit = rows_h * C4;
             for (int base = tid; base < limit; base += U * NT_) {
                 float4 v[U];
@@ -429,7 +454,10 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     off[u] = (int64_t)row * p.ldc + n0 + 4 * c4;
                     const int rls = idx < limit ? rl : 0;      // (stay inside the staged slab)
                     v[u] = *reinterpret_cast<const float4*>(sC + rls * LDC + 4 * c4);
-                    if constexpr (PM == 5) {
+                    if constexpr (PM == 9) {   // .x = the four codes, .y = their four mask bits
+                        c2[u].x = *reinterpret_cast<const uint32_t*>(sCodeH + rls * BN + 4 * c4);
+                        c2[u].y = ((uint32_t) reinterpret_cast<const uint8_t*>(sCodeH)[SLAB * BN + ((rls * BN + 4 * c4) >> 3)] >> (4 * (c4 & 1))) & 0xfu;
+                    } else if constexpr (PM == 5) {
                         if constexpr (CODE_LDS) c2[u] = *reinterpret_cast<const uint2*>(sCodeH + (rls * BN + 4 * c4) * 2);
                         else c2[u] = ok[u] ? *reinterpret_cast<const uint2*>(p.post_code + off[u]) : make_uint2(0u, 0u);
                     }
@@ -438,10 +466,10 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
 #pragma unroll
                     for (int u = 0; u < U; ++u)
                         if (ok[u]) *reinterpret_cast<float4*>(p.C + off[u]) = v[u];
-                } else if constexpr (PM == 4) {
+                } else if constexpr (P4) {
                     const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
-                    const bool w16 = p.out16_hi != nullptr, wbf = p.out_hi != nullptr, w8 = p.out8 != nullptr;   // uniform
-                    uint32_t w[U][4], wh[U][4], cd[U][4];
+                    const bool w16 = PM == 10 && p.out16_hi != nullptr, wbf = p.out_hi != nullptr, w8 = p.out8 != nullptr;   // uniform
+                    uint32_t w[U][4], wh[PM == 10 ? U : 1][4], cd[U][4];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const float cv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -450,7 +478,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                             const float t = rintf(cv[e] * qinv) + qzp;
                             const uint32_t ix = (uint32_t)(int)(fminf(fmaxf(t, fmin_), fmax_) - fmin_);
                             w[u][e] = sLutF[ix];
-                            wh[u][e] = sLutH[ix];
+                            if constexpr (PM == 10) wh[u][e] = sLutH[ix];
                             cd[u][e] = ix | ((t >= fmin_ && t <= fmax_) ? 0x8000u : 0u);
                         }
                     }
@@ -459,13 +487,22 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         uint2 hi2, lo2, cc, h16, l16;
                         hi2.x = (w[u][0] & 0xffffu) | (w[u][1] << 16); hi2.y = (w[u][2] & 0xffffu) | (w[u][3] << 16);
                         lo2.x = (w[u][0] >> 16) | (w[u][1] & 0xffff0000u); lo2.y = (w[u][2] >> 16) | (w[u][3] & 0xffff0000u);
-                        h16.x = (wh[u][0] & 0xffffu) | (wh[u][1] << 16); h16.y = (wh[u][2] & 0xffffu) | (wh[u][3] << 16);
-                        l16.x = (wh[u][0] >> 16) | (wh[u][1] & 0xffff0000u); l16.y = (wh[u][2] >> 16) | (wh[u][3] & 0xffff0000u);
+                        if constexpr (PM == 10) {
+                            h16.x = (wh[u][0] & 0xffffu) | (wh[u][1] << 16); h16.y = (wh[u][2] & 0xffffu) | (wh[u][3] << 16);
+                            l16.x = (wh[u][0] >> 16) | (wh[u][1] & 0xffff0000u); l16.y = (wh[u][2] >> 16) | (wh[u][3] & 0xffff0000u);
+                        } else h16 = l16 = make_uint2(0u, 0u);
                         cc.x = cd[u][0] | (cd[u][1] << 16); cc.y = cd[u][2] | (cd[u][3] << 16);
                         if (ok[u] && wbf) {
                             *reinterpret_cast<uint2*>(p.out_hi + off[u]) = hi2;
                             *reinterpret_cast<uint2*>(p.out_lo + off[u]) = lo2;
-                            *reinterpret_cast<uint2*>(p.post_code + off[u]) = cc;
+                        }
+                        if (ok[u] && p.post_code) *reinterpret_cast<uint2*>(p.post_code + off[u]) = cc;
+                        if (p.out8_mask) {   // (uniform) the four in-range bits of 8 consecutive lanes = 32 consecutive columns of one row -> one word
+                            uint32_t mk = (cd[u][0] >> 15) | ((cd[u][1] >> 15) << 1) | ((cd[u][2] >> 15) << 2) | ((cd[u][3] >> 15) << 3);
+                            mk |= ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)mk, 0x101, 0xf, 0xf, true) & 0xfu) << 4;
+                            mk |= ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)mk, 0x102, 0xf, 0xf, true) & 0xffu) << 8;
+                            mk |= ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)mk, 0x104, 0xf, 0xf, true) & 0xffffu) << 16;
+                            if (ok[u] && (lane & 7) == 0) *reinterpret_cast<uint32_t*>(p.out8_mask + (off[u] >> 3)) = mk;
                         }
                         if (ok[u] && w16) {
                             *reinterpret_cast<uint2*>(p.out16_hi + off[u]) = h16;
@@ -506,11 +543,12 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                             if (p.out8_mask && (lane & 7) == 0) *reinterpret_cast<uint32_t*>(p.out8_mask + (eo >> 3)) = mk;
                         }
                     }
-                } else {   // PM == 5
+                } else {   // PM == 5 / 9
                     float dg[U][4];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const uint32_t cd[4] = {c2[u].x & 0xffffu, c2[u].x >> 16, c2[u].y & 0xffffu, c2[u].y >> 16};
+                        const uint32_t cd[4] = {PM == 9 ? c2[u].x : c2[u].x & 0xffffu, PM == 9 ? c2[u].x >> 8 : c2[u].x >> 16,
+                                                PM == 9 ? c2[u].x >> 16 : c2[u].y & 0xffffu, PM == 9 ? c2[u].x >> 24 : c2[u].y >> 16};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) dg[u][e] = sLut[cd[e] & 0xffu];   // (unconditional: no branch between the lookups)
                     }
@@ -525,7 +563,8 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const uint32_t cde = (e & 1) ? ((e & 2) ? c2[u].y : c2[u].x) >> 16 : ((e & 2) ? c2[u].y : c2[u].x);
-                            const float o = (cde & 0x8000u) ? cv[e] * dg[u][e] * sv[e] : 0.f;
+                            const bool in_range = PM == 9 ? ((c2[u].y >> e) & 1u) != 0 : (cde & 0x8000u) != 0;
+                            const float o = in_range ? cv[e] * dg[u][e] * sv[e] : 0.f;
                             oh[e] = (__bf16)o;
                             ol[e] = (__bf16)(o - (float)oh[e]);
                         }
@@ -565,7 +604,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     }
                     *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
                     *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
-                } else if constexpr (PM == 4) {
+                } else if constexpr (P4) {
                     const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
                     const float cv[4] = {v.x, v.y, v.z, v.w};
                     uint32_t w[4], cd[4];
@@ -909,8 +948,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     constexpr bool PM5_48 = PM == 5 && RING_ >= 48 * (BN + 4) * 4 + 1024 + 2 * 48 * BN * 2 && RING_ < 64 * (BN + 4) * 4 + 1024 + 2 * 64 * BN * 2;
     // mode 8 (fused LayerNorm backward) stages 96 rows at a time in 160 KiB of LDS (the launch asks for it): 84 instead of 108 accumulator
     // registers are still live while the first slab's rows are processed
-    constexpr int SLAB = PM == 8 ? 96 : PM5_48 ? 48 : RING_ >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;
-    constexpr int EPI_LDS = PM == 8 ? 160 * 1024 : NSTAGE * STAGE;
+    // mode 9: 64 rows + two (codes + mask bits) buffers of 27 KiB need 154 KiB: the launch asks for 160 like mode 8
+    constexpr int SLAB = PM == 8 ? 96 : PM == 9 ? 64 : PM5_48 ? 48 : RING_ >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;
+    constexpr int EPI_LDS = (PM == 8 || PM == 9) ? 160 * 1024 : NSTAGE * STAGE;
     static_assert(EPI_LDS >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
     nt_epilogue<WM, WN, TM, TNT, SLAB, PM, EPI_LDS, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
@@ -1359,6 +1399,7 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
         switch (a.pm) {
             case 3: QV_PM(3); break;
             case 4: QV_PM(4); break;
+            case 10: QV_PM(10); break;
             case 6: QV_PM(6); break;
             case 7: QV_PM(7); break;
             default: QV_PM(0); break;
@@ -1369,9 +1410,13 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
             case 2: QV_PM(2); break;
             case 3: QV_PM(3); break;
             case 4: QV_PM(4); break;
+            case 10: QV_PM(10); break;
             case 5: QV_PM(5); break;
             case 8:
                 if constexpr (TA == 2 && TB == 1 && WM == 1 && WN == 8 && TM == 13 && TNT == 3) QV_PM(8);   // (whole 384-column rows per tile only)
+                break;
+            case 9:
+                if constexpr (TA == 2 && TB == 1 && WM == 1 && WN == 8 && TM == 13 && TNT == 3) QV_PM(9);   // (the tall tile only)
                 break;
             default: QV_PM(0); break;
         }
@@ -1399,6 +1444,7 @@ static void nt_br_launch(const NTArgs& a, int grid, hipStream_t st) {
         switch (a.pm) {
             case 3: QV_BR(3); break;
             case 4: QV_BR(4); break;
+            case 10: QV_BR(10); break;
             default: QV_BR(0); break;
         }
     } else {
@@ -1436,9 +1482,20 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
         a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
         a.lut_out = post->lut_out; a.out8_mask = reinterpret_cast<uint8_t*>(post->out8_mask);
+        if (post->mode == 4 && a.out16_hi) a.pm = 10;
         a.lnb_x = post->lnb_x; a.lnb_mean = post->lnb_mean; a.lnb_rstd = post->lnb_rstd; a.lnb_gamma = post->lnb_gamma; a.lnb_beta = post->lnb_beta;
         a.lnb_dx_in = post->lnb_dx_in; a.lnb_dgamma = post->lnb_dgamma; a.lnb_dbeta = post->lnb_dbeta;
         a.lnb_nmask = reinterpret_cast<const unsigned long long*>(post->lnb_nmask);
+        if (post->mode == 9) {
+            a.post_code8 = reinterpret_cast<const uint8_t*>(post->code8); a.post_mask = reinterpret_cast<const uint8_t*>(post->code_mask);
+            if (!(A_lo && !f16 && !B_lo && N % 384 == 0 && K % 32 == 0 && ldc % 128 == 0 && a.post_qp && a.out_hi && a.out_lo && a.post_code8 && a.post_mask &&
+                  a.post_qmax - a.post_qmin < 256)) {
+                set_error("gemm_nt: epilogue mode 9 needs a split A operand, N %% 384 == 0, ldc %% 128 == 0, the uint8 codes and the mask bits");
+                return 1;
+            }
+            nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), (size_t)160 * 1024, st);
+            return 0;
+        }
         if (post->mode == 8) {
             if (!(A_lo && !f16 && !B_lo && N == 384 && K % 32 == 0 && ldc == 384 && C && a.post_qp && a.lnb_x && a.lnb_mean && a.lnb_rstd && a.lnb_gamma && a.lnb_beta &&
                   a.lnb_dx_in && a.lnb_dgamma && a.lnb_dbeta && (!a.out_hi || (a.out_lo && a.lnb_nmask)))) {
@@ -1516,7 +1573,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);
         return 0;
     }
-    if (nt_breg() && !B_lo && N % 384 == 0 && K % 64 == 0 && (a.pm == 0 || (A_lo && a.pm == 5) || (!A_lo && (a.pm == 3 || a.pm == 4)))) {
+    if (nt_breg() && !B_lo && N % 384 == 0 && K % 64 == 0 && (a.pm == 0 || (A_lo && a.pm == 5) || (!A_lo && (a.pm == 3 || a.pm == 4 || a.pm == 10)))) {
         if (A_lo) nt_br_launch<2, 4, false, false, kLdsBr2>(a, cdiv(M, 208) * (N / 384), st);
         else nt_br_launch<1, 4, false, false, kLdsBr1>(a, cdiv(M, 208) * (N / 384), st);
         return 0;
@@ -1631,7 +1688,8 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
         a.out16_hi = reinterpret_cast<_Float16*>(post->out16_hi); a.out16_lo = reinterpret_cast<_Float16*>(post->out16_lo); a.out16_scale = post->out16_scale;
         a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
         a.lut_out = post->lut_out; a.out8_mask = reinterpret_cast<uint8_t*>(post->out8_mask);
-        const bool full4 = a.out_hi && a.out_lo && a.post_code, half4 = !a.out_hi && !a.out_lo && !a.post_code && a.out16_hi && a.out16_lo && a.out16_scale;
+        if (post->mode == 4 && a.out16_hi) a.pm = 10;   // the instantiation that also looks up / stores the fp16 planes
+        const bool full4 = a.out_hi && a.out_lo && (a.post_code || (post->mode == 4 && a.out8 && a.out8_mask && ldc % 32 == 0)), half4 = !a.out_hi && !a.out_lo && !a.post_code && a.out16_hi && a.out16_lo && a.out16_scale;
         if ((post->mode == 4 && (!a.post_qp || !(full4 || half4) || a.post_qmax - a.post_qmin >= 256)) ||
             (post->mode == 6 && (!a.post_qp || !a.resid || !C)) ||
             (post->mode == 7 && (!a.post_qp || !a.out8 || a.code_T < 1 || a.code_hd < 8 || (a.out8_mask && a.code_hd % 32 != 0) || (a.code_hd & (a.code_hd - 1)) != 0 || M >= (1 << 22) || N / 3 >= 1024 || a.code_T >= 1024 || (N / 3) % a.code_hd != 0 || a.post_qmax - a.post_qmin >= 256))) {

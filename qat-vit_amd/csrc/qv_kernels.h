@@ -74,6 +74,10 @@ struct NTPost {
     // mode 4, optional: out8 = the grid index (q - qmin) of every element as uint8 [M, ldc] and lut_out[256] = packed fp16 (hi | lo << 16) pair of
     // 2^k * gelu(grid value) per index (with out16_scale): the A operand of launch_gemm_nt_codes - fc2 forward from 1 B per element
     uint32_t* lut_out = nullptr;
+    // mode 9 (= mode 5 with the codes as one byte per element + the STE mask as one bit per element): code8 uint8 [M, ldc], code_mask bit c % 8 of
+    // byte (row * ldc + c) / 8.  Mode 4 writes that mask plane when out8_mask is set (then `code`, the uint16 plane, may be NULL).
+    const void* code8 = nullptr;
+    const void* code_mask = nullptr;
     // mode 3 on the int8 kernel: -1 = the A-stationary strip kernel when the shape allows it (K == 384) unless QATVIT_I8_STATS_STRIP=0; 0 / 1 = force
     int stats_strip = -1;
     // mode 7, optional (training): the STE mask bit of every element in the same order as the codes, one bit per element (head_dim % 32 == 0)

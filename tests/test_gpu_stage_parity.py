@@ -201,6 +201,7 @@ def _run(backend, seed, teacher, golden_tag):
         pytest.skip("diagnostic knob set: the per-tensor checks below read the code planes of the default path (uint16 fc1 codes, qkv codes)")
     f16 = os.environ.get("QATVIT_F16", "1") != "0"
     fc2_codes = f16 and os.environ.get("QATVIT_FC2_CODES", "1") != "0"
+    fc1_bits = fc2_codes and os.environ.get("QATVIT_FC1_BITS", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0"
     qkv_2pass = os.environ.get("QATVIT_QKV_2PASS", "1") != "0" and os.environ.get("QATVIT_ATTN_CODES", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0" and qb - qa <= 255
 
     def cmp_part(tb, st, i, part, lim=CODE_FLIP_FRAC, tol=TOL, split_fc2=True):
@@ -230,7 +231,12 @@ def _run(backend, seed, teacher, golden_tag):
             tb.close(st, "x_mid", eng.tensor("x_mid", i, (M, D)), tr.norm2_in[i].reshape(M, D), tol)
         elif part == 2:
             tb.codes(st, "norm2", eng.tensor("h2q", i, (M, D), torch.bfloat16), tr.codes(f"{pre}.norm2.{A}").reshape(M, D), lim)
-            code = eng.tensor("Y1", i, (M, Hd), torch.int16).int() & 0xffff                     # (q - qmin) | in_range << 15
+            if fc1_bits:   # the backward's form of the fc1 codes: the byte plane fc2's forward reads + one STE mask bit per element
+                mb = eng.tensor("Y1m", i, (M, Hd // 8), torch.uint8).int()
+                inr = ((mb.unsqueeze(-1) >> torch.arange(8, device=mb.device)) & 1).reshape(M, Hd)
+                code = eng.tensor("G8", i, (M, Hd), torch.uint8).int() | (inr << 15)
+            else:
+                code = eng.tensor("Y1", i, (M, Hd), torch.int16).int() & 0xffff                 # (q - qmin) | in_range << 15
             f1 = fqm[f"{pre}.mlp.fc1.{A}"]
             tb.codes(st, "mlp.fc1", (code & 0x7fff).float() + qa - f1.zero_point.float(), tr.codes(f"{pre}.mlp.fc1.{A}").reshape(M, Hd), lim)
             of1 = tr.fq[f"{pre}.mlp.fc1.{A}"]
