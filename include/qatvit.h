@@ -141,6 +141,12 @@ int qatvit_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
  * them in a fixed order, applies scale and mask and adds to C: no atomics on C, bit-reproducible.  dbias always uses
  * atomics.  Q_lo, s1, W (fp32 [N,Kw], with w_scale/w_zp [1] or [N]), dbias, row_div may be NULL.  N % 128 == 0, Kw % 128 == 0. */
 int64_t qatvit_gemm_tn_scratch_bytes(void);
+/* qatvit_gemm_tn for a Q operand that takes at most 256 distinct values (mlp.fc2's weight gradient: Q = gelu(fq(fc1 output))): Qc uint8 [M,ldq] =
+ * table index per element (ldq in bytes), lutQ[256] = the bf16 (hi | lo << 16) pair per index.  The kernel expands the codes inside the workgroup:
+ * bit-identical to qatvit_gemm_tn on the expanded (Q_hi, Q_lo) planes, 1 B instead of 4 B per Q element.  N % 128 == 0, Kw % 384 == 0, ldq % 16 == 0. */
+int qatvit_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int32_t M, int32_t N, int32_t Kw, int32_t ldp,
+                         int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel,
+                         int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes, void* stream);
 int qatvit_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int32_t M, int32_t N,
                    int32_t Kw, int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale,
                    const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias,

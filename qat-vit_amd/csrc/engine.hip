@@ -67,7 +67,7 @@ struct Plan {
     // byte offsets into the workspace
     int64_t qp_cnt;   // one ticket counter per activation quantizer (producer tails)
     int64_t stats, qp_act, qp_w, imgq, Y0, meanF, rstdF, hq, logits_pre;
-    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2, qkv8, qkvm, G8, glut, Y1m;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2, qkv8, qkvm, G8, glut, Y1m, glutq;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
     int64_t blk_stride;
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
@@ -123,7 +123,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->h1q8 = take(M * D); p->h2q8 = take(M * D);
     p->mproj = take(ln_maskbits_bytes(M, (int)D)); p->m2 = take(ln_maskbits_bytes(M, (int)D));
     p->qkv8 = take(M * 3 * D); p->qkvm = take(M * 3 * D / 8);   // the quantised qkv as the attention forward saw it (codes + STE mask bits), for its backward
-    p->G8 = take(M * Hd); p->glut = take(256 * 4); p->Y1m = take(M * Hd / 8);   // (Y1m: the STE mask bits of fc1's fake-quant)   // gelu(fq(fc1 output)) as one byte per element + the 256-entry table of fp16 pairs (fc2 forward from codes)
+    p->G8 = take(M * Hd); p->glut = take(256 * 4); p->Y1m = take(M * Hd / 8); p->glutq = take(256 * 4);   // (Y1m: the STE mask bits of fc1's fake-quant)   // gelu(fq(fc1 output)) as one byte per element + the 256-entry table of fp16 pairs (fc2 forward from codes)
     p->blk_stride = o - b0;
     o = b0 + p->blk_stride * d.depth;
     // x_in[depth] (input of the final norm) lives where block `depth` would start
@@ -231,6 +231,13 @@ static bool fc2_codes() {
 // read by the fc2 dgrad epilogue) instead of the byte plane fc2's forward reads anyway + one STE mask bit per element (1.125 B read, 0.125 B written)
 static bool fc1_bits() {
     static const int on = getenv("QATVIT_FC1_BITS") ? atoi(getenv("QATVIT_FC1_BITS")) : 1;
+    return on != 0;
+}
+
+// QATVIT_FC2W_CODES=0: fc2's weight gradient reads gelu(fq(fc1)) as the bf16 (hi, lo) planes fc1's storing pass wrote (4 B per element written and read)
+// instead of the byte plane + a 256-entry bf16-pair table expanded inside the wgrad kernel (launch_gemm_tn_codes) - the same bits either way
+static bool fc2w_codes() {
+    static const int on = getenv("QATVIT_FC2W_CODES") ? atoi(getenv("QATVIT_FC2W_CODES")) : 1;
     return on != 0;
 }
 
@@ -397,6 +404,14 @@ struct Ctx {
         return launch_gemm_nt(dY_hi, dY_lo, at<void>(p.wT_off[wi]), dX, M, K, N, N, N, K, c.w_per_channel ? nullptr : f.scale, nullptr, nullptr,
                               nullptr, nullptr, 1, st, nullptr, post);
     }
+    // the same with X as uint8 table indices + a 256-entry bf16-pair table (fc2: X = gelu(fq(fc1 output)))
+    int linear_wgrad_codes(const void* dY_hi, const void* dY_lo, int M, int wi, const void* X8, const uint32_t* lutq, float* dW, float* db) const {
+        int N, K; wshape(d, wi, &N, &K);
+        const qatvit_fq& f = wfq[wi];
+        ProfScope ps(prof, 6, 2.0 * M * N * K, st);
+        return launch_gemm_tn_codes(dY_hi, dY_lo, X8, lutq, dW, M, N, K, N, K, K, nullptr, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel, c.w_qmin,
+                                    c.w_qmax, db, c.w_per_channel ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
+    }
     // wgrad: dW[N,K] += sum_m dY[m,N] X[m,K] * s_x, masked by the weight FQ; db[N] += sum_m dY
     int linear_wgrad(const void* dY_hi, const void* dY_lo, int M, int wi, const void* X_hi, const void* X_lo, const float* s_x, float* dW, float* db,
                      bool dy_scaled = true) const {
@@ -417,6 +432,8 @@ static bool fc1_code_bits(const Ctx& x, int i) {
     return fc1_bits() && fc1_recompute() && use_i8() && fc2_codes() && x.f16_ok(x.widx(i, WB_FC2)) && d.Hd % 384 == 0 && d.D % 64 == 0 && d.Hd % 128 == 0 &&
            x.c.act_qmax - x.c.act_qmin <= 255;
 }
+// fc2's weight gradient from the byte plane + bf16-pair table (needs the code-bits form above and the 128 x 384 wgrad tile)
+static bool fc2w_code_form(const Ctx& x, int i) { return fc2w_codes() && fc1_code_bits(x, i) && x.d.D % 128 == 0 && x.d.Hd % 384 == 0; }
 static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) {
     const Dims& d = x.d;
     const Plan& p = x.p;
@@ -484,6 +501,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
                       x.blk<void>(p.Y1, i)};
             if (fc2_c) { p2.out8 = x.blk<void>(p.G8, i); p2.lut_out = x.blk<uint32_t>(p.glut, i); p2.out16_scale = scal16 + 1; }
             if (fc1_b) { p2.code = nullptr; p2.out8_mask = x.blk<void>(p.Y1m, i); }
+            if (fc1_b && fc2w_code_form(x, i)) { p2.out_hi = p2.out_lo = nullptr; p2.lutq_out = x.blk<uint32_t>(p.glutq, i); }   // no 4-byte plane of gelu(fq(fc1)) at all
             else if (fc2_16) { p2.out16_hi = x.at<void>(p.G16_hi); p2.out16_lo = x.at<void>(p.G16_lo); p2.out16_scale = scal16 + 1; }
             if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
                              x.aidx(i, AB_FC1), &p2, false))
@@ -679,7 +697,9 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             const int w_fc2 = x.widx(i, WB_FC2), w_fc1 = x.widx(i, WB_FC1), w_proj = x.widx(i, WB_PROJ), w_qkv = x.widx(i, WB_QKV);
             // ---- MLP branch
             if (!ln_fuse || (inject && s == stage_from)) launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
-            if (x.linear_wgrad(dYh, dYl, M, w_fc2, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
+            if (fc2w_code_form(x, i)) {
+                if (x.linear_wgrad_codes(dYh, dYl, M, w_fc2, x.blk<void>(p.G8, i), x.blk<uint32_t>(p.glutq, i), BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
+            } else if (x.linear_wgrad(dYh, dYl, M, w_fc2, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
             {   // fc2 dgrad with the GELU backward + fc1's STE mask fused into its epilogue: dY1 = (dYs . W_fc2) * gelu'(fq(Y1)) * mask(Y1)
                 NTPost post{x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), x.at<void>(p.dY1_hi),
                             x.at<void>(p.dY1_lo)};
@@ -898,7 +918,7 @@ int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, in
         {"Y1", p.Y1, true}, {"G_hi", p.G_hi, true}, {"G_lo", p.G_lo, true}, {"Y2", p.Y2, true}, {"dxA", p.dxA, false}, {"dqkv_hi", p.dqkv_hi, false},
         {"dqkv_lo", p.dqkv_lo, false}, {"dO", p.dO, false},
         {"dH", p.dH, false}, {"lse", p.lse, true}, {"O16_hi", p.O16_hi, false}, {"O16_lo", p.O16_lo, false}, {"G16_hi", p.G16_hi, false},
-        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false}, {"G8", p.G8, true}, {"glut", p.glut, true}, {"Y1m", p.Y1m, true}, {"qkv8", p.qkv8, true}, {"qkvm", p.qkvm, true},
+        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false}, {"G8", p.G8, true}, {"glut", p.glut, true}, {"Y1m", p.Y1m, true}, {"glutq", p.glutq, true}, {"qkv8", p.qkv8, true}, {"qkvm", p.qkvm, true},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) return t.off + (t.per_block ? p.blk_stride * block : 0);

@@ -155,6 +155,7 @@ struct NTArgs {
     // fc1 storing pass (mode 4 with out8_mask) writes 0.125 instead of 2 B per element for the backward
     const uint8_t* post_code8;
     const uint8_t* post_mask;
+    uint32_t* lutq_out;      // mode 4 (optional): the 256-entry table of bf16 (hi | lo << 16) pairs of gelu(grid value) - the table the fc2 weight gradient expands the codes through
 };
 
 constexpr int kStandIn = 512;
@@ -258,7 +259,11 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
             const _Float16 hl = (_Float16)(g16 - (float)hh);
             sLutH[tid] = (uint32_t)__builtin_bit_cast(uint16_t, hh) | ((uint32_t)__builtin_bit_cast(uint16_t, hl) << 16);
             if (p.lut_out && blockIdx.x == 0) p.lut_out[tid] = sLutH[tid];
-        } else if (p.lut_out && blockIdx.x == 0 && tid < 256) p.lut_out[tid] = 0u;
+            if (p.lutq_out && blockIdx.x == 0) p.lutq_out[tid] = sLutF[tid];
+        } else if (blockIdx.x == 0 && tid < 256) {
+            if (p.lut_out) p.lut_out[tid] = 0u;
+            if (p.lutq_out) p.lutq_out[tid] = 0u;
+        }
     }
     float ca[TNT], cb[TNT];
 #pragma unroll
@@ -1483,6 +1488,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
         a.lut_out = post->lut_out; a.out8_mask = reinterpret_cast<uint8_t*>(post->out8_mask);
         if (post->mode == 4 && a.out16_hi) a.pm = 10;
+        a.lutq_out = post->lutq_out;
         a.lnb_x = post->lnb_x; a.lnb_mean = post->lnb_mean; a.lnb_rstd = post->lnb_rstd; a.lnb_gamma = post->lnb_gamma; a.lnb_beta = post->lnb_beta;
         a.lnb_dx_in = post->lnb_dx_in; a.lnb_dgamma = post->lnb_dgamma; a.lnb_dbeta = post->lnb_dbeta;
         a.lnb_nmask = reinterpret_cast<const unsigned long long*>(post->lnb_nmask);
@@ -1689,7 +1695,9 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
         a.resid = post->resid; a.embed_np = post->embed_np; a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.code_T = post->code_T; a.code_hd = post->code_hd;
         a.lut_out = post->lut_out; a.out8_mask = reinterpret_cast<uint8_t*>(post->out8_mask);
         if (post->mode == 4 && a.out16_hi) a.pm = 10;   // the instantiation that also looks up / stores the fp16 planes
-        const bool full4 = a.out_hi && a.out_lo && (a.post_code || (post->mode == 4 && a.out8 && a.out8_mask && ldc % 32 == 0)), half4 = !a.out_hi && !a.out_lo && !a.post_code && a.out16_hi && a.out16_lo && a.out16_scale;
+        a.lutq_out = post->lutq_out;
+        const bool codes4 = post->mode == 4 && a.out8 && a.out8_mask && a.lut_out && a.lutq_out && !a.out_hi && !a.out_lo && !a.post_code && ldc % 32 == 0;   // codes + mask bits + the two tables only
+        const bool full4 = codes4 || (a.out_hi && a.out_lo && (a.post_code || (post->mode == 4 && a.out8 && a.out8_mask && ldc % 32 == 0))), half4 = !a.out_hi && !a.out_lo && !a.post_code && a.out16_hi && a.out16_lo && a.out16_scale;
         if ((post->mode == 4 && (!a.post_qp || !(full4 || half4) || a.post_qmax - a.post_qmin >= 256)) ||
             (post->mode == 6 && (!a.post_qp || !a.resid || !C)) ||
             (post->mode == 7 && (!a.post_qp || !a.out8 || a.code_T < 1 || a.code_hd < 8 || (a.out8_mask && a.code_hd % 32 != 0) || (a.code_hd & (a.code_hd - 1)) != 0 || M >= (1 << 22) || N / 3 >= 1024 || a.code_T >= 1024 || (N / 3) % a.code_hd != 0 || a.post_qmax - a.post_qmin >= 256))) {
@@ -1757,6 +1765,9 @@ struct TNArgs {
     int abl;              // timing-only ablation (tools/bench_gemm.py): 1 = skip the atomic epilogue
     const float* row_div; // optional [N]: results (and dbias) are divided by row_div[n] (P was pre-multiplied by the per-channel weight scale)
     float* partial;       // optional scratch [splits][tiles][tile elements]: splits store raw accumulators here, k_tn_reduce sums them in order
+    // QC form (fc2 weight gradient): the Q operand gelu(fq(fc1 output)) as ONE byte per element + a 256-entry table of bf16 (hi | lo << 16) pairs
+    const uint8_t* Qc;    // [M, ldq] uint8 table indices (ldq in bytes)
+    const uint32_t* lutQ;
 };
 
 template <int ROWB>  // ROWB: bytes per LDS row of the image (256 for a 128-column tile, 768 for a 384-column tile)
@@ -1776,7 +1787,11 @@ __device__ inline bf16x8 tr_frag(const char* img, int row0, int col0, int lane) 
 }
 
 // Output tile 128 (N) x BKW (Kw), WM x WNK waves each (16*TM) x (16*TNT); BK token rows per step.
-template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK, bool SPREAD = false>
+// QC: the Q operand comes in as uint8 table indices (12 KB instead of 48 KB of LDS-DMA per 32-token step - the L2 -> LDS fill is what bounds these
+// kernels) and is expanded through a 256-entry table of bf16 (hi, lo) pairs INSIDE the workgroup: codes of tile s+1 land in a staging buffer by
+// LDS-DMA during step s-1, every thread expands 24 of them between the MFMA groups of step s (8-B code read, eight table gathers, two 16-B writes
+// into the hi / lo images in the layout the LDS-DMA of the plane form produces), the MFMAs of step s+1 read them: same fragments, same bits.
+template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK, bool SPREAD = false, bool QC = false>
 __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     constexpr int BN = 128, NW = WM * WNK;
     constexpr int TM = BN / WM / 16;                // 16-row fragments of P per wave
@@ -1788,6 +1803,9 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     static_assert((IMGP / 1024) % NW == 0 && (IMGQ / 1024) % NW == 0, "pieces must divide evenly over the waves");
     constexpr int NDMA = 2 * PP + TQ * PQ;
     constexpr int QCH = QROWB / 16;                 // 16-B chunks per Q row
+    static_assert(!QC || (TQ == 2 && NSTAGE == 2 && BK == 32 && BKW == 384 && NW == 8 && !SPREAD), "codes form: the 128 x 384 tile, 32-token steps");
+    // QC LDS map: [3 x (P hi, P lo)] [(Q hi, Q lo) images written by the expansion] [3 x code staging] [table]
+    constexpr int QC_PST = 2 * IMGP, QC_QIMG = 3 * QC_PST, QC_QST = 2 * IMGQ, QC_CB = QC_QIMG + QC_QST, QC_CBS = BK * BKW, QC_LUT = QC_CB + 3 * QC_CBS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1849,6 +1867,113 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
+    if constexpr (QC) {
+        uint32_t* sLutQ = reinterpret_cast<uint32_t*>(smem + QC_LUT);
+        if (tid < 256) sLutQ[tid] = p.lutQ[tid];
+        const v4i32 rQc = make_rsrc_v(p.Qc, (int64_t)p.M * p.ldq);
+        auto issue_p = [&](int s) {      // this wave's P piece (hi and lo image) of k-step s
+            char* st = smem + (s % 3) * QC_PST;
+            const int mrow0 = (s_begin + s) * BK;
+            const int piece = wave, row = piece * 4 + (lane >> 4);
+            const int src_chunk = (lane & 15) ^ tn_sw(row);
+            const uint32_t offP = (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + src_chunk * 8) * 2);
+            dma16_asm(rP0, st + piece * 1024, offP);
+            dma16_asm(rP1, st + IMGP + piece * 1024, offP);
+        };
+        auto issue_c = [&](int s) {      // this wave's code pieces of k-step s: 12 KiB = 12 pieces over 8 waves, linear [32 tokens][384 codes]
+            char* cb = smem + QC_CB + (s % 3) * QC_CBS;
+            const int mrow0 = (s_begin + s) * BK;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int piece = wave + 8 * c;
+                if (piece < QC_CBS / 1024) {
+                    const int L = piece * 64 + lane, row = L / (BKW / 16), cp = L % (BKW / 16);
+                    dma16_asm(rQc, cb + piece * 1024, (uint32_t)((int64_t)(mrow0 + row) * p.ldq + k0 + cp * 16));
+                }
+            }
+        };
+        // 8 codes (chunk c8 of the tile: token c8 / 48, columns 8 (c8 % 48) ..) -> one 16-B chunk of the hi and of the lo image; the table gathers
+        // of a round are issued one MFMA group before their results are packed and stored (LDS latency under the MFMAs)
+        uint32_t w[8];
+        auto lookup = [&](int s, int i) {
+            const char* cb = smem + QC_CB + (s % 3) * QC_CBS;
+            const int c8 = tid + NW * 64 * i, row = c8 / (BKW / 8), col8 = c8 % (BKW / 8);
+            const uint2 cd = *reinterpret_cast<const uint2*>(cb + row * BKW + col8 * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w[e] = sLutQ[(cd.x >> (8 * e)) & 0xffu];
+                w[4 + e] = sLutQ[(cd.y >> (8 * e)) & 0xffu];
+            }
+        };
+        auto pack_store = [&](int s, int i) {
+            char* qi = smem + QC_QIMG;   // (one pair of images: see the second barrier of the step)
+            const int c8 = tid + NW * 64 * i, row = c8 / (BKW / 8), col8 = c8 % (BKW / 8);
+            v4i32 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hi[q] = (int)__builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x05040100u);
+                lo[q] = (int)__builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x07060302u);
+            }
+            const int o = row * QROWB + ((col8 ^ tn_sw(row)) << 4);
+            *reinterpret_cast<v4i32*>(qi + o) = hi;
+            *reinterpret_cast<v4i32*>(qi + IMGQ + o) = lo;
+        };
+        auto expand = [&](int s, int i) { lookup(s, i); pack_store(s, i); };
+        static_assert((BK * BKW / 8) % (NW * 64) == 0, "whole expansion rounds");
+        constexpr int NEXP = BK * BKW / 8 / (NW * 64);   // 3
+        static_assert(NEXP + 1 <= TM, "one MFMA group more than expansion rounds");
+        // Three P stages and three code buffers (requests run two steps ahead: a step is shorter than a DMA round trip), ONE pair of Q images:
+        // every wave takes its twelve Q fragments into registers at the top of the step, a second barrier frees the images, and the expansion of
+        // tile s+1 overwrites them between the MFMA groups of step s.
+        const int ncode = wave < QC_CBS / 1024 - 8 ? 2 : 1;          // this wave's code pieces per tile (12 pieces over 8 waves)
+        if (nsteps > 0) { issue_p(0); issue_c(0); }
+        if (nsteps > 1) { issue_p(1); issue_c(1); }
+        if (nsteps > 2) issue_c(2);
+        wait_vmcnt<0>();
+        __syncthreads();                                 // table + everything requested so far in LDS
+        if (nsteps > 0) {
+#pragma unroll
+            for (int i = 0; i < NEXP; ++i) expand(0, i);
+        }
+        for (int s = 0; s < nsteps; ++s) {
+            // P(s) and codes(s+1) have landed once only the requests of step s-1 - P(s+1), codes(s+2) - are outstanding
+            const int young = (s >= 1 && s + 1 < nsteps ? 2 : 0) + (s >= 1 && s + 2 < nsteps ? ncode : 0);
+            if (young == 4) wait_vmcnt<4>();
+            else if (young == 3) wait_vmcnt<3>();
+            else if (young == 2) wait_vmcnt<2>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // A: ... and everyone's share of the images of tile s is written
+            if (s + 2 < nsteps) issue_p(s + 2);          // into the P stage step s-1 read
+            if (s + 3 < nsteps) issue_c(s + 3);          // into the code buffer the expansion of step s-1 consumed
+            const char* st = smem + (s % 3) * QC_PST;
+            const char* sq = smem + QC_QIMG;
+            bf16x8 qf[2][TNT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) qf[t][j] = tr_frag<QROWB>(sq + t * IMGQ, 0, wn * (16 * TNT) + 16 * j, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B: every wave holds its Q fragments: the images are free
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (s + 1 < nsteps) {   // tile s+1's images, between the MFMA groups: round i's gathers here, its pack + stores one group later
+                    if (i >= 1 && i - 1 < NEXP) pack_store(s + 1, i - 1);
+                    if (i < NEXP) lookup(s + 1, i);
+                }
+                const bf16x8 ph = tr_frag<PROWB>(st, 0, wm * (16 * TM) + 16 * i, lane);
+                const bf16x8 pl = tr_frag<PROWB>(st + IMGP, 0, wm * (16 * TM) + 16 * i, lane);
+                if (do_bias) {
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ones, accb[i], 0, 0, 0);
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, ones, accb[i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, qf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[1][j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < nsteps) issue(s);
@@ -1892,6 +2017,7 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
         }
     }
 
+    }   // !QC
     // ---- epilogue: scale, weight-FQ STE mask, accumulate
     if (p.abl == 1) {
 #pragma unroll
@@ -2078,6 +2204,40 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
         else QV_TN_LAUNCH(1, 3, 4, 2, 4, 64);        // 3 x 48 KiB
     }
 #undef QV_TN_LAUNCH
+    return 0;
+}
+
+// Weight gradient with the Q operand as uint8 table indices + a 256-entry table of bf16 (hi | lo << 16) pairs (fc2: Q = gelu(fq(fc1 output))): the
+// 128 x 384 tile of launch_gemm_tn's split-Q form, the same MFMAs in the same order - bit-identical to it on the expanded planes.
+int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                         const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
+                         const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
+    if (M < 1 || N % 128 != 0 || Kw % 384 != 0 || ldp % 8 != 0 || ldq % 16 != 0 || !P_hi || !P_lo || !Qc || !lutQ || !C) {
+        set_error("gemm_tn_codes: unsupported arguments M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%384==0, ldp%%8==0, ldq%%16==0)", M, N, Kw, ldp, ldq);
+        return 1;
+    }
+    TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), nullptr, nullptr, C, M, N, Kw, ldp, ldq, ldc, 0, 0, s1, W, w_scale, w_zp,
+             w_per_channel, w_qmin, w_qmax, dbias, 0, row_div, nullptr, reinterpret_cast<const uint8_t*>(Qc), lutQ};
+    constexpr int bk = 32;
+    const int steps = (M + bk - 1) / bk;
+    const int tiles = (N / 128) * (Kw / 384);
+    int splits = 256 / tiles;
+    const int min_steps = 256 / bk;
+    if (splits > steps / min_steps) splits = steps / min_steps > 0 ? steps / min_steps : 1;
+    if (splits < 1) splits = 1;
+    a.steps_per_split = (steps + splits - 1) / splits;
+    splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
+    a.tiles = tiles;
+    const int grid = tiles * splits;
+    constexpr size_t lds = 3 * (2 * 32 * 256) + (2 * 32 * 768) + 3 * (32 * 384) + 1024;   // 133 KiB
+    constexpr int tm = 4;
+    const int64_t tile_f4 = (int64_t)2 * 4 * tm * 6 * 64;
+    const bool two_phase = partial && splits > 1 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;
+    a.partial = two_phase ? partial : nullptr;
+    static bool once = (allow_lds(k_gemm_tn<2, 2, 2, 4, 6, 32, false, true>, lds), true);
+    (void)once;
+    k_gemm_tn<2, 2, 2, 4, 6, 32, false, true><<<grid, 512, lds, st>>>(a);
+    if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, 2, 4, tm, 6);
     return 0;
 }
 

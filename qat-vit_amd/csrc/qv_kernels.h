@@ -74,6 +74,7 @@ struct NTPost {
     // mode 4, optional: out8 = the grid index (q - qmin) of every element as uint8 [M, ldc] and lut_out[256] = packed fp16 (hi | lo << 16) pair of
     // 2^k * gelu(grid value) per index (with out16_scale): the A operand of launch_gemm_nt_codes - fc2 forward from 1 B per element
     uint32_t* lut_out = nullptr;
+    uint32_t* lutq_out = nullptr;   // mode 4, optional: the same table as bf16 (hi | lo << 16) pairs (launch_gemm_tn_codes: the fc2 weight gradient)
     // mode 9 (= mode 5 with the codes as one byte per element + the STE mask as one bit per element): code8 uint8 [M, ldc], code_mask bit c % 8 of
     // byte (row * ldc + c) / 8.  Mode 4 writes that mask plane when out8_mask is set (then `code`, the uint16 plane, may be NULL).
     const void* code8 = nullptr;
@@ -114,6 +115,10 @@ constexpr int64_t kTnScratchBytes = 256ll * 128 * 384 * 4;
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                    const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
                    float* dbias, const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
+// Q operand = uint8 table indices [M, ldq bytes] + lutQ[256] packed bf16 (hi | lo << 16) pairs, expanded inside the kernel (fc2 weight gradient)
+int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                         const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
+                         const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st,
                        void* out8 = nullptr, int center = 0);

@@ -303,3 +303,43 @@ def test_gemm_i8_statistics_pass_strip_kernel(native_lib, M, N, per_channel):
         return np.frombuffer(np.uint32(u).tobytes(), dtype=np.float32)[0]
 
     assert ord2f(out[1][0]) == C.min().item() and ord2f(out[1][1]) == C.max().item()
+
+
+@pytest.mark.parametrize("two_phase", [0, 1])
+@pytest.mark.parametrize("M,N,Kw", [(1000, 384, 1536), (5000, 384, 1536), (50432, 384, 1536), (777, 768, 3072)])
+def test_gemm_tn_codes_equals_planes(native_lib, M, N, Kw, two_phase):
+    """fc2 weight gradient from codes: the Q operand as uint8 table indices + a 256-entry table of bf16 (hi, lo) pairs, expanded inside the workgroup,
+    against qatvit_gemm_tn on the expanded planes (the same 128 x 384 tile, the same MFMAs in the same order): bit-identical with the ordered
+    two-phase reduction, and within 2e-5 of fp64 either way."""
+    torch.manual_seed(M + N + Kw)
+    dev = "cuda"
+    P = torch.randn(M, N, device=dev) * 1e-3
+    Ph, Pl = split(P)
+    idx = (torch.randn(M, Kw, device=dev).abs() * 40).clamp(0, 255).to(torch.uint8)
+    idx[::5, ::3] = torch.randint(0, 256, idx[::5, ::3].shape, device=dev, dtype=torch.uint8)
+    vals = torch.randn(256, device=dev) * 2.0 ** torch.randint(-6, 3, (256,), device=dev).float()
+    th, tl = split(vals)
+    lut = (th.view(torch.int16).int() & 0xffff) | (tl.view(torch.int16).int() << 16)
+    Qh, Ql = th[idx.long()].contiguous(), tl[idx.long()].contiguous()
+    s1 = torch.tensor([0.031], device=dev)
+    W = torch.randn(N, Kw, device=dev)
+    w_scale = torch.tensor([2.0 / 127], device=dev)
+    w_zp = torch.zeros(1, dtype=torch.int32, device=dev)
+    nb = native_lib.qatvit_gemm_tn_scratch_bytes()
+    scratch = torch.empty(nb if two_phase else 16, dtype=torch.uint8, device=dev)
+    Ca, Cb = torch.zeros(N, Kw, device=dev), torch.zeros(N, Kw, device=dev)
+    dba, dbb = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    sp, sn = (scratch.data_ptr(), nb) if two_phase else (None, 0)
+    assert native_lib.qatvit_gemm_tn(Ph.data_ptr(), Pl.data_ptr(), Qh.data_ptr(), Ql.data_ptr(), Ca.data_ptr(), M, N, Kw, N, Kw, Kw, s1.data_ptr(), W.data_ptr(),
+                                     w_scale.data_ptr(), w_zp.data_ptr(), 0, -128, 127, dba.data_ptr(), None, sp, sn, _st()) == 0, native_lib.qatvit_last_error()
+    assert native_lib.qatvit_gemm_tn_codes(Ph.data_ptr(), Pl.data_ptr(), idx.data_ptr(), lut.data_ptr(), Cb.data_ptr(), M, N, Kw, N, Kw, Kw, s1.data_ptr(),
+                                           W.data_ptr(), w_scale.data_ptr(), w_zp.data_ptr(), 0, -128, 127, dbb.data_ptr(), None, sp, sn, _st()) == 0, \
+        native_lib.qatvit_last_error()
+    torch.cuda.synchronize()
+    if two_phase:
+        assert torch.equal(Ca, Cb)
+    qv = torch.round(W * (torch.ones(1, device=dev) / w_scale))
+    mask = ((qv >= -128) & (qv <= 127)).double()
+    ref = (P.double().t() @ (Qh.double() + Ql.double())) * s1.double() * mask
+    assert rel_l2(Cb.cpu(), ref.cpu()) < 2e-5 and rel_l2(Ca.cpu(), ref.cpu()) < 2e-5
+    assert rel_l2(dbb.cpu(), P.double().sum(0).cpu()) < 2e-5

@@ -201,6 +201,7 @@ def _run(backend, seed, teacher, golden_tag):
         pytest.skip("diagnostic knob set: the per-tensor checks below read the code planes of the default path (uint16 fc1 codes, qkv codes)")
     f16 = os.environ.get("QATVIT_F16", "1") != "0"
     fc2_codes = f16 and os.environ.get("QATVIT_FC2_CODES", "1") != "0"
+    fc2w_codes = fc2_codes and os.environ.get("QATVIT_FC1_BITS", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0" and os.environ.get("QATVIT_FC2W_CODES", "1") != "0"
     fc1_bits = fc2_codes and os.environ.get("QATVIT_FC1_BITS", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0"
     qkv_2pass = os.environ.get("QATVIT_QKV_2PASS", "1") != "0" and os.environ.get("QATVIT_ATTN_CODES", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0" and qb - qa <= 255
 
@@ -243,8 +244,14 @@ def _run(backend, seed, teacher, golden_tag):
             ref_in = (tr.pre(f"{pre}.mlp.fc1.{A}") * (1.0 / of1.scale)).round() + of1.zero_point
             ref_mask = ((ref_in >= qa) & (ref_in <= qb)).reshape(M, Hd)
             tb.codes(st, "mlp.fc1 STE mask", (code >> 15).float(), ref_mask.float(), lim)
-            gl = eng.tensor("G_hi", i, (M, Hd), torch.bfloat16).float() + eng.tensor("G_lo", i, (M, Hd), torch.bfloat16).float()
-            tb.close(st, "gelu out (bf16 pair, bwd)", gl, tr.fc2_in[i].reshape(M, Hd), tol)
+            if fc2w_codes:   # what the fc2 weight gradient reads: the byte plane + the 256-entry table of bf16 (hi, lo) pairs
+                lq = eng.tensor("glutq", i, (256,), torch.int32)
+                pq = (lq & 0xffff).to(torch.int16).view(torch.bfloat16).float() + ((lq >> 16) & 0xffff).to(torch.int16).view(torch.bfloat16).float()
+                gl = pq[eng.tensor("G8", i, (M, Hd), torch.uint8).long()]
+                tb.close(st, "gelu out (codes + bf16 pair table, bwd)", gl, tr.fc2_in[i].reshape(M, Hd), tol)
+            else:
+                gl = eng.tensor("G_hi", i, (M, Hd), torch.bfloat16).float() + eng.tensor("G_lo", i, (M, Hd), torch.bfloat16).float()
+                tb.close(st, "gelu out (bf16 pair, bwd)", gl, tr.fc2_in[i].reshape(M, Hd), tol)
             if f16 and fc2_codes:   # what the fc2 forward GEMM reads: one byte per element + the 256-entry table of fp16 (hi, lo) pairs
                 sc = eng.tensor("scal16", 0, (2,))
                 lut = eng.tensor("glut", i, (256,), torch.int32)
@@ -330,6 +337,12 @@ def _run(backend, seed, teacher, golden_tag):
                 lo_t[idx.reshape(-1)] = (gs - g16h.float()).to(torch.float16).reshape(-1)
                 packed = (hi_t.view(torch.int16).int() & 0xffff) | (lo_t.view(torch.int16).int() << 16)
                 eng.tensor("glut", i, (256,), torch.int32).copy_(packed)
+                if fc2w_codes:   # ... and the bf16-pair table the fc2 weight gradient expands the same codes through
+                    qh_t = torch.zeros(256, dtype=torch.bfloat16, device="cuda")
+                    ql_t = torch.zeros(256, dtype=torch.bfloat16, device="cuda")
+                    qh_t[idx.reshape(-1)] = gh.reshape(-1)
+                    ql_t[idx.reshape(-1)] = (g_ref - gh.float()).to(torch.bfloat16).reshape(-1)
+                    eng.tensor("glutq", i, (256,), torch.int32).copy_((qh_t.view(torch.int16).int() & 0xffff) | (ql_t.view(torch.int16).int() << 16))
                 eng.tensor("G8", i, (M, Hd), torch.uint8).copy_(idx.to(torch.uint8))
             else:
                 eng.tensor("G16_hi", 0, (M, Hd), torch.float16).copy_(g16h)
