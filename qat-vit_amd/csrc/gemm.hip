@@ -482,7 +482,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         for (int e = 0; e < 4; ++e) {
                             const float t = rintf(cv[e] * qinv) + qzp;
                             const uint32_t ix = (uint32_t)(int)(fminf(fmaxf(t, fmin_), fmax_) - fmin_);
-                            w[u][e] = sLutF[ix];
+                            w[u][e] = wbf ? sLutF[ix] : 0u;   // (uniform: the codes-only form of the pass looks nothing up)
                             if constexpr (PM == 10) wh[u][e] = sLutH[ix];
                             cd[u][e] = ix | ((t >= fmin_ && t <= fmax_) ? 0x8000u : 0u);
                         }
