@@ -313,13 +313,13 @@ def main():
     # ---- per-kernel legs: every rank runs the same extra steps (collectives stay matched), rank 0 times its own launches
     KINDS = {1: "k_gemm_nt split-A, plain epilogue (proj / fc2 forward on fp16 pairs, proj dgrad on bf16 pairs)",
              4: "k_gemm_nt split-A dgrad + LayerNorm backward fused into the epilogue (fc1 / qkv dgrad, mode 8)",
-             5: "k_gemm_nt split-A fc2 dgrad + GELU backward fused into the epilogue (mode 5)",
+             5: "k_gemm_nt split-A fc2 dgrad + GELU backward fused into the epilogue (mode 9: codes + mask bits; mode 5: uint16 codes)",
              2: "k_gemm_nt grid A on int8 MFMA, plain epilogue (patch embedding; qkv when it runs once)",
              7: "k_gemm_nt grid A on int8 MFMA, statistics-only pass (mode 3: qkv and fc1 first passes)",
-             8: "k_gemm_nt grid A on int8 MFMA, fc1 storing pass (mode 4: gelu(fq(.)) as codes + bf16 pair)",
+             8: "k_gemm_nt grid A on int8 MFMA, fc1 storing pass (mode 4: gelu(fq(.)) as uint8 codes + STE mask bits + two 256-entry tables)",
              9: "k_gemm_nt grid A on int8 MFMA, qkv code pass (mode 7: uint8 codes + STE mask bits in the attention layout)",
              3: "k_gemm_tn<1,..> + k_tn_reduce: weight gradients with grid X (qkv / fc1 / patch-embed; split dY: 2 bf16 passes issued)",
-             6: "k_gemm_tn<2,..> + k_tn_reduce: weight gradients with split X (proj / fc2; 3 bf16 passes issued)"}
+             6: "k_gemm_tn<2,..> + k_tn_reduce: weight gradients with split X (proj; fc2 with X as codes expanded in the kernel; 3 bf16 passes issued)"}
     SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_plain", 7: "nt_int8_stats_pass",
              8: "nt_int8_fc1_store_pass", 9: "nt_int8_qkv_code_pass", 3: "tn_grid_x", 6: "tn_split_x"}
     prof = {}
@@ -338,6 +338,8 @@ def main():
         Mr, Dm, Hd, dep = args.batch * T, c.embed_dim, c.mlp_hidden, c.depth
         Kpe, Mpe = c.in_chans * c.patch_size ** 2, args.batch * (T - 1)
         codes = os.environ.get("QATVIT_FC2_CODES", "1") != "0" and os.environ.get("QATVIT_F16", "1") != "0"
+        bits = codes and os.environ.get("QATVIT_FC1_BITS", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0"      # fc1 codes for the backward: byte plane + mask bits
+        fc2w = bits and os.environ.get("QATVIT_FC2W_CODES", "1") != "0"                                                # fc2 wgrad from the byte plane: no bf16 pair of gelu(fq(fc1))
         qkv2 = os.environ.get("QATVIT_QKV_2PASS", "1") != "0" and os.environ.get("QATVIT_ATTN_CODES", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0"
         # ALGORITHMIC HBM bytes per step of each class: every operand once, in the format the kernel reads / writes it;
         # weights once per launch; split-reduction partials, mask bit planes (1/32 of an fp32 plane) and re-reads are NOT counted
@@ -347,14 +349,14 @@ def main():
                       + (Mr * Hd * (1 if codes else 4) + Dm * Hd * 2 + Mr * Dm * 4)              # fc2 forward: codes (or fp16 pair) in, fp32 out
                       + (Mr * Dm * 4 + Dm * Dm * 2 + Mr * Dm * 4)),                              # proj dgrad: bf16 pair in, fp32 out
             4: dep * ((Mr * Hd * 4 + Dm * Hd * 2 + lnb) + (Mr * 3 * Dm * 4 + 3 * Dm * Dm * 2 + lnb)),   # fc1 dgrad, qkv dgrad (+ LayerNorm backward)
-            5: dep * (Mr * Dm * 4 + Dm * Hd * 2 + Mr * Hd * 2 + Mr * Hd * 4),                    # fc2 dgrad: pair in, uint16 codes in, pair out
+            5: dep * (Mr * Dm * 4 + Dm * Hd * 2 + (Mr * Hd * 9 // 8 if bits else Mr * Hd * 2) + Mr * Hd * 4),   # fc2 dgrad: pair in, codes (+ mask bits) in, pair out
             2: (Mpe * Kpe + Dm * Kpe + Mpe * Dm * 4) + (0 if qkv2 else dep * (Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 4)),   # patch embedding (+ one-pass qkv: fp32 out)
             7: dep * ((Mr * Dm + Hd * Dm) + ((Mr * Dm + 3 * Dm * Dm) if qkv2 else 0)),          # statistics passes: operands in, nothing stored
-            8: dep * (Mr * Dm + Hd * Dm + Mr * Hd * ((1 if codes else 4) + 2 + 4)),             # fc1 storing pass: codes (or fp16 pair) + uint16 code + bf16 pair
+            8: dep * (Mr * Dm + Hd * Dm + Mr * Hd * (1 if codes else 4) + (Mr * Hd // 8 if bits else Mr * Hd * 2) + (0 if fc2w else Mr * Hd * 4)),   # fc1 storing pass: codes (or fp16 pair) + mask bits (or uint16 code) [+ bf16 pair]
             9: dep * (Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 9 // 8),                            # qkv code pass: 1 B + 1 bit per element out
             3: (Mpe * Dm * 4 + Mpe * Kpe * 2 + Dm * Kpe * 4)
                + dep * ((Mr * 3 * Dm * 4 + Mr * Dm * 2 + 3 * Dm * Dm * 4) + (Mr * Hd * 4 + Mr * Dm * 2 + Hd * Dm * 4)),   # qkv, fc1 wgrad
-            6: dep * ((Mr * Dm * 4 + Mr * Dm * 4 + Dm * Dm * 4) + (Mr * Dm * 4 + Mr * Hd * 4 + Hd * Dm * 4)),             # proj, fc2 wgrad
+            6: dep * ((Mr * Dm * 4 + Mr * Dm * 4 + Dm * Dm * 4) + (Mr * Dm * 4 + Mr * Hd * (1 if fc2w else 4) + Hd * Dm * 4)),   # proj, fc2 wgrad (Q as codes)
         }
         gemms = {}
         for kind, (ms, cnt, fl) in prof.items():
