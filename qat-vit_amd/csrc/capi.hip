@@ -152,6 +152,19 @@ int qatvit_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, con
     return 0;
 }
 
+int qatvit_gemm_tn_i8q(const void* P_hi, const void* P_lo, const void* Qi8, const float* q_qp, int32_t center, float* C, int32_t M, int32_t N, int32_t Kw,
+                       int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp,
+                       int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes,
+                       void* stream) {
+    QV_CHECK_ARG(P_hi && P_lo && Qi8 && q_qp && C, "qatvit_gemm_tn_i8q: null pointer argument");
+    QV_CHECK_ARG(!W || (w_scale && w_zp), "qatvit_gemm_tn_i8q: weight mask needs w_scale and w_zp");
+    if (launch_gemm_tn_i8q(P_hi, P_lo, Qi8, q_qp, center, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div,
+                           (hipStream_t)stream, scratch, scratch_bytes))
+        return 1;
+    QV_CHECK_LAUNCH("qatvit_gemm_tn_i8q");
+    return 0;
+}
+
 int64_t qatvit_gemm_tn_scratch_bytes(void) { return kTnScratchBytes; }
 
 int32_t qatvit_attn_padded_tokens(int32_t T) { return attn_padded_tokens(T); }

@@ -241,6 +241,14 @@ static bool fc2w_codes() {
     return on != 0;
 }
 
+// QATVIT_TNW_I8=1: the weight gradients with a grid X operand (qkv, fc1, patch embedding) read X as the int8 plane q - center the forward GEMM read,
+// widened inside the kernel (launch_gemm_tn_i8q: half the bytes of the operand every N tile re-reads; the same bits), instead of the bf16 integers
+// q - zp.  Default 0: measured 140 vs 118 us per launch - the widening and the second barrier cost more than the 24 KB of LDS-DMA per step they save
+static bool tnw_i8() {
+    static const int on = getenv("QATVIT_TNW_I8") ? atoi(getenv("QATVIT_TNW_I8")) : 0;
+    return on != 0;
+}
+
 // QATVIT_WBATCH=0: one launch triple per weight instead of three multi-tensor launches (tuning; also the path of models deeper than the
 // tables hold).  That path does not write the fp16 weight copies, so the fp16-pair forward GEMMs are off with it.
 static bool w_batched(const Dims& d) {
@@ -413,11 +421,15 @@ struct Ctx {
                                     c.w_qmax, db, c.w_per_channel ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
     }
     // wgrad: dW[N,K] += sum_m dY[m,N] X[m,K] * s_x, masked by the weight FQ; db[N] += sum_m dY
+    // (X8: the grid operand once more as int8 q - center, with s_x = the qparams of its quantizer: read instead of X_hi when the tile allows it)
     int linear_wgrad(const void* dY_hi, const void* dY_lo, int M, int wi, const void* X_hi, const void* X_lo, const float* s_x, float* dW, float* db,
-                     bool dy_scaled = true) const {
+                     bool dy_scaled = true, const void* X8 = nullptr) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
         ProfScope ps(prof, X_lo ? 6 : 3, 2.0 * M * N * K, st);   // grid X (qkv / fc1 / patch-embed wgrad) | split X (proj / fc2 wgrad)
+        if (X8 && !X_lo && s_x && tnw_i8() && use_i8() && N % 128 == 0 && K % 384 == 0)
+            return launch_gemm_tn_i8q(dY_hi, dY_lo, X8, s_x, center(), dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
+                                      c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
         return launch_gemm_tn(dY_hi, dY_lo, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
                               c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
     }
@@ -708,7 +720,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 if (x.linear_dgrad(dYh, dYl, M, w_fc2, nullptr, &post)) return 1;
             }
             if (x.linear_wgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.blk<void>(p.h2q, i), nullptr, x.act_qp(x.aidx(i, AB_N2)),
-                               BG(i, B_FC1W), BG(i, B_FC1B)))
+                               BG(i, B_FC1W), BG(i, B_FC1B), true, x.blk<void>(p.h2q8, i)))
                 return 1;
             const LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dYh, dYl};
             const bool lnb = ln_fuse && lnb_fuse() && d.D == 384;   // the dgrad tile holds whole LayerNorm rows: its epilogue IS the LayerNorm backward
@@ -736,7 +748,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                                 attn_codes(c) ? x.blk<void>(p.qkvm, i) : nullptr))
                 return 1;
             if (x.linear_wgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.blk<void>(p.h1q, i), nullptr, x.act_qp(x.aidx(i, AB_N1)),
-                               BG(i, B_QKVW), BG(i, B_QKVB)))
+                               BG(i, B_QKVW), BG(i, B_QKVB), true, x.blk<void>(p.h1q8, i)))
                 return 1;
             const LnBwdNext nx_fc2{i > 0 ? x.blk<void>(p.m2, i - 1) : nullptr, i > 0 ? x.dy_colscale(x.widx(i - 1, WB_FC2)) : nullptr, dYh, dYl};
             if (lnb) {
@@ -759,7 +771,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                              d.T, d.D, st);
             // (no dgrad into the image, so dY0 is not pre-scaled by the per-channel weight scale)
             if (x.linear_wgrad(x.at<void>(p.dY0_hi), x.at<void>(p.dY0_lo), d.B * d.np, 0, x.at<void>(p.imgq), nullptr, x.act_qp(A_IN), G(P_PE_W),
-                               G(P_PE_B), false))
+                               G(P_PE_B), false, x.at<void>(p.imgq8)))
                 return 1;
         }
     }

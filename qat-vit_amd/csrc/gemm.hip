@@ -1768,6 +1768,11 @@ struct TNArgs {
     // QC form (fc2 weight gradient): the Q operand gelu(fq(fc1 output)) as ONE byte per element + a 256-entry table of bf16 (hi | lo << 16) pairs
     const uint8_t* Qc;    // [M, ldq] uint8 table indices (ldq in bytes)
     const uint32_t* lutQ;
+    // QI form (weight gradients with a grid X operand: qkv, fc1): Q as int8 [M, ldq] = q - center (the plane the int8 forward GEMM reads);
+    // the kernel widens it to the bf16 integer q - zp = int8 + q_off (q_off = center - zero_point, read from q_qp[2])
+    const int8_t* Qi;
+    const float* q_qp;    // {scale, 1/scale, zp, on} of X's quantizer
+    int q_center;
 };
 
 template <int ROWB>  // ROWB: bytes per LDS row of the image (256 for a 128-column tile, 768 for a 384-column tile)
@@ -1791,7 +1796,9 @@ __device__ inline bf16x8 tr_frag(const char* img, int row0, int col0, int lane) 
 // kernels) and is expanded through a 256-entry table of bf16 (hi, lo) pairs INSIDE the workgroup: codes of tile s+1 land in a staging buffer by
 // LDS-DMA during step s-1, every thread expands 24 of them between the MFMA groups of step s (8-B code read, eight table gathers, two 16-B writes
 // into the hi / lo images in the layout the LDS-DMA of the plane form produces), the MFMAs of step s+1 read them: same fragments, same bits.
-template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK, bool SPREAD = false, bool QC = false>
+// QI: the grid Q operand (bf16 integers q - zp) comes in as the int8 plane q - center the forward GEMM read (24 instead of 48 KB of LDS-DMA per
+// 64-token step) and is widened inside the workgroup - the QC scheme without table: one pair-free image, two staging buffers, arithmetic only.
+template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK, bool SPREAD = false, bool QC = false, bool QI = false>
 __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     constexpr int BN = 128, NW = WM * WNK;
     constexpr int TM = BN / WM / 16;                // 16-row fragments of P per wave
@@ -1867,7 +1874,91 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    if constexpr (QC) {
+    static_assert(!QI || (TQ == 1 && NSTAGE == 2 && BK == 64 && BKW == 384 && NW == 8 && !SPREAD && !QC), "int8-Q form: the 128 x 384 tile, 64-token steps");
+    if constexpr (QI) {
+        // LDS map: [2 x (P hi, P lo)] 64 KB | [Q image] 48 KB | [2 x int8 staging] 48 KB = 160 KB
+        constexpr int QI_PST = 2 * IMGP, QI_QIMG = 2 * QI_PST, QI_CB = QI_QIMG + IMGQ, QI_CBS = BK * BKW;
+        const v4i32 rQi = make_rsrc_v(p.Qi, (int64_t)p.M * p.ldq);
+        const float qsub = 8388736.0f - ((float)p.q_center - p.q_qp[2]);   // 2^23 + 128 - (center - zp)
+        auto issue_p = [&](int s) {
+            char* st = smem + (s & 1) * QI_PST;
+            const int mrow0 = (s_begin + s) * BK;
+#pragma unroll
+            for (int c = 0; c < PP; ++c) {
+                const int piece = wave * PP + c, row = piece * 4 + (lane >> 4);
+                const int src_chunk = (lane & 15) ^ tn_sw(row);
+                const uint32_t offP = (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + src_chunk * 8) * 2);
+                dma16_asm(rP0, st + piece * 1024, offP);
+                dma16_asm(rP1, st + IMGP + piece * 1024, offP);
+            }
+        };
+        auto issue_c = [&](int s) {      // 24 KiB of int8 = 24 pieces: three per wave, linear [64 tokens][384]
+            char* cb = smem + QI_CB + (s & 1) * QI_CBS;
+            const int mrow0 = (s_begin + s) * BK;
+#pragma unroll
+            for (int c = 0; c < QI_CBS / 1024 / NW; ++c) {
+                const int piece = wave + NW * c, L = piece * 64 + lane, row = L / (BKW / 16), cp = L % (BKW / 16);
+                dma16_asm(rQi, cb + piece * 1024, (uint32_t)((int64_t)(mrow0 + row) * p.ldq + k0 + cp * 16));
+            }
+        };
+        // 8 int8 (chunk c8: token c8 / 48, columns 8 (c8 % 48) ..) -> one 16-B chunk of bf16 integers in the image (exact: |q - zp| <= 255)
+        auto widen = [&](int s, int i) {
+            const char* cb = smem + QI_CB + (s & 1) * QI_CBS;
+            char* qi = smem + QI_QIMG;
+            const int c8 = tid + NW * 64 * i, row = c8 / (BKW / 8), col8 = c8 % (BKW / 8);
+            const uint2 cd = *reinterpret_cast<const uint2*>(cb + row * BKW + col8 * 8);
+            const uint32_t x[2] = {cd.x ^ 0x80808080u, cd.y ^ 0x80808080u};
+            bf16x8 f;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    f[4 * d + e] = (__bf16)(__builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, x[d], 0x07040400u + (uint32_t)e)) - qsub);
+            *reinterpret_cast<bf16x8*>(qi + row * QROWB + ((col8 ^ tn_sw(row)) << 4)) = f;
+        };
+        constexpr int NEXP = BK * BKW / 8 / (NW * 64);   // 6
+        constexpr int NGRP = (BK / 32) * TM;             // 8 MFMA groups per step
+        static_assert(NEXP <= NGRP, "one widening round per MFMA group");
+        if (nsteps > 0) { issue_p(0); issue_c(0); }
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (nsteps > 0) {
+#pragma unroll
+            for (int i = 0; i < NEXP; ++i) widen(0, i);
+        }
+        if (nsteps > 1) issue_c(1);
+        for (int s = 0; s < nsteps; ++s) {
+            wait_vmcnt<0>();                             // this wave's pieces of P(s) and of the int8 tile s+1
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // A: ... and its share of the image of tile s; everyone left step s-1
+            if (s + 1 < nsteps) issue_p(s + 1);
+            if (s + 2 < nsteps) issue_c(s + 2);
+            const char* st = smem + (s & 1) * QI_PST;
+            const char* sq = smem + QI_QIMG;
+            bf16x8 qf[BK / 32][TNT];
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) qf[kk][j] = tr_frag<QROWB>(sq, 32 * kk, wn * (16 * TNT) + 16 * j, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B: every wave holds its Q fragments: the image is free
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (s + 1 < nsteps && kk * TM + i < NEXP) widen(s + 1, kk * TM + i);
+                    const bf16x8 ph = tr_frag<PROWB>(st, 32 * kk, wm * (16 * TM) + 16 * i, lane);
+                    const bf16x8 pl = tr_frag<PROWB>(st + IMGP, 32 * kk, wm * (16 * TM) + 16 * i, lane);
+                    if (do_bias) {
+                        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ones, accb[i], 0, 0, 0);
+                        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, ones, accb[i], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TNT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[kk][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, qf[kk][j], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    } else if constexpr (QC) {
         uint32_t* sLutQ = reinterpret_cast<uint32_t*>(smem + QC_LUT);
         if (tid < 256) sLutQ[tid] = p.lutQ[tid];
         const v4i32 rQc = make_rsrc_v(p.Qc, (int64_t)p.M * p.ldq);
@@ -2237,6 +2328,40 @@ int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, con
     static bool once = (allow_lds(k_gemm_tn<2, 2, 2, 4, 6, 32, false, true>, lds), true);
     (void)once;
     k_gemm_tn<2, 2, 2, 4, 6, 32, false, true><<<grid, 512, lds, st>>>(a);
+    if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, 2, 4, tm, 6);
+    return 0;
+}
+
+// Weight gradient with a grid Q operand given as the int8 plane q - center (what the int8 forward GEMM read) instead of the bf16 integers q - zp:
+// the 128 x 384 tile / 64-token steps of launch_gemm_tn's grid-Q form, the same MFMAs in the same order - bit-identical to it.
+int launch_gemm_tn_i8q(const void* P_hi, const void* P_lo, const void* Qi8, const float* q_qp, int center, float* C, int M, int N, int Kw, int ldp, int ldq,
+                       int ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
+                       float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
+    if (M < 1 || N % 128 != 0 || Kw % 384 != 0 || ldp % 8 != 0 || ldq % 16 != 0 || !P_hi || !P_lo || !Qi8 || !q_qp || !C) {
+        set_error("gemm_tn_i8q: unsupported arguments M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%384==0, ldp%%8==0, ldq%%16==0)", M, N, Kw, ldp, ldq);
+        return 1;
+    }
+    TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), nullptr, nullptr, C, M, N, Kw, ldp, ldq, ldc, 0, 0, s1, W, w_scale, w_zp,
+             w_per_channel, w_qmin, w_qmax, dbias, 0, row_div, nullptr, nullptr, nullptr, reinterpret_cast<const int8_t*>(Qi8), q_qp, center};
+    constexpr int bk = 64;
+    const int steps = (M + bk - 1) / bk;
+    const int tiles = (N / 128) * (Kw / 384);
+    int splits = 256 / tiles;
+    const int min_steps = 256 / bk;
+    if (splits > steps / min_steps) splits = steps / min_steps > 0 ? steps / min_steps : 1;
+    if (splits < 1) splits = 1;
+    a.steps_per_split = (steps + splits - 1) / splits;
+    splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
+    a.tiles = tiles;
+    const int grid = tiles * splits;
+    constexpr size_t lds = 2 * (2 * 64 * 256) + 64 * 768 + 2 * (64 * 384);   // 160 KiB
+    constexpr int tm = 4;
+    const int64_t tile_f4 = (int64_t)2 * 4 * tm * 6 * 64;
+    const bool two_phase = partial && splits > 1 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;
+    a.partial = two_phase ? partial : nullptr;
+    static bool once = (allow_lds(k_gemm_tn<1, 2, 2, 4, 6, 64, false, false, true>, lds), true);
+    (void)once;
+    k_gemm_tn<1, 2, 2, 4, 6, 64, false, false, true><<<grid, 512, lds, st>>>(a);
     if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, 2, 4, tm, 6);
     return 0;
 }

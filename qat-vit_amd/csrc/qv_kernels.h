@@ -119,6 +119,10 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
 int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                          const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
                          const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
+// grid Q operand as the int8 plane q - center [M, ldq bytes] (+ its quantizer's qparams and the centre), widened inside the kernel (qkv / fc1 weight gradient)
+int launch_gemm_tn_i8q(const void* P_hi, const void* P_lo, const void* Qi8, const float* q_qp, int center, float* C, int M, int N, int Kw, int ldp, int ldq,
+                       int ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
+                       float* dbias, const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st,
                        void* out8 = nullptr, int center = 0);
