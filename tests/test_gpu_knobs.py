@@ -1,0 +1,80 @@
+"""Every QATVIT_* A/B knob of the engine still runs, and the forms documented as "the same bits" are the same bits: one training step of a ViT-S-width
+depth-2 student per knob, each in its own process (the knobs are read once per process), against the default configuration."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# knob -> how its step relates to the default one: "bits" = every output bit-identical (gradients that go through fp32 atomics - biases, LayerNorm
+# affine parameters, cls / pos - are compared to 1e-5 instead), float tolerance otherwise
+KNOBS = {
+    "QATVIT_FC2_CODES=0": "bits",          # fc2 forward from the fp16 planes instead of codes + table
+    "QATVIT_FC1_BITS=0": "bits",           # uint16 code plane instead of byte plane + mask bits
+    "QATVIT_FC2W_CODES=0": "bits",         # fc2 weight gradient from the bf16 planes
+    "QATVIT_QKV_2PASS=0": "bits",          # qkv GEMM once, fp32 output, attention quantises on load
+    "QATVIT_I8_STATS_STRIP=0": "bits",     # general tiled kernel for the statistics passes
+    "QATVIT_TNW_I8=1": "bits",             # qkv / fc1 weight gradients with X as int8 widened in the kernel
+    "QATVIT_QP_TAIL=1": "bits",            # k_qparams in the tail of its producer
+    "QATVIT_I8=0": "bits",                 # grid x grid GEMMs on bf16 MFMA
+    "QATVIT_NT_BREG=1": "bits",            # B operand through registers
+    "QATVIT_ATTN_CODES=0": "bits",         # attention backward re-quantises the fp32 qkv (implies the one-pass qkv GEMM)
+    "QATVIT_LNB_FUSE=0": 2e-5,             # LayerNorm backward as its own kernel (another summation order for dgamma / dbeta)
+    "QATVIT_FC1_RECOMPUTE=0": 2e-3,        # fc1 once, fp32 output, separate fq + GELU pass; fc2 forward then on the bf16 pair (as with QATVIT_F16=0)
+    "QATVIT_F16=0": 2e-3,                  # bf16 pairs for the forward float operands (2^-17 instead of 2^-23: one-step flips possible)
+}
+ATOMIC = ("bias", "norm", "cls_token", "pos_embed")
+
+
+def run(tmp_path, tag, env_kv, backend):
+    out = tmp_path / f"{tag}.pt"
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("QATVIT_"):
+            del env[k]
+    if env_kv:
+        k, v = env_kv.split("=")
+        env[k] = v
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "knob_worker.py"), str(out), backend], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (env_kv, r.stderr[-1500:])
+    return torch.load(out, weights_only=False)
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("backend", ["qnnpack", "x86"])
+def test_knob_forms_match_the_default(native_lib, tmp_path, backend):
+    ref = run(tmp_path, "default", None, backend)
+    again = run(tmp_path, "default2", None, backend)
+    assert torch.equal(ref["logits"], again["logits"])                      # the step itself is reproducible across processes
+    bad = []
+    for kv, how in KNOBS.items():
+        got = run(tmp_path, kv.replace("=", "_"), kv, backend)
+        if how == "bits":
+            if not torch.equal(got["logits"], ref["logits"]) or not torch.equal(got["loss"], ref["loss"]):
+                bad.append((kv, "logits / loss differ", rel(got["logits"], ref["logits"])))
+            for n, (s, z, mn, mx) in ref["fq"].items():
+                gs, gz, gmn, gmx = got["fq"][n]
+                if not (torch.equal(s, gs) and torch.equal(z, gz) and torch.equal(mn, gmn) and torch.equal(mx, gmx)):
+                    bad.append((kv, "fake-quant state differs", n))
+                    break
+            for n, g in ref["grads"].items():
+                if any(t in n for t in ATOMIC):
+                    if rel(got["grads"][n], g) > 1e-5:
+                        bad.append((kv, "gradient (atomics) differs", n, rel(got["grads"][n], g)))
+                elif not torch.equal(got["grads"][n], g):
+                    bad.append((kv, "gradient differs", n, rel(got["grads"][n], g)))
+        else:
+            if rel(got["logits"], ref["logits"]) > how * 50:
+                bad.append((kv, "logits", rel(got["logits"], ref["logits"])))
+            worst = max(rel(got["grads"][n], g) for n, g in ref["grads"].items())
+            if worst > how * 50:
+                bad.append((kv, "gradients", worst))
+    assert not bad, bad
