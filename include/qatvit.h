@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QATVIT_ABI_VERSION 2
+#define QATVIT_ABI_VERSION 3
 
 int qatvit_abi_version(void);
 const char* qatvit_last_error(void);
@@ -108,13 +108,33 @@ int qatvit_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
                        int32_t ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, void* stream);
 
-/* The statistics-only first pass of a two-pass GEMM (qkv, fc1): the product of qatvit_gemm_nt_i8 is formed for its minimum / maximum only, which
- * go into stats[0] / stats[1] as order-preserving uint32 (atomicMin / atomicMax on the caller-initialised pair {0xff800000, 0x007fffff}).  strip != 0:
- * the A-stationary kernel (K == 384; N % 1152 == 0 or N % 1536 == 0: one workgroup per 208-row strip keeps its A rows in LDS and streams the weight);
- * strip == 0: the general tiled kernel.  Both return the same bits. */
+/* The statistics-only first pass of a two-pass GEMM (qkv, fc1) on the general 208 x 384 tile: the product of qatvit_gemm_nt_i8 is formed for its
+ * minimum / maximum only, which go into stats[0] / stats[1] as order-preserving uint32 (atomicMin / atomicMax on the caller-initialised pair
+ * {0xff800000, 0x007fffff}).  N % 384 == 0, K % 64 == 0. */
 int qatvit_gemm_nt_i8_minmax(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N, int32_t K,
                              int32_t lda, int32_t ldb, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats,
-                             int32_t strip, void* stream);
+                             void* stream);
+
+/* int8 weight [N,K] row-major -> MFMA fragment order, the B operand of qatvit_i8_strip: 16-byte units indexed
+ * [n / 48][k / 64][(n % 48) / 16][lane = 16 * ((k % 64) / 16) + n % 16], byte k % 16 inside the unit, so that one wave reads each of its
+ * 16 x 64 weight fragments as 1 KiB of contiguous memory straight into registers.  N % 48 == 0, K % 64 == 0. */
+int qatvit_w8_fragment_order(const void* B8, void* B8f, int32_t N, int32_t K, void* stream);
+
+/* The K = 384 two-pass forward GEMMs of a block (attn.qkv, mlp.fc1: nnqat.Linear.forward, torch/ao/nn/qat/modules/linear.py:49-50, + the
+ * activation_post_process hook, torch/ao/quantization/quantize.py:150-152) on int8 MFMA, A-stationary: one workgroup keeps a 208-row strip of A8
+ * in LDS for all column tiles, each wave reads its weight fragments from B8f (qatvit_w8_fragment_order) into registers, the k-loop has no barrier.
+ * v[m,n] = (sum_k A8*B8 + (center - zero_point) * wsum[n]) * (*s1) * (*s2) * col_scale[n] + bias[n]  - the value qatvit_gemm_nt_i8 stores, bit for bit.
+ *   mode 3: min / max of v into stats (as qatvit_gemm_nt_i8_minmax); nothing is stored.
+ *   mode 7: out_qp = {scale, 1/scale, zero_point, enabled} of the OUTPUT's quantizer: out8 = clamp(rint(v / scale) + zero_point) - qmin as uint8 in the
+ *           attention layout [b][head][q|k|v][t][64] (N = 3 * embed_dim, embed_dim % 384 == 0, code_T tokens per image) and out8_mask = the STE
+ *           mask (qmin <= q <= qmax), one bit per element in the same order.
+ *   mode 4: out8 = the same code row-major [M,N], out8_mask [M,N/8]; lut_out / lutq_out [256] = packed fp16 / bf16 (hi | lo << 16) pairs of
+ *           2^k * gelu(grid value) / gelu(grid value), *out16_scale = 2^-k (the tables qatvit_gemm_nt_codes / qatvit_gemm_tn_codes expand the codes through).
+ * N % 1152 == 0 or N % 1536 == 0; K is 384 (not passed); lda % 16 == 0; M < 2^22. */
+int qatvit_i8_strip(int32_t mode, const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N,
+                    int32_t lda, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, const float* out_qp,
+                    int32_t qmin, int32_t qmax, void* out8, void* out8_mask, int32_t code_T, uint32_t* lut_out, uint32_t* lutq_out,
+                    float* out16_scale, void* stream);
 
 /* qatvit_gemm_nt_f16 for an A operand that takes at most 256 distinct values (mlp.fc2: A = gelu(fq(fc1 output))): A8 uint8 [M,lda] = table
  * index per element (lda in bytes), lut[256] = the fp16 (hi | lo << 16) pair per index.  The kernel expands the codes through the table on their

@@ -101,13 +101,37 @@ int qatvit_gemm_nt_f16(const void* A16_hi, const void* A16_lo, const void* B16, 
 
 int qatvit_gemm_nt_i8_minmax(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N, int32_t K,
                              int32_t lda, int32_t ldb, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats,
-                             int32_t strip, void* stream) {
+                             void* stream) {
     QV_CHECK_ARG(A8 && B8 && wsum && a_qp && stats, "qatvit_gemm_nt_i8_minmax: null pointer argument");
     NTPost post{};
     post.mode = 3;
-    post.stats_strip = strip ? 1 : 0;
     if (launch_gemm_nt_i8(A8, B8, wsum, a_qp, center, nullptr, M, N, K, lda, ldb, N, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream, &post)) return 1;
     QV_CHECK_LAUNCH("qatvit_gemm_nt_i8_minmax");
+    return 0;
+}
+
+int qatvit_w8_fragment_order(const void* B8, void* B8f, int32_t N, int32_t K, void* stream) {
+    if (launch_w8_fragment_order(B8, B8f, N, K, (hipStream_t)stream)) return 1;
+    QV_CHECK_LAUNCH("qatvit_w8_fragment_order");
+    return 0;
+}
+
+int qatvit_i8_strip(int32_t mode, const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N,
+                    int32_t lda, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, const float* out_qp,
+                    int32_t qmin, int32_t qmax, void* out8, void* out8_mask, int32_t code_T, uint32_t* lut_out, uint32_t* lutq_out,
+                    float* out16_scale, void* stream) {
+    QV_CHECK_ARG(A8 && B8f && wsum && a_qp && s1, "qatvit_i8_strip: null pointer argument");
+    QV_CHECK_ARG(mode == 3 || mode == 4 || mode == 7, "qatvit_i8_strip: mode %d (3 = statistics, 7 = qkv codes, 4 = fc1 codes)", mode);
+    NTPost post{};
+    post.mode = mode;
+    post.qp = out_qp; post.qmin = qmin; post.qmax = qmax; post.out8 = out8; post.out8_mask = out8_mask; post.code_T = code_T; post.code_hd = 64;
+    post.lut_out = lut_out; post.lutq_out = lutq_out; post.out16_scale = out16_scale;
+    if (!launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, 384, lda, N, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream, &post, nullptr, true)) {
+        set_error("qatvit_i8_strip: unsupported arguments (mode %d M=%d N=%d lda=%d: need N %% 1152 == 0 or N %% 1536 == 0, lda %% 16 == 0, M < 2^22, "
+                  "the mode's output pointers, qmax - qmin < 256; mode 7: (N / 3) %% 384 == 0, 0 < code_T < 1024)", mode, M, N, lda);
+        return 1;
+    }
+    QV_CHECK_LAUNCH("qatvit_i8_strip");
     return 0;
 }
 

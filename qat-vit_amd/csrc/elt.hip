@@ -630,7 +630,8 @@ __global__ __launch_bounds__(64) void k_embed_bwd(const float* __restrict__ dx0,
 // wq[n][k] = q(W[n][k]) - zp (bf16), wqT[k][n] = same, transposed (dgrad's B operand)
 __device__ inline void wquant_body(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
                                    __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K, int bx, int by,
-                                   int8_t* __restrict__ w8 = nullptr, int32_t* __restrict__ wsum = nullptr, _Float16* __restrict__ w16 = nullptr) {
+                                   int8_t* __restrict__ w8 = nullptr, int32_t* __restrict__ wsum = nullptr, _Float16* __restrict__ w16 = nullptr,
+                                   int8_t* __restrict__ w8f = nullptr) {
     // 32x32 tile transpose through LDS
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -645,6 +646,7 @@ __device__ inline void wquant_body(const float* __restrict__ W, const float* __r
             wq[(int64_t)n * K + k] = (__bf16)v;
             if (w8) w8[(int64_t)n * K + k] = (int8_t)v;   // the same integer for the int8-MFMA forward GEMMs
             if (w16) w16[(int64_t)n * K + k] = (_Float16)v;   // ... and for the fp16-pair forward GEMMs (|v| <= 128: exact)
+            if (w8f) w8f[w8f_offset(n, k, K)] = (int8_t)v;    // ... and in MFMA-fragment order for the strip kernel (i8strip.hip)
         }
         tile[ty + 8 * i][tx] = v;
     }
@@ -672,7 +674,20 @@ __global__ __launch_bounds__(256) void k_w_quant_all(const WQuantTab t) {
     while (wi + 1 < t.n && (int)blockIdx.x >= t.blk0[wi + 1]) ++wi;
     const int b = blockIdx.x - t.blk0[wi], kt = (t.K[wi] + 31) / 32;
     wquant_body(t.W[wi], t.qp[wi], t.per_channel, t.qmin, t.qmax, reinterpret_cast<__bf16*>(t.wq[wi]), reinterpret_cast<__bf16*>(t.wqT[wi]), t.N[wi],
-                t.K[wi], b % kt, b / kt, reinterpret_cast<int8_t*>(t.w8[wi]), t.wsum[wi], reinterpret_cast<_Float16*>(t.w16[wi]));
+                t.K[wi], b % kt, b / kt, reinterpret_cast<int8_t*>(t.w8[wi]), t.wsum[wi], reinterpret_cast<_Float16*>(t.w16[wi]),
+                reinterpret_cast<int8_t*>(t.w8f[wi]));
+}
+static_assert(sizeof(WQuantTab) <= 4096, "WQuantTab travels as a kernel argument");
+// row-major int8 [N, K] -> fragment order (kernel-level tests / callers that hold a row-major weight)
+__global__ __launch_bounds__(256) void k_w8_fragment_order(const int8_t* __restrict__ B8, int8_t* __restrict__ B8f, int N, int K) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    B8f[w8f_offset((int)(i / K), (int)(i % K), K)] = B8[i];
+}
+int launch_w8_fragment_order(const void* B8, void* B8f, int N, int K, hipStream_t st) {
+    if (N < 48 || N % 48 != 0 || K % 64 != 0 || !B8 || !B8f) { set_error("w8_fragment_order: need N %% 48 == 0, K %% 64 == 0 (N=%d K=%d)", N, K); return 1; }
+    k_w8_fragment_order<<<cdiv((int64_t)N * K, 256), 256, 0, st>>>(reinterpret_cast<const int8_t*>(B8), reinterpret_cast<int8_t*>(B8f), N, K);
+    return 0;
 }
 
 // ============================================================================ launchers

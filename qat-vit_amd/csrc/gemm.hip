@@ -1242,146 +1242,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_ac(const NTArgs p) {
 }
 
 
-// ============================================================================ statistics-only pass of a K = 384 int8 GEMM, A-stationary
-// The first passes of the two-pass GEMMs (qkv, fc1) compute their product only for its min / max.  The general tall kernel pays, per 208 x 384
-// output tile, a prologue round trip plus 227 KB through LDS-DMA (A tile 80 KB + W tile 147 KB) for 3 us of int8 MFMA - and re-fetches the same A
-// rows for each of the 3-4 column tiles.  Here ONE workgroup owns a 208-row strip: its whole A strip (208 x 384 B = 78 KB, six k-tiles) stays in LDS,
-// the weight streams through a 3-stage ring as one continuous sequence of (column tile, k-tile) steps - no drain between column tiles - and min / max
-// accumulate in registers across the strip: one reduction and one atomic pair per workgroup.  243 workgroups = one round.  Same MFMAs in the same order
-// per accumulator and the same epilogue arithmetic as k_gemm_nt<.., PM = 3, I8>: the statistics (hence the qparams) are bit-identical.
-struct I8StatArgs {
-    const int8_t* A;      // [M, lda] q - center
-    const int8_t* B;      // [N, ldb] weight integers
-    int M, N, lda, ldb;   // K == 384
-    const float* s1;
-    const float* s2;
-    const float* col_scale;
-    const float* bias;
-    const int32_t* wsum;
-    const float* aqp;
-    int center;
-    uint32_t* stats;
-    int stat_slots;
-    QpTail tail;
-};
-
-template <int NTL>   // column tiles (of 384) per workgroup: N == gridDim.y * NTL * 384
-__global__ __launch_bounds__(512, 2) void k_gemm_i8_stats(const I8StatArgs p) {
-    constexpr int TM = 13, TNT = 3, BM = 208, BN = 384, KT = 6, NSTG = 3;
-    constexpr int IMGA = BM * 64, IMGB = BN * 64, LA = KT * IMGA;
-    constexpr int G = NTL * KT;                         // stream length
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;
-    char* sBr = smem + LA;
-    float* sRed = reinterpret_cast<float*>(smem + LA + NSTG * IMGB);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * BM, nbase = blockIdx.y * NTL * BN;
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)p.M * p.lda);
-    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, (int64_t)p.N * p.ldb);
-    const int lR = lane >> 3, lL = (lane & 7) ^ lR;
-    const int prow = 2 * lR + (lL >> 2), pk = lL & 3;
-    const int nA = wave < 5 ? 2 : 1;                    // this wave's A pieces per k-tile (13 pieces over 8 waves)
-    auto issue_a = [&](int kt, int c) {
-        const int q = c * 8 + wave;
-        if (q >= TM) return;
-        const uint32_t off = (uint32_t)((int64_t)(m0 + q * 16 + prow) * p.lda + kt * 64 + pk * 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(sA + kt * IMGA + q * 1024), 16, off, 0, 0, 0);
-    };
-    auto issue_b = [&](int gpos, int c) {
-        const int nt = gpos / KT, kt = gpos % KT, q = c * 8 + wave;
-        const uint32_t off = (uint32_t)((int64_t)(nbase + nt * BN + q * 16 + prow) * p.ldb + kt * 64 + pk * 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(sBr + (gpos % NSTG) * IMGB + q * 1024), 16, off, 0, 0, 0);
-    };
-    // stream position g: A k-tile g (first column tile only) and B tile g, in that order
-    auto issue_pos = [&](int gpos) {
-        if (gpos < KT) { issue_a(gpos, 0); issue_a(gpos, 1); }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) issue_b(gpos, c);
-    };
-    // per-column constants of every column tile of the strip, in registers (ordinary loads inside the streaming loop would drain the DMA queue)
-    const float alpha = *(p.s1 ? p.s1 : kOnes.v) * *(p.s2 ? p.s2 : kOnes.v);
-    const int zc = p.center - (int)p.aqp[2];
-    int corr[NTL][TNT];
-    float ca[NTL][TNT], cb[NTL][TNT];
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt)
-#pragma unroll
-        for (int j = 0; j < TNT; ++j) {
-            const int col = nbase + nt * BN + wave * 48 + 16 * j + r;
-            corr[nt][j] = zc * p.wsum[col];
-            ca[nt][j] = alpha * (p.col_scale ? p.col_scale[col] : 1.0f);
-            cb[nt][j] = p.bias ? p.bias[col] : 0.0f;
-        }
-    issue_pos(0);
-    issue_pos(1);
-
-    i32x4 acc[TM][TNT];
-    float mn = INFINITY, mx = -INFINITY;
-    auto step = [&](int gpos) {
-        // position gpos has landed once at most position gpos + 1's pieces (this wave's share) are outstanding
-        if (gpos + 1 >= G) wait_vmcnt<0>();
-        else if (gpos + 1 >= KT) wait_vmcnt<3>();
-        else if (nA == 2) wait_vmcnt<5>();
-        else wait_vmcnt<4>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const bool more = gpos + 2 < G;
-        const int kt = gpos % KT;
-        const char* st = sA + kt * IMGA;
-        const char* sB = sBr + (gpos % NSTG) * IMGB;
-        bf16x8 bfrag[TNT];
-#pragma unroll
-        for (int j = 0; j < TNT; ++j) bfrag[j] = *reinterpret_cast<const bf16x8*>(sB + nt_off32(wave * 48 + 16 * j + r, g));
-        constexpr int PF = 3;
-        bf16x8 af[PF];
-#pragma unroll
-        for (int i = 0; i < PF - 1; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + nt_off32(16 * i + r, g));
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (more) {   // next-but-one position's pieces between the MFMA groups (the A pieces, if any, first)
-                if (i == 0 && gpos + 2 < KT) { issue_a(gpos + 2, 0); issue_a(gpos + 2, 1); }
-                if (i == 2) issue_b(gpos + 2, 0);
-                if (i == 6) issue_b(gpos + 2, 1);
-                if (i == 10) issue_b(gpos + 2, 2);
-            }
-            if (i + PF - 1 < TM) af[(i + PF - 1) % PF] = *reinterpret_cast<const bf16x8*>(st + nt_off32(16 * (i + PF - 1) + r, g));
-#pragma unroll
-            for (int j = 0; j < TNT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[i % PF]), __builtin_bit_cast(i32x4, bfrag[j]), acc[i][j], 0, 0, 0);
-        }
-    };
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TNT; ++j) acc[i][j] = i32x4{};
-#pragma clang loop unroll(disable)
-        for (int kt = 0; kt < KT; ++kt) step(nt * KT + kt);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TNT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = (float)(acc[i][j][e] + corr[nt][j]) * ca[nt][j] + cb[nt][j];
-                    if (m0 + 16 * i + 4 * g + e < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
-                }
-    }
-    mn = wave_min(mn);
-    mx = wave_max(mx);
-    if (lane == 0) { sRed[wave] = mn; sRed[8 + wave] = mx; }
-    lds_barrier();
-    if (tid == 0) {
-#pragma unroll
-        for (int w = 1; w < 8; ++w) { mn = fminf(mn, sRed[w]); mx = fmaxf(mx, sRed[8 + w]); }
-    }
-    if (p.tail.counter) qparams_tail(p.tail, p.stats, p.stat_slots, gridDim.x * gridDim.y, reinterpret_cast<uint32_t*>(sRed) + 32, mn, mx);
-    else if (tid == 0) stat_atomic(p.stats, p.stat_slots, mn, mx);
-}
-
 template <typename K>
 static void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1676,7 +1536,7 @@ int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, f
 // bit for bit (both accumulate the same integers exactly).  Tall 208 x 384 tiles only: N % 384 == 0, K % 64 == 0.
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
-                      hipStream_t st, const NTPost* post, const QpTail* tail) {
+                      hipStream_t st, const NTPost* post, const QpTail* tail, const void* B8f) {
     if (M < 1 || N % 384 != 0 || K % 64 != 0 || lda % 16 != 0 || ldb % 16 != 0 || ldc % 4 != 0 || !wsum || !a_qp) {
         set_error("gemm_nt_i8: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d (need N%%384==0, K%%64==0, ld%%16==0)", M, N, K, lda, ldb);
         return 1;
@@ -1708,25 +1568,9 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
         set_error("gemm_nt_i8: null output");
         return 1;
     }
-    // statistics-only pass with K == 384: the A-stationary strip kernel (QATVIT_I8_STATS_STRIP=0: the general tall kernel)
-    static const int strip = getenv("QATVIT_I8_STATS_STRIP") ? atoi(getenv("QATVIT_I8_STATS_STRIP")) : 1;
-    const bool strip_ok = post && post->mode == 3 && K == 384 && stats && (N % (4 * 384) == 0 || N % (3 * 384) == 0);
-    if (post && post->mode == 3 && post->stats_strip == 1 && !strip_ok) { set_error("gemm_nt_i8: the strip statistics kernel needs K == 384, N %% 1152 == 0 or N %% 1536 == 0"); return 1; }
-    if (strip_ok && (post->stats_strip == 1 || (post->stats_strip < 0 && strip))) {
-        I8StatArgs sa{reinterpret_cast<const int8_t*>(A8), reinterpret_cast<const int8_t*>(B8), M, N, lda, ldb, s1, s2, col_scale, bias, wsum, a_qp, center,
-                      stats, stat_slots < 1 ? 1 : stat_slots, (tail && stats) ? *tail : QpTail{}};
-        constexpr int kLds = 6 * 208 * 64 + 3 * 384 * 64 + 512;
-        if (N % (4 * 384) == 0) {
-            static bool once4 = (allow_lds(k_gemm_i8_stats<4>, (size_t)kLds), true);
-            (void)once4;
-            k_gemm_i8_stats<4><<<dim3(cdiv(M, 208), N / (4 * 384)), 512, kLds, st>>>(sa);
-        } else {
-            static bool once3 = (allow_lds(k_gemm_i8_stats<3>, (size_t)kLds), true);
-            (void)once3;
-            k_gemm_i8_stats<3><<<dim3(cdiv(M, 208), N / (3 * 384)), 512, kLds, st>>>(sa);
-        }
-        return 0;
-    }
+    // the K = 384 two-pass GEMMs (qkv, fc1: statistics pass, code passes) on the A-stationary strip kernel (i8strip.hip) when the weight came in
+    // fragment order too; everything else (plain fp32 output, K != 384, the inference epilogues) on the general tall tile below
+    if (post && launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, K, lda, ldc, s1, s2, col_scale, bias, stats, stat_slots, st, post, tail)) return 0;
     static const int i8_4w = getenv("QATVIT_NT_I8_4W") ? atoi(getenv("QATVIT_NT_I8_4W")) : 0;   // 112 x 384 tiles, 4 waves, 2 stages (62 KiB): two workgroups per CU
     if (i8_4w) {
         static const int stagger = getenv("QATVIT_NT_STAGGER") ? atoi(getenv("QATVIT_NT_STAGGER")) : 0;

@@ -1,0 +1,373 @@
+// The two-pass K = 384 forward GEMMs of the student (fused qkv, mlp.fc1) on int8 MFMA, A-stationary, barrier-free k-loop (gfx950).
+//
+// Reference op: nnqat.Linear.forward -> F.linear(x, weight_fake_quant(W), b) followed by the activation_post_process hook
+// (torch/ao/nn/qat/modules/linear.py:49-50; torch/ao/quantization/quantize.py:150-152) for blocks.N.attn.qkv and blocks.N.mlp.fc1 of the
+// prepared QATWrapper(ViT) (/root/reference/src/models/model_registry.py:113-120 under /root/reference/src/training/qat_trainer.py:341).
+//
+// Both operands sit on fake-quant grids, so the product is an exact integer GEMM (v_mfma_i32_16x16x64_i8).  The output's observer needs the
+// min / max of the WHOLE output before anything can be quantised, so the product is evaluated twice on the same operands (the same bits):
+//   MODE 3   statistics only: min / max of  (acc + corr[n]) * ca[n] + cb[n]  -> the observer's accumulator (nothing stored)
+//   MODE 7   qkv:  uint8 codes clamp(q) - qmin + STE mask bits in the attention layout [b][h][q|k|v][t][d]
+//   MODE 4   fc1:  uint8 grid indices [M, ldc] + STE mask bits [M, ldc / 8] (+ the two 256-entry gelu tables fc2's forward / weight gradient expand them through)
+// Structure (one workgroup = 8 waves = one 208-row strip of A, M = B * 197 rows -> 243 strips = one round on 256 CUs):
+//   * the strip's int8 A rows (208 x 384 B = 78 KiB) are fetched ONCE by LDS-DMA and stay in LDS for all 3 - 4 column tiles of 384;
+//   * wave w owns columns 48 w .. 48 w + 47 of every column tile.  Its weight fragments belong to nobody else, so they never touch LDS: the
+//     weight prepared once per step in FRAGMENT ORDER (w8f: [48-column group][k-step][fragment][lane] x 16 B, written by k_w_quant_all) is
+//     read straight into registers, 1 KiB contiguous per wave-instruction, one k-step ahead;
+//   * hence the k-loop has NO barrier and NO LDS write: 13 A-fragment ds_read_b128 + 39 MFMAs per k-step per wave, waves run freely;
+//   * MFMA operands are SWAPPED (weight fragment as A, activation fragment as B): an accumulator register then holds 4 CONSECUTIVE OUTPUT
+//     COLUMNS of one token, so the epilogue packs four codes into one dword (v_cvt_pk_u8_f32) and stages them with ONE ds_write_b32 -
+//     1 B per element through LDS instead of 4 - and the store loop is a pure 16-B copy into whole 64-B .. 384-B row runs;
+//   * statistics pass: min / max over the 13 row fragments in the INTEGER domain (the affine map to the stored value is monotone per
+//     column: ca > 0), the float map once per column - 2 instead of 12 VALU instructions per element, the same bits.
+// Every arithmetic step on an element is the one the general tall kernel (gemm.hip, k_gemm_nt<.., I8>) performs, in the same order:
+// tests/test_gpu_knobs.py compares the two (QATVIT_I8_STRIP=0) bit for bit.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "qv_common.h"
+#include "qv_kernels.h"
+#include "qv_qparams.h"
+
+namespace qv {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct I8StripArgs {
+    const int8_t* A;        // [M, lda] q - center
+    const i32x4* Bf;        // weight integers in fragment order (see above), N x 384 bytes
+    int M, N, lda;
+    const float* s1;        // alpha = (*s1) * (*s2)
+    const float* s2;
+    const float* col_scale; // optional [N]
+    const float* bias;      // optional [N]
+    const int32_t* wsum;    // [N] row sums of the weight integers
+    const float* aqp;       // qparams of the A operand's quantizer (zero point enters the correction)
+    int center;
+    // MODE 3
+    uint32_t* stats;
+    int stat_slots;
+    QpTail tail;
+    // MODE 7 / 4
+    const float* qp;        // {scale, 1 / scale, zp, on} of the OUTPUT's quantizer (fresh from the statistics pass)
+    int qmin, qmax;
+    uint8_t* out8;
+    uint8_t* out8_mask;
+    int ldc;                // MODE 4: row stride of out8
+    int code_T, D;          // MODE 7: tokens per image, embed dim (head_dim == 64)
+    uint32_t* lut_out;      // MODE 4 tables
+    uint32_t* lutq_out;
+    float* out16_scale;
+};
+
+// LDS image of one [208][64 B] k-tile of A: two 64-B tile rows share one 128-B LDS row; chunk ((row & 1) * 4 + k-chunk) XOR (LDS row & 7)
+__device__ inline int strip_off(int row, int chunk) {
+    const int R = row >> 1;
+    return R * 128 + (((((row & 1) << 2) | chunk) ^ (R & 7)) << 4);
+}
+__device__ inline void strip_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int MODE, int NTL>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384
+__global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
+    constexpr int TM = 13, TNT = 3, BM = 208, BN = 384, KT = 6;
+    constexpr int IMGA = BM * 64, LA = KT * IMGA;        // 79,872 B
+    constexpr int SROW = 400;                            // staged code row: 384 B + 16 B (bank spread of the packed ds_write_b32)
+    constexpr int H0 = 7;                                // row fragments of the first staging round (112 rows); the second takes 6 (96 rows)
+    constexpr int STG = 16 * H0 * SROW;                  // 44,800 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NC = NTL * BN;                         // columns of this workgroup
+    char* sA = smem;
+    int* sCorr = reinterpret_cast<int*>(smem + LA);      // per-column constants of the epilogue: corr | ca | cb, [NC] each
+    float* sCa = reinterpret_cast<float*>(sCorr + NC);
+    float* sCb = sCa + NC;
+    char* sStage = smem + LA + 3 * NC * 4;
+    char* sMask = sStage + STG;                          // [112][48 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * BM, nbase = blockIdx.y * NTL * BN;
+
+    // ---- A strip: 6 k-tiles x 13 pieces of 1 KiB, dealt to the 8 waves; the swizzle goes on the SOURCE address (the DMA destination is lane-linear)
+    {
+        const int64_t abytes = (int64_t)p.M * p.lda;   // wave-uniform raw-buffer descriptor: lanes past the end read zero
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.A), 0, abytes > 0xffffffffll ? 0xffffffffu : (uint32_t)abytes, 0x00020000);
+        const int lR = lane >> 3, lL = (lane & 7) ^ lR;
+        const int prow = 2 * lR + (lL >> 2), pk = lL & 3;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int q = c * 8 + wave;
+                if (q < TM) {
+                    const uint32_t off = (uint32_t)((int64_t)(m0 + q * 16 + prow) * p.lda + kt * 64 + pk * 16);   // rows past M read as zero
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(sA + kt * IMGA + q * 1024), 16, off, 0, 0, 0);
+                }
+            }
+    }
+    // this wave's weight fragments: group (nbase / 48 + 8 nt + wave), k-step kt, fragment j: 1 KiB each, lane * 16 B inside.  Buffer loads with the
+    // fragment's offset in an SGPR (one VGPR of address for all 18 fragments of a column tile: as 64-bit global addresses they were 36 registers)
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4*>(p.Bf), 0, (uint32_t)((int64_t)p.N * 384), 0x00020000);
+    const int bgrp = (nbase / 48 + wave) * (KT * TNT);   // (uniform) fragment index of (nt = 0, kt = 0, j = 0)
+    auto load_b = [&](int nt, int kt, i32x4 (&b)[TNT]) {
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rB, lane * 16, (bgrp + nt * 8 * (KT * TNT) + kt * TNT + j) * 1024, 0);
+            b[j] = __builtin_bit_cast(i32x4, v);
+        }
+    };
+    i32x4 b0[TNT], b1[TNT];
+    load_b(0, 0, b0);
+
+    // per-column constants v = (float)(acc + corr[n]) * ca[n] + cb[n], once per workgroup into LDS (published by the barrier below): in the swapped
+    // accumulator layout a lane needs 3 x 4 columns x 3 constants per column tile - as registers next to 156 accumulators they spill
+    {
+        const float alpha = *p.s1 * (p.s2 ? *p.s2 : 1.0f);
+        const int zc = p.center - (int)p.aqp[2];
+        for (int c = tid; c < NC; c += 512) {
+            sCorr[c] = zc * p.wsum[nbase + c];
+            sCa[c] = alpha * (p.col_scale ? p.col_scale[nbase + c] : 1.0f);
+            sCb[c] = p.bias ? p.bias[nbase + c] : 0.0f;
+        }
+    }
+    struct Consts { int4 corr; float4 ca, cb; };
+    auto consts_of = [&](int nt, int j, int g) {
+        const int c = nt * BN + wave * 48 + 16 * j + 4 * g;   // this lane's 4 columns of fragment j
+        return Consts{*reinterpret_cast<const int4*>(sCorr + c), *reinterpret_cast<const float4*>(sCa + c), *reinterpret_cast<const float4*>(sCb + c)};
+    };
+
+    if constexpr (MODE == 4) {   // the two 256-entry tables of gelu(grid value) and the fp16 pair's scale: data-independent, one workgroup writes them
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 256) {
+            const float ga = fabsf(((float)p.qmin - p.qp[2]) * p.qp[0]), gb = fabsf(((float)p.qmax - p.qp[2]) * p.qp[0]);
+            int ex;
+            (void)frexpf(fmaxf(ga, gb), &ex);
+            const float gs = ldexpf(1.0f, 14 - ex);
+            if (p.out16_scale && tid == 0) *p.out16_scale = ldexpf(1.0f, ex - 14);
+            uint32_t wq = 0u, wh = 0u;
+            if (tid <= p.qmax - p.qmin) {
+                const float gv = gelu_fwd(((float)(tid + p.qmin) - p.qp[2]) * p.qp[0]);
+                const __bf16 gh = (__bf16)gv;
+                const __bf16 gl = (__bf16)(gv - (float)gh);
+                wq = (uint32_t)__builtin_bit_cast(uint16_t, gh) | ((uint32_t)__builtin_bit_cast(uint16_t, gl) << 16);
+                const float g16 = gv * gs;
+                const _Float16 hh = (_Float16)g16;
+                const _Float16 hl = (_Float16)(g16 - (float)hh);
+                wh = (uint32_t)__builtin_bit_cast(uint16_t, hh) | ((uint32_t)__builtin_bit_cast(uint16_t, hl) << 16);
+            }
+            if (p.lut_out) p.lut_out[tid] = wh;
+            if (p.lutq_out) p.lutq_out[tid] = wq;
+        }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's A pieces have landed, its constants are written ...
+    __builtin_amdgcn_s_barrier();                        // ... and everybody else's
+    asm volatile("" ::: "memory");
+
+    float mn = INFINITY, mx = -INFINITY;                 // MODE 3
+    const bool ragged = m0 + BM > p.M;                   // (uniform) the last strip holds rows past M: they read as zero and must not be observed / stored
+
+    i32x4 acc[TM][TNT];
+#pragma clang loop unroll(disable)
+    for (int nt = 0; nt < NTL; ++nt) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+        // ---- k-loop: no barrier, no LDS write; weight fragments one k-step ahead in registers (the other buffer)
+        auto kstep = [&](int kt, const i32x4 (&bc)[TNT]) {
+            // (the strip is loop-invariant across column tiles: without this opaque zero in its address hipcc hoists all 78 fragment reads out of
+            //  the nt loop - 312 registers, spilled to scratch)
+            __builtin_amdgcn_sched_barrier(0);           // one scheduling region per k-step: merged regions rotate the accumulators through spare registers and spill
+            int opaque = 0;
+            asm volatile("" : "+v"(opaque));
+            const char* st = sA + opaque + kt * IMGA;
+            constexpr int PF = 3;
+            i32x4 af[PF];
+#pragma unroll
+            for (int i = 0; i < PF - 1; ++i) af[i] = *reinterpret_cast<const i32x4*>(st + strip_off(16 * i + r, g));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i + PF - 1 < TM) af[(i + PF - 1) % PF] = *reinterpret_cast<const i32x4*>(st + strip_off(16 * (i + PF - 1) + r, g));
+#pragma unroll
+                for (int j = 0; j < TNT; ++j)   // swapped roles: D[row = weight column 4 g + e][col = token r]
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bc[j], af[i % PF], acc[i][j], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int kt = 0; kt < KT; kt += 2) {
+            load_b(nt, kt + 1, b1);
+            kstep(kt, b0);
+            if (kt + 2 < KT) load_b(nt, kt + 2, b0);
+            else if (MODE == 3 && nt + 1 < NTL) load_b(nt + 1, 0, b0);   // (code passes: requested after the first staging round, when 84 accumulators are dead)
+            kstep(kt + 1, b1);
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 3) {
+            // integer min / max per column over this lane's 13 tokens, then the (monotone: ca > 0) float map once per column
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) {
+                int lo[4], hi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = 0x7fffffff;
+                    hi[e] = (int)0x80000000;
+                    if (!ragged) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) { lo[e] = min(lo[e], acc[i][j][e]); hi[e] = max(hi[e], acc[i][j][e]); }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const bool ok = m0 + 16 * i + r < p.M;
+                            lo[e] = min(lo[e], ok ? acc[i][j][e] : 0x7fffffff);
+                            hi[e] = max(hi[e], ok ? acc[i][j][e] : (int)0x80000000);
+                        }
+                    }
+                }
+                const Consts k = consts_of(nt, j, g);
+                const int kc[4] = {k.corr.x, k.corr.y, k.corr.z, k.corr.w};
+                const float ka[4] = {k.ca.x, k.ca.y, k.ca.z, k.ca.w}, kb[4] = {k.cb.x, k.cb.y, k.cb.z, k.cb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (lo[e] <= hi[e]) {   // (this lane's token column holds at least one valid row)
+                        mn = fminf(mn, (float)(lo[e] + kc[e]) * ka[e] + kb[e]);
+                        mx = fmaxf(mx, (float)(hi[e] + kc[e]) * ka[e] + kb[e]);
+                    }
+            }
+        } else {
+            const float qinv = p.qp[1], qzp = p.qp[2], fmin_ = (float)p.qmin, fmax_ = (float)p.qmax;
+            const int tilebase = nbase + nt * BN;
+            // two staging rounds per column tile (rows 0 .. 111, then 112 .. 207): quantise in registers, 4 codes -> 1 dword -> LDS, barrier,
+            // 16-B copies into the output layout
+            auto round = [&](auto I0c, auto I1c) {
+                constexpr int I0 = decltype(I0c)::value, I1 = decltype(I1c)::value, ROWS = 16 * (I1 - I0);
+                strip_lds_barrier();                     // the previous round's store loop has read the staging area
+                // (lane-derived addresses are re-derived from an opaque copy of the thread id: kept live across the k-loop they are spilled, and every
+                //  reload from scratch is an s_waitcnt vmcnt(0) - a wait for all global stores in flight)
+                int tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                const int lane = tid & 63, r = lane & 15, g = lane >> 4;
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) {
+                    const Consts k = consts_of(nt, j, g);
+                    const int kc[4] = {k.corr.x, k.corr.y, k.corr.z, k.corr.w};
+                    const float ka[4] = {k.ca.x, k.ca.y, k.ca.z, k.ca.w}, kb[4] = {k.cb.x, k.cb.y, k.cb.z, k.cb.w};
+#pragma unroll
+                    for (int i = I0; i < I1; ++i) {
+                        const int rl = 16 * (i - I0) + r;
+                        uint32_t pk = 0, mk = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = (float)(acc[i][j][e] + kc[e]) * ka[e] + kb[e];
+                            const float t = rintf(v * qinv) + qzp, tc = fminf(fmaxf(t, fmin_), fmax_);
+                            pk = __builtin_amdgcn_cvt_pk_u8_f32(tc - fmin_, e, pk);
+                            mk |= (uint32_t)(t == tc) << e;
+                        }
+                        *reinterpret_cast<uint32_t*>(sStage + rl * SROW + wave * 48 + 16 * j + 4 * g) = pk;
+                        // mask byte of 8 consecutive columns = the nibbles of lanes g = 2h (low) and 2h + 1 (high)
+                        const uint32_t other = (uint32_t)__shfl_xor((int)mk, 16, 64);
+                        if ((g & 1) == 0) reinterpret_cast<uint8_t*>(sMask)[rl * 48 + wave * 6 + 2 * j + (g >> 1)] = (uint8_t)(mk | (other << 4));
+                    }
+                }
+                strip_lds_barrier();
+                const int row0 = m0 + 16 * I0;
+                if constexpr (MODE == 4) {
+                    for (int idx = tid; idx < ROWS * 24; idx += 512) {
+                        const int rl = idx / 24, c = idx % 24, row = row0 + rl;
+                        const uint4 v = *reinterpret_cast<const uint4*>(sStage + rl * SROW + 16 * c);
+                        if (row < p.M) *reinterpret_cast<uint4*>(p.out8 + (int64_t)row * p.ldc + tilebase + 16 * c) = v;
+                    }
+                    for (int idx = tid; idx < ROWS * 3; idx += 512) {
+                        const int rl = idx / 3, c = idx % 3, row = row0 + rl;
+                        const uint4 v = *reinterpret_cast<const uint4*>(sMask + rl * 48 + 16 * c);
+                        if (row < p.M) *reinterpret_cast<uint4*>(p.out8_mask + (((int64_t)row * p.ldc + tilebase) >> 3) + 16 * c) = v;
+                    }
+                } else {
+                    // attention layout [b][h][q|k|v][t][d], head_dim 64: the tile's 384 columns are 6 whole heads of one of q / k / v
+                    const int which = tilebase / p.D, h0 = (tilebase % p.D) >> 6, Hh = p.D >> 6;
+                    const float invT = 1.0f / (float)p.code_T;
+                    for (int idx = tid; idx < ROWS * 24; idx += 512) {
+                        const int hh = idx / (ROWS * 4), rem = idx % (ROWS * 4), rl = rem >> 2, c4 = rem & 3, row = row0 + rl;
+                        const uint4 v = *reinterpret_cast<const uint4*>(sStage + rl * SROW + 64 * hh + 16 * c4);
+                        const int bb = (int)(((float)row + 0.5f) * invT), tt = row - bb * p.code_T;   // (exact for row < 2^22: checked by the launcher)
+                        const int64_t eo = ((((int64_t)bb * Hh + h0 + hh) * 3 + which) * p.code_T + tt) * 64 + 16 * c4;
+                        if (row < p.M) *reinterpret_cast<uint4*>(p.out8 + eo) = v;
+                    }
+                    for (int idx = tid; idx < ROWS * 6; idx += 512) {
+                        const int hh = idx / ROWS, rl = idx % ROWS, row = row0 + rl;
+                        const uint2 v = *reinterpret_cast<const uint2*>(sMask + rl * 48 + 8 * hh);
+                        const int bb = (int)(((float)row + 0.5f) * invT), tt = row - bb * p.code_T;
+                        const int64_t eo = ((((int64_t)bb * Hh + h0 + hh) * 3 + which) * p.code_T + tt) * 64;
+                        if (row < p.M) *reinterpret_cast<uint2*>(p.out8_mask + (eo >> 3)) = v;
+                    }
+                }
+            };
+            round(std::integral_constant<int, 0>{}, std::integral_constant<int, H0>{});
+            if (nt + 1 < NTL) load_b(nt + 1, 0, b0);
+            round(std::integral_constant<int, H0>{}, std::integral_constant<int, TM>{});
+        }
+    }
+
+    if constexpr (MODE == 3) {
+        float* sRed = reinterpret_cast<float*>(sStage);
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (lane == 0) { sRed[wave] = mn; sRed[8 + wave] = mx; }
+        strip_lds_barrier();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < 8; ++w) { mn = fminf(mn, sRed[w]); mx = fmaxf(mx, sRed[8 + w]); }
+        }
+        if (p.tail.counter) qparams_tail(p.tail, p.stats, p.stat_slots, gridDim.x * gridDim.y, reinterpret_cast<uint32_t*>(sRed) + 32, mn, mx);
+        else if (tid == 0) stat_atomic(p.stats, p.stat_slots, mn, mx);
+    }
+}
+
+template <int MODE, int NTL>
+static void strip_launch(const I8StripArgs& a, hipStream_t st) {
+    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : 112 * 400 + 112 * 48);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+    (void)once;
+    k_i8_strip<MODE, NTL><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), 512, kLds, st>>>(a);
+}
+
+// true when the strip kernel covers the request (the caller then launched it); false -> the general tall kernel
+bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
+                     const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
+                     const NTPost* post, const QpTail* tail, bool force) {
+    static const int on = getenv("QATVIT_I8_STRIP") ? atoi(getenv("QATVIT_I8_STRIP")) : 1;   // 0: the general tall kernel (A/B arm of the bit-identity test)
+    if ((!on && !force) || !B8f || !post || K != 384 || lda % 16 != 0 || !s1 || M >= (1 << 22)) return false;
+    const int ntl = N % (4 * 384) == 0 ? 4 : N % (3 * 384) == 0 ? 3 : 0;
+    if (!ntl) return false;
+    I8StripArgs a{};
+    a.A = reinterpret_cast<const int8_t*>(A8); a.Bf = reinterpret_cast<const i32x4*>(B8f); a.M = M; a.N = N; a.lda = lda;
+    a.s1 = s1; a.s2 = s2; a.col_scale = col_scale; a.bias = bias; a.wsum = wsum; a.aqp = a_qp; a.center = center;
+    if (post->mode == 3) {
+        if (!stats) return false;
+        a.stats = stats; a.stat_slots = stat_slots < 1 ? 1 : stat_slots;
+        if (tail) a.tail = *tail;
+        if (ntl == 4) strip_launch<3, 4>(a, st); else strip_launch<3, 3>(a, st);
+        return true;
+    }
+    a.qp = post->qp; a.qmin = post->qmin; a.qmax = post->qmax;
+    a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.out8_mask = reinterpret_cast<uint8_t*>(post->out8_mask);
+    if (!a.qp || !a.out8 || !a.out8_mask || a.qmax - a.qmin >= 256) return false;
+    if (post->mode == 7) {
+        const int D = N / 3;
+        if (post->code_hd != 64 || D % 384 != 0 || post->code_T < 1 || post->code_T >= 1024) return false;
+        a.code_T = post->code_T; a.D = D;
+        if (ntl == 4) strip_launch<7, 4>(a, st); else strip_launch<7, 3>(a, st);
+        return true;
+    }
+    if (post->mode == 4) {
+        // the codes-only form of the storing pass: grid indices + mask bits + the two tables, no 2- or 4-byte plane
+        if (post->out_hi || post->out_lo || post->code || post->out16_hi || post->out16_lo || !post->lut_out || !post->lutq_out || ldc % 128 != 0) return false;
+        a.ldc = ldc; a.lut_out = post->lut_out; a.lutq_out = post->lutq_out; a.out16_scale = post->out16_scale;
+        if (ntl == 4) strip_launch<4, 4>(a, st); else strip_launch<4, 3>(a, st);
+        return true;
+    }
+    return false;
+}
+
+}  // namespace qv

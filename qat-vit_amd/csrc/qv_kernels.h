@@ -79,8 +79,6 @@ struct NTPost {
     // byte (row * ldc + c) / 8.  Mode 4 writes that mask plane when out8_mask is set (then `code`, the uint16 plane, may be NULL).
     const void* code8 = nullptr;
     const void* code_mask = nullptr;
-    // mode 3 on the int8 kernel: -1 = the A-stationary strip kernel when the shape allows it (K == 384) unless QATVIT_I8_STATS_STRIP=0; 0 / 1 = force
-    int stats_strip = -1;
     // mode 7, optional (training): the STE mask bit of every element in the same order as the codes, one bit per element (head_dim % 32 == 0)
     void* out8_mask = nullptr;
     // mode 8 (split-A dgrad whose output rows are whole LayerNorm rows, N == 384): the LayerNorm backward fused into the epilogue -
@@ -105,7 +103,18 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                    const QpTail* tail = nullptr);   // tail (with stats): the last workgroup also runs the observer / qparams update of the output's quantizer
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
-                      hipStream_t st, const NTPost* post = nullptr, const QpTail* tail = nullptr);
+                      hipStream_t st, const NTPost* post = nullptr, const QpTail* tail = nullptr,
+                      const void* B8f = nullptr);   // B8f: the same weight integers in fragment order (launch_w8_fragment_order): enables the strip kernel
+// ---- i8strip.hip: the K = 384 two-pass forward GEMMs (qkv, fc1), A-stationary; returns true when it covered (and launched) the request
+bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
+                     const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
+                     const NTPost* post, const QpTail* tail, bool force = false);
+// byte offset of element (n, k) of an [N, K] int8 weight in fragment order: [48-column group][64-deep k-step][16-column fragment][lane = 16 (k % 64 / 16) + n % 16][k % 16]
+__host__ __device__ inline int64_t w8f_offset(int n, int k, int K) {
+    const int cg = n / 48, cr = n % 48, j = cr / 16, r = cr % 16, kt = k / 64, kk = k % 64;
+    return ((((int64_t)cg * (K / 64) + kt) * 3 + j) * 64 + (kk / 16) * 16 + r) * 16 + (kk % 16);
+}
+int launch_w8_fragment_order(const void* B8, void* B8f, int N, int K, hipStream_t st);   // N % 48 == 0, K % 64 == 0
 // A operand = uint8 grid indices [M, lda] expanded through lut[256] (packed fp16 hi | lo << 16 pairs) inside the kernel; B16 = weight integers as fp16
 int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                          const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
@@ -165,6 +174,7 @@ struct WQpTab {
 struct WQuantTab {
     const float* W[kMaxW]; const float* qp[kMaxW]; void* wq[kMaxW]; void* wqT[kMaxW]; void* w8[kMaxW]; int32_t* wsum[kMaxW];   // w8 / wsum optional (int8 copies + row sums)
     void* w16[kMaxW];   // optional: the same integers as fp16 (B operand of the fp16-pair forward GEMMs: proj, fc2)
+    void* w8f[kMaxW];   // optional: the int8 integers once more in fragment order (w8f_offset: B operand of the strip kernel; N % 48 == 0, K % 64 == 0)
     int N[kMaxW], K[kMaxW], blk0[kMaxW + 1]; int n, per_channel, qmin, qmax;
 };
 int launch_w_observe_all(WObsTab& t, hipStream_t st);      // fills blk0

@@ -31,7 +31,9 @@ SIGNATURES = {
     "qatvit_optim_adamw": (c_int, [c_void_p] * 7 + [c_int32, c_int64] + [c_double] * 5 + [c_int64, c_void_p, c_void_p]),
     "qatvit_gemm_nt": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_nt_f16": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
-    "qatvit_gemm_nt_i8_minmax": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 5 + [c_int32, c_void_p]),
+    "qatvit_gemm_nt_i8_minmax": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
+    "qatvit_w8_fragment_order": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "qatvit_i8_strip": (c_int, [c_int32] + [c_void_p] * 4 + [c_int32] * 4 + [c_void_p] * 6 + [c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 4),
     "qatvit_gemm_nt_codes": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_nt_i8": (c_int, [c_void_p] * 4 + [c_int32, c_void_p] + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_tn_scratch_bytes": (c_int64, []),
@@ -97,7 +99,7 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library drift
             fn.restype, fn.argtypes = res, args
-        if L.qatvit_abi_version() != 2:
+        if L.qatvit_abi_version() != 3:
             raise RuntimeError("libqatvit.so ABI version mismatch")
         _lib = L
     return _lib

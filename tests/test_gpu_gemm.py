@@ -259,50 +259,107 @@ def test_gemm_nt_codes_equals_planes(native_lib, M, N, K):
     assert torch.equal(st_a, st_b)
 
 
+def _ord2f(k):   # qv_common.h: order-preserving uint32 -> float
+    k = int(k) & 0xFFFFFFFF
+    u = (k & 0x7FFFFFFF) if (k & 0x80000000) else (~k & 0xFFFFFFFF)
+    return np.frombuffer(np.uint32(u).tobytes(), dtype=np.float32)[0]
+
+
+def _unpack_bits(mask_bytes, n):
+    """bit i % 8 of byte i / 8 -> bool [n]"""
+    b = mask_bytes.view(torch.uint8).flatten()
+    return ((b[:, None] >> torch.arange(8, device=b.device, dtype=torch.uint8)[None, :]) & 1).flatten()[:n].bool()
+
+
 @pytest.mark.parametrize("per_channel", [0, 1])
-@pytest.mark.parametrize("M,N", [(1576, 1152), (1576, 1536), (50432, 1536), (50432, 1152), (209, 2304), (40, 3072)])
-def test_gemm_i8_statistics_pass_strip_kernel(native_lib, M, N, per_channel):
-    """The statistics-only first pass of the two-pass GEMMs (qkv, fc1: K = 384): the A-stationary strip kernel against the general tiled kernel and
-    against the min / max of the tensor qatvit_gemm_nt_i8 stores - the same bits (the observer, hence every code downstream, depends on them)."""
-    K = 384
-    torch.manual_seed(M + N + per_channel)
+@pytest.mark.parametrize("qrange", [(0, 255), (0, 127)])
+@pytest.mark.parametrize("B,T,N", [(8, 197, 1152), (8, 197, 1536), (256, 197, 1536), (256, 197, 1152), (1, 209, 2304), (1, 40, 3072), (3, 65, 1152)])
+def test_i8_strip_kernel_equals_general_kernel(native_lib, B, T, N, per_channel, qrange):
+    """The A-stationary strip kernel of the two-pass K = 384 GEMMs (qkv, fc1: csrc/i8strip.hip) against qatvit_gemm_nt_i8 (general 208 x 384 tile, fp32
+    output): the statistics pass returns the min / max of that tensor bit for bit; the code passes return, for every element, the code and the STE mask bit
+    that fake-quantising that fp32 value with the given qparams yields - in the row-major layout (fc1, mode 4) and in the attention layout (qkv, mode 7).
+    Integer rounding must be bit-exact: torch.equal throughout.  Ragged last strips (M % 208 != 0), one / several column-tile groups, both activation ranges."""
+    K, M = 384, B * T
+    torch.manual_seed(M + N + per_channel + qrange[1])
     dev = "cuda"
     zp, center = 131, 128
     q = torch.randint(0, 256, (M, K), device=dev)
     W = torch.randint(-128, 128, (N, K), device=dev)
     A8 = (q - center).to(torch.int8)
     B8 = W.to(torch.int8)
+    B8f = torch.empty_like(B8)
+    assert native_lib.qatvit_w8_fragment_order(B8.data_ptr(), B8f.data_ptr(), N, K, _st()) == 0, native_lib.qatvit_last_error()
     wsum = W.sum(1).to(torch.int32)
     aqp = torch.tensor([0.0173, 1 / 0.0173, float(zp), 1.0], device=dev)
     s1 = torch.tensor([0.0173], device=dev)
     s2 = torch.tensor([0.0041], device=dev)
     cs = (torch.rand(N, device=dev) * 0.01 + 0.001) if per_channel else None
     bias = torch.randn(N, device=dev)
+    s2p, csp = (None, cs.data_ptr()) if per_channel else (s2.data_ptr(), None)
 
     def fresh():
         return torch.tensor([0xFF800000 - (1 << 32), 0x007FFFFF], dtype=torch.int32, device=dev)
 
     C = torch.empty(M, N, device=dev)
-    st_full = fresh()
+    st_full, st_gen, st_strip = fresh(), fresh(), fresh()
     assert native_lib.qatvit_gemm_nt_i8(A8.data_ptr(), B8.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), center, C.data_ptr(), M, N, K, K, K, N, s1.data_ptr(),
-                                        None if per_channel else s2.data_ptr(), cs.data_ptr() if per_channel else None, bias.data_ptr(), st_full.data_ptr(),
-                                        _st()) == 0, native_lib.qatvit_last_error()
-    out = []
-    for strip in (0, 1):
-        st = fresh()
-        assert native_lib.qatvit_gemm_nt_i8_minmax(A8.data_ptr(), B8.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), center, M, N, K, K, K, s1.data_ptr(),
-                                                   None if per_channel else s2.data_ptr(), cs.data_ptr() if per_channel else None, bias.data_ptr(),
-                                                   st.data_ptr(), strip, _st()) == 0, native_lib.qatvit_last_error()
-        out.append(st)
+                                        s2p, csp, bias.data_ptr(), st_full.data_ptr(), _st()) == 0, native_lib.qatvit_last_error()
+    assert native_lib.qatvit_gemm_nt_i8_minmax(A8.data_ptr(), B8.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), center, M, N, K, K, K, s1.data_ptr(), s2p, csp,
+                                               bias.data_ptr(), st_gen.data_ptr(), _st()) == 0, native_lib.qatvit_last_error()
+
+    def strip(mode, stats=None, qp=None, out8=None, mask=None, code_T=0, lut=None, lutq=None, sc=None):
+        assert native_lib.qatvit_i8_strip(mode, A8.data_ptr(), B8f.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), center, M, N, K, s1.data_ptr(), s2p, csp,
+                                          bias.data_ptr(), _ptr(stats), _ptr(qp), qrange[0], qrange[1], _ptr(out8), _ptr(mask), code_T, _ptr(lut), _ptr(lutq),
+                                          _ptr(sc), _st()) == 0, native_lib.qatvit_last_error()
+
+    strip(3, stats=st_strip)
     torch.cuda.synchronize()
-    assert torch.equal(out[0], st_full) and torch.equal(out[1], st_full)
+    assert torch.equal(st_gen, st_full) and torch.equal(st_strip, st_full)
+    assert _ord2f(st_strip[0]) == C.min().item() and _ord2f(st_strip[1]) == C.max().item()
 
-    def ord2f(k):   # qv_common.h: order-preserving uint32 -> float
-        k = int(k) & 0xFFFFFFFF
-        u = (k & 0x7FFFFFFF) if (k & 0x80000000) else (~k & 0xFFFFFFFF)
-        return np.frombuffer(np.uint32(u).tobytes(), dtype=np.float32)[0]
+    # an output quantizer that clips ~10 % at either end (exercises the clamp and the STE mask), arithmetic as ATen's cachemask kernel
+    lo, hi = torch.quantile(C.flatten()[:: max(1, C.numel() // 100000)], torch.tensor([0.1, 0.9], device=dev)).tolist()
+    scale = torch.tensor([(hi - lo) / (qrange[1] - qrange[0])], device=dev, dtype=torch.float32)
+    inv = torch.ones(1, device=dev) / scale
+    zpo = float(round(qrange[0] - lo / scale.item()))
+    qp = torch.cat([scale, inv, torch.tensor([zpo, 1.0], device=dev)])
+    t = torch.round(C * inv) + zpo
+    tc = t.clamp(qrange[0], qrange[1])
+    want_code = (tc - qrange[0]).to(torch.uint8)
+    want_mask = t == tc
+    assert 0.02 < (~want_mask).float().mean().item() < 0.5
 
-    assert ord2f(out[1][0]) == C.min().item() and ord2f(out[1][1]) == C.max().item()
+    # mode 4: row-major codes + mask bits + the two tables
+    out8 = torch.full((M, N), 0xEE, dtype=torch.uint8, device=dev)
+    mask = torch.full((M, N // 8), 0xEE, dtype=torch.uint8, device=dev)
+    lut = torch.zeros(256, dtype=torch.int32, device=dev)
+    lutq = torch.zeros(256, dtype=torch.int32, device=dev)
+    sc = torch.zeros(1, device=dev)
+    strip(4, qp=qp, out8=out8, mask=mask, lut=lut, lutq=lutq, sc=sc)
+    torch.cuda.synchronize()
+    assert torch.equal(out8, want_code)
+    assert torch.equal(_unpack_bits(mask, M * N).view(M, N), want_mask)
+    grid = (torch.arange(qrange[0], qrange[1] + 1, device=dev).float() - zpo) * scale
+    g = torch.nn.functional.gelu(grid.double()).float()
+    n = grid.numel()
+    l16 = lut[:n]
+    got16 = ((l16 & 0xffff).to(torch.int16).view(torch.float16).double() + ((l16 >> 16) & 0xffff).to(torch.int16).view(torch.float16).double()) * sc.double()
+    lq = lutq[:n]
+    gotq = (lq & 0xffff).to(torch.int16).view(torch.bfloat16).double() + ((lq >> 16) & 0xffff).to(torch.int16).view(torch.bfloat16).double()
+    assert (got16 - g.double()).abs().max().item() <= 2e-6 * g.abs().max().item() and (gotq - g.double()).abs().max().item() <= 2e-5 * g.abs().max().item()
+    assert (lut[n:] == 0).all() and (lutq[n:] == 0).all()
+
+    # mode 7: the attention layout [b][head][q|k|v][t][64]
+    if (N // 3) % 384 == 0:
+        D, H = N // 3, N // 3 // 64
+        out8 = torch.full((B, H, 3, T, 64), 0xEE, dtype=torch.uint8, device=dev)
+        mask = torch.full((B, H, 3, T, 8), 0xEE, dtype=torch.uint8, device=dev)
+        strip(7, qp=qp, out8=out8, mask=mask, code_T=T)
+        torch.cuda.synchronize()
+        want = want_code.view(B, T, 3, H, 64).permute(0, 3, 2, 1, 4).contiguous()
+        assert torch.equal(out8, want)
+        wm = want_mask.view(B, T, 3, H, 64).permute(0, 3, 2, 1, 4).contiguous()
+        assert torch.equal(_unpack_bits(mask, M * N).view(B, H, 3, T, 64), wm)
 
 
 @pytest.mark.parametrize("two_phase", [0, 1])

@@ -17,7 +17,7 @@ KNOBS = {
     "QATVIT_FC1_BITS=0": "bits",           # uint16 code plane instead of byte plane + mask bits
     "QATVIT_FC2W_CODES=0": "bits",         # fc2 weight gradient from the bf16 planes
     "QATVIT_QKV_2PASS=0": "bits",          # qkv GEMM once, fp32 output, attention quantises on load
-    "QATVIT_I8_STATS_STRIP=0": "bits",     # general tiled kernel for the statistics passes
+    "QATVIT_I8_STRIP=0": "bits",           # the two-pass K = 384 GEMMs (qkv, fc1) on the general tall tile instead of the A-stationary strip kernel
     "QATVIT_TNW_I8=1": "bits",             # qkv / fc1 weight gradients with X as int8 widened in the kernel
     "QATVIT_QP_TAIL=1": "bits",            # k_qparams in the tail of its producer
     "QATVIT_I8=0": "bits",                 # grid x grid GEMMs on bf16 MFMA
