@@ -60,6 +60,7 @@ struct I8StripArgs {
     uint32_t* lut_out;      // MODE 4 tables
     uint32_t* lutq_out;
     float* out16_scale;
+    unsigned long long* dbg;   // experiments only: s_memtime stamps of workgroups 0 and 100 ([2][8 waves][32])
 };
 
 // LDS image of one [208][64 B] k-tile of A: two 64-B tile rows share one 128-B LDS row; chunk ((row & 1) * 4 + k-chunk) XOR (LDS row & 7)
@@ -69,9 +70,17 @@ __device__ inline int strip_off(int row, int chunk) {
 }
 __device__ inline void strip_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int MODE, int NTL>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384
+// VAR (tuning / timing-only ablations): bit 0 = every workgroup starts its k-loop and its column tiles at a different (k-step, tile) offset;
+// bit 1 = weight fragments two k-steps ahead (three register buffers); bit 2 = A-fragment ring 4 deep; 8 = no weight loads in the loop (timing only);
+// 16 = no A-fragment reads in the loop (timing only)
+template <int MODE, int NTL, int VAR = 0>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384
 __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     constexpr int TM = 13, TNT = 3, BM = 208, BN = 384, KT = 6;
+    constexpr bool ROT = VAR & 1, NOB = VAR & 8, NOA = VAR & 16;
+    constexpr int BD = (VAR & 2) ? 2 : 1, PF = (VAR & 4) ? 4 : 3;
+    constexpr bool PIN = VAR & 32, NOM = VAR & 64;   // 64: no MFMAs (timing only)
+    constexpr bool STAMP = VAR & 1024;
+    constexpr bool NOST = VAR & 128, NOSG = VAR & 256, NOEP = VAR & 512;   // timing only: no global stores / no LDS staging either / no epilogue at all
     constexpr int IMGA = BM * 64, LA = KT * IMGA;        // 79,872 B
     constexpr int SROW = 400;                            // staged code row: 384 B + 16 B (bank spread of the packed ds_write_b32)
     constexpr int H0 = 7;                                // row fragments of the first staging round (112 rows); the second takes 6 (96 rows)
@@ -88,6 +97,17 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * BM, nbase = blockIdx.y * NTL * BN;
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if constexpr (STAMP) {
+            if (p.dbg && (blockIdx.x == 0 || blockIdx.x == 100) && blockIdx.y == 0) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0 && nstamp < 32) p.dbg[((blockIdx.x ? 1 : 0) * 8 + wave) * 32 + nstamp] = t;
+                ++nstamp;
+            }
+        }
+    };
+    stamp();   // 0: kernel entry
 
     // ---- A strip: 6 k-tiles x 13 pieces of 1 KiB, dealt to the 8 waves; the swizzle goes on the SOURCE address (the DMA destination is lane-linear)
     {
@@ -117,8 +137,13 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
             b[j] = __builtin_bit_cast(i32x4, v);
         }
     };
-    i32x4 b0[TNT], b1[TNT];
-    load_b(0, 0, b0);
+    // rotation: the 243 workgroups of a launch otherwise sweep the same weight bytes at the same time
+    const int rotk = ROT ? (int)(blockIdx.x % KT) : 0, rotn = ROT ? (int)((blockIdx.x / KT) % NTL) : 0;
+    auto kidx = [&](int kt) { const int k = kt + rotk; return k >= KT ? k - KT : k; };
+    auto nidx = [&](int nt) { const int n = nt + rotn; return n >= NTL ? n - NTL : n; };
+    i32x4 bb[BD + 1][TNT];
+    load_b(nidx(0), kidx(0), bb[0]);
+    if constexpr (BD == 2) load_b(nidx(0), kidx(1), bb[1]);
 
     // per-column constants v = (float)(acc + corr[n]) * ca[n] + cb[n], once per workgroup into LDS (published by the barrier below): in the swapped
     // accumulator layout a lane needs 3 x 4 columns x 3 constants per column tile - as registers next to 156 accumulators they spill
@@ -161,47 +186,59 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     }
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's A pieces have landed, its constants are written ...
+    stamp();   // 1: own DMA landed
     __builtin_amdgcn_s_barrier();                        // ... and everybody else's
     asm volatile("" ::: "memory");
+    stamp();   // 2: strip complete
 
     float mn = INFINITY, mx = -INFINITY;                 // MODE 3
     const bool ragged = m0 + BM > p.M;                   // (uniform) the last strip holds rows past M: they read as zero and must not be observed / stored
 
     i32x4 acc[TM][TNT];
 #pragma clang loop unroll(disable)
-    for (int nt = 0; nt < NTL; ++nt) {
+    for (int nti = 0; nti < NTL; ++nti) {
+        const int nt = nidx(nti);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TNT; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
-        // ---- k-loop: no barrier, no LDS write; weight fragments one k-step ahead in registers (the other buffer)
+        // ---- k-loop: no barrier, no LDS write; weight fragments BD k-steps ahead in registers
         auto kstep = [&](int kt, const i32x4 (&bc)[TNT]) {
             // (the strip is loop-invariant across column tiles: without this opaque zero in its address hipcc hoists all 78 fragment reads out of
             //  the nt loop - 312 registers, spilled to scratch)
             __builtin_amdgcn_sched_barrier(0);           // one scheduling region per k-step: merged regions rotate the accumulators through spare registers and spill
             int opaque = 0;
             asm volatile("" : "+v"(opaque));
-            const char* st = sA + opaque + kt * IMGA;
-            constexpr int PF = 3;
+            const char* st = sA + opaque + kidx(kt) * IMGA;
             i32x4 af[PF];
 #pragma unroll
             for (int i = 0; i < PF - 1; ++i) af[i] = *reinterpret_cast<const i32x4*>(st + strip_off(16 * i + r, g));
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if (i + PF - 1 < TM) af[(i + PF - 1) % PF] = *reinterpret_cast<const i32x4*>(st + strip_off(16 * (i + PF - 1) + r, g));
+                // (pin the software pipeline: left to itself hipcc issues the fragment reads in pairs right in front of their MFMAs - lgkmcnt(1) after
+                //  two back-to-back reads - and the LDS latency of every fragment is exposed: 28 vs 17 us for the whole statistics pass)
+                if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+                if (i + PF - 1 < TM && !NOA) af[(i + PF - 1) % PF] = *reinterpret_cast<const i32x4*>(st + strip_off(16 * (i + PF - 1) + r, g));
+                if constexpr (NOA) asm volatile("" : "+v"(af[i % (PF - 1)]));   // (timing-only arm: opaque, or the identical MFMA chains of different i are merged)
+                if constexpr (NOM) { asm volatile("" :: "v"(af[i % PF])); continue; }
 #pragma unroll
                 for (int j = 0; j < TNT; ++j)   // swapped roles: D[row = weight column 4 g + e][col = token r]
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bc[j], af[i % PF], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bc[j], af[NOA ? i % (PF - 1) : i % PF], acc[i][j], 0, 0, 0);
             }
         };
 #pragma unroll
-        for (int kt = 0; kt < KT; kt += 2) {
-            load_b(nt, kt + 1, b1);
-            kstep(kt, b0);
-            if (kt + 2 < KT) load_b(nt, kt + 2, b0);
-            else if (MODE == 3 && nt + 1 < NTL) load_b(nt + 1, 0, b0);   // (code passes: requested after the first staging round, when 84 accumulators are dead)
-            kstep(kt + 1, b1);
+        for (int kt = 0; kt < KT; ++kt) {
+            // request k-step kt + BD (of this column tile or the next); code passes request the next tile's first BD steps after their first
+            // staging round instead, when 84 accumulators are dead
+            if constexpr (!NOB) {
+                if (kt + BD < KT) load_b(nt, kidx(kt + BD), bb[(kt + BD) % (BD + 1)]);
+                else if (MODE == 3 && nti + 1 < NTL) load_b(nidx(nti + 1), kidx(kt + BD - KT), bb[(kt + BD) % (BD + 1)]);
+            }
+            kstep(kt, bb[NOB ? 0 : kt % (BD + 1)]);
+            if (kt == 2) stamp();   // half of the k-loop
         }
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();   // k-loop done
 
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MODE == 3) {
@@ -236,7 +273,9 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
                     }
             }
         } else {
-            const float qinv = p.qp[1], qzp = p.qp[2], fmin_ = (float)p.qmin, fmax_ = (float)p.qmax;
+            // u = rint(v / s) + (zp - qmin) = q - qmin (small-integer float arithmetic: exact, the same value as (rint(v / s) + zp) - qmin);
+            // code = clamp(u, 0, qmax - qmin), in range <=> u == clamp(u)
+            const float qinv = p.qp[1], zoff = p.qp[2] - (float)p.qmin, frange = (float)(p.qmax - p.qmin);
             const int tilebase = nbase + nt * BN;
             // two staging rounds per column tile (rows 0 .. 111, then 112 .. 207): quantise in registers, 4 codes -> 1 dword -> LDS, barrier,
             // 16-B copies into the output layout
@@ -260,17 +299,23 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float v = (float)(acc[i][j][e] + kc[e]) * ka[e] + kb[e];
-                            const float t = rintf(v * qinv) + qzp, tc = fminf(fmaxf(t, fmin_), fmax_);
-                            pk = __builtin_amdgcn_cvt_pk_u8_f32(tc - fmin_, e, pk);
-                            mk |= (uint32_t)(t == tc) << e;
+                            const float u = rintf(v * qinv) + zoff, uc = __builtin_amdgcn_fmed3f(u, 0.0f, frange);
+                            pk = __builtin_amdgcn_cvt_pk_u8_f32(uc, e, pk);
+                            mk |= (uint32_t)(u == uc) << e;
                         }
+                        if constexpr (NOSG) { asm volatile("" :: "v"(pk), "v"(mk)); continue; }
                         *reinterpret_cast<uint32_t*>(sStage + rl * SROW + wave * 48 + 16 * j + 4 * g) = pk;
-                        // mask byte of 8 consecutive columns = the nibbles of lanes g = 2h (low) and 2h + 1 (high)
+                        // mask byte of 8 consecutive columns = the nibbles of lanes g = 2h (low) and 2h + 1 (high); BOTH lanes of a pair write the same
+                        // byte to the same address (a lane-dependent branch here would end the basic block after every fragment)
                         const uint32_t other = (uint32_t)__shfl_xor((int)mk, 16, 64);
-                        if ((g & 1) == 0) reinterpret_cast<uint8_t*>(sMask)[rl * 48 + wave * 6 + 2 * j + (g >> 1)] = (uint8_t)(mk | (other << 4));
+                        const uint32_t lo4 = (g & 1) ? other : mk, hi4 = (g & 1) ? mk : other;
+                        reinterpret_cast<uint8_t*>(sMask)[rl * 48 + wave * 6 + 2 * j + (g >> 1)] = (uint8_t)(lo4 | (hi4 << 4));
                     }
                 }
+                stamp();   // staged (VALU + LDS writes issued)
+                if constexpr (NOSG || NOST) return;
                 strip_lds_barrier();
+                stamp();   // barrier passed
                 const int row0 = m0 + 16 * I0;
                 if constexpr (MODE == 4) {
                     for (int idx = tid; idx < ROWS * 24; idx += 512) {
@@ -303,12 +348,26 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
                     }
                 }
             };
+            if constexpr (NOEP) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNT; ++j) asm volatile("" :: "v"(acc[i][j]));
+                if (nti + 1 < NTL) load_b(nidx(nti + 1), kidx(0), bb[0]);
+                continue;
+            }
             round(std::integral_constant<int, 0>{}, std::integral_constant<int, H0>{});
-            if (nt + 1 < NTL) load_b(nt + 1, 0, b0);
+            if (nti + 1 < NTL && !NOB) {
+#pragma unroll
+                for (int d = 0; d < BD; ++d) load_b(nidx(nti + 1), kidx(d), bb[d]);
+            }
+            stamp();   // stores of round 1 issued
             round(std::integral_constant<int, H0>{}, std::integral_constant<int, TM>{});
+            stamp();   // stores of round 2 issued
         }
     }
 
+    stamp();   // end
     if constexpr (MODE == 3) {
         float* sRed = reinterpret_cast<float*>(sStage);
         mn = wave_min(mn);
@@ -324,12 +383,34 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     }
 }
 
+template <int MODE, int NTL, int VAR>
+static void strip_launch_v(const I8StripArgs& a, hipStream_t st) {
+    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : 112 * 400 + 112 * 48);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+    (void)once;
+    k_i8_strip<MODE, NTL, VAR><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), 512, kLds, st>>>(a);
+}
 template <int MODE, int NTL>
 static void strip_launch(const I8StripArgs& a, hipStream_t st) {
-    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : 112 * 400 + 112 * 48);
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
-    (void)once;
-    k_i8_strip<MODE, NTL><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), 512, kLds, st>>>(a);
+#ifdef QV_STRIP_EXPERIMENTS
+    const char* e = getenv("QATVIT_STRIP_VAR");   // (read per launch: tools/bench_i8strip.py flips it between timed arms of one process)
+    const int v = e ? atoi(e) : 0;
+    if constexpr (NTL == 3) {
+        switch (v) {
+            case 32: return strip_launch_v<MODE, NTL, 32>(a, st);
+            case 36: return strip_launch_v<MODE, NTL, 36>(a, st);
+            case 16: return strip_launch_v<MODE, NTL, 16>(a, st);
+            case 96: return strip_launch_v<MODE, NTL, 96>(a, st);
+            case 104: return strip_launch_v<MODE, NTL, 104>(a, st);
+            case 128: return strip_launch_v<MODE, NTL, 128>(a, st);
+            case 256: return strip_launch_v<MODE, NTL, 256>(a, st);
+            case 512: return strip_launch_v<MODE, NTL, 512>(a, st);
+            case 1024: { I8StripArgs b = a; const char* d = getenv("QATVIT_STRIP_DBG"); b.dbg = d ? reinterpret_cast<unsigned long long*>(strtoull(d, nullptr, 0)) : nullptr; return strip_launch_v<MODE, NTL, 1024>(b, st); }
+            default: break;
+        }
+    }
+#endif
+    strip_launch_v<MODE, NTL, 0>(a, st);
 }
 
 // true when the strip kernel covers the request (the caller then launched it); false -> the general tall kernel
