@@ -17,7 +17,12 @@
 //   * hence the k-loop has NO barrier and NO LDS write: 13 A-fragment ds_read_b128 + 39 MFMAs per k-step per wave, waves run freely;
 //   * MFMA operands are SWAPPED (weight fragment as A, activation fragment as B): an accumulator register then holds 4 CONSECUTIVE OUTPUT
 //     COLUMNS of one token, so the epilogue packs four codes into one dword (v_cvt_pk_u8_f32) and stages them with ONE ds_write_b32 -
-//     1 B per element through LDS instead of 4 - and the store loop is a pure 16-B copy into whole 64-B .. 384-B row runs;
+//     1 B per element through LDS instead of 4;
+//   * the staging area is WAVE-PRIVATE (64 rows x its 48 columns at a time): a wave transposes its own codes through LDS into 16-B pieces of
+//     whole rows and stores them itself, so there is NO workgroup barrier after the prologue.  With workgroup-wide staging (round 3's first
+//     form: profiles/round3_i8strip_v1_ablations_and_stamps.txt) the barriers kept all waves - through the launch, all workgroups - in the
+//     same phase and the pass was the SUM of MFMA, quantise (VALU), and store-burst times; free-running SIMD partners drift apart and one
+//     wave's MFMAs run under the other's quantise / store phase;
 //   * statistics pass: min / max over the 13 row fragments in the INTEGER domain (the affine map to the stored value is monotone per
 //     column: ca > 0), the float map once per column - 2 instead of 12 VALU instructions per element, the same bits.
 // Every arithmetic step on an element is the one the general tall kernel (gemm.hip, k_gemm_nt<.., I8>) performs, in the same order:
@@ -70,44 +75,40 @@ __device__ inline int strip_off(int row, int chunk) {
 }
 __device__ inline void strip_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// VAR (tuning / timing-only ablations): bit 0 = every workgroup starts its k-loop and its column tiles at a different (k-step, tile) offset;
-// bit 1 = weight fragments two k-steps ahead (three register buffers); bit 2 = A-fragment ring 4 deep; 8 = no weight loads in the loop (timing only);
-// 16 = no A-fragment reads in the loop (timing only)
-template <int MODE, int NTL, int VAR = 0>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384
+#ifdef QV_STRIP_EXPERIMENTS
+#define QV_STAMP() stamp()
+#else
+#define QV_STAMP() ((void)0)
+#endif
+
+template <int MODE, int NTL>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384
 __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
-    constexpr int TM = 13, TNT = 3, BM = 208, BN = 384, KT = 6;
-    constexpr bool ROT = VAR & 1, NOB = VAR & 8, NOA = VAR & 16;
-    constexpr int BD = (VAR & 2) ? 2 : 1, PF = (VAR & 4) ? 4 : 3;
-    constexpr bool PIN = VAR & 32, NOM = VAR & 64;   // 64: no MFMAs (timing only)
-    constexpr bool STAMP = VAR & 1024;
-    constexpr bool NOST = VAR & 128, NOSG = VAR & 256, NOEP = VAR & 512;   // timing only: no global stores / no LDS staging either / no epilogue at all
+    constexpr int TM = 13, TNT = 3, BM = 208, BN = 384, KT = 6, PF = 3;
     constexpr int IMGA = BM * 64, LA = KT * IMGA;        // 79,872 B
-    constexpr int SROW = 400;                            // staged code row: 384 B + 16 B (bank spread of the packed ds_write_b32)
-    constexpr int H0 = 7;                                // row fragments of the first staging round (112 rows); the second takes 6 (96 rows)
-    constexpr int STG = 16 * H0 * SROW;                  // 44,800 B
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NC = NTL * BN;                         // columns of this workgroup
+    constexpr int CH = 4;                                // row fragments per staging chunk: 64 rows x 48 columns of codes + 64 x 8 B of mask bits per wave
+    constexpr int WSTG = 16 * CH * 48 + 16 * CH * 16;    // 4 KiB per wave: [64][48 B] codes + [64][16 B] mask nibbles
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
     int* sCorr = reinterpret_cast<int*>(smem + LA);      // per-column constants of the epilogue: corr | ca | cb, [NC] each
     float* sCa = reinterpret_cast<float*>(sCorr + NC);
     float* sCb = sCa + NC;
-    char* sStage = smem + LA + 3 * NC * 4;
-    char* sMask = sStage + STG;                          // [112][48 B]
+    char* sStage = smem + LA + 3 * NC * 4;               // MODE 3: reduction scratch; code passes: 8 wave-private staging areas
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * BM, nbase = blockIdx.y * NTL * BN;
+#ifdef QV_STRIP_EXPERIMENTS
     int nstamp = 0;
-    auto stamp = [&]() {
-        if constexpr (STAMP) {
-            if (p.dbg && (blockIdx.x == 0 || blockIdx.x == 100) && blockIdx.y == 0) {
-                const unsigned long long t = __builtin_amdgcn_s_memtime();
-                if (lane == 0 && nstamp < 32) p.dbg[((blockIdx.x ? 1 : 0) * 8 + wave) * 32 + nstamp] = t;
-                ++nstamp;
-            }
+    auto stamp = [&]() {   // s_memtime stamps of workgroups 0 and 100 (tools/stamp_i8strip.py); p.dbg is NULL outside that tool
+        if (p.dbg && (blockIdx.x == 0 || blockIdx.x == 100) && blockIdx.y == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && nstamp < 32) p.dbg[((blockIdx.x ? 1 : 0) * 8 + wave) * 32 + nstamp] = t;
+            ++nstamp;
         }
     };
-    stamp();   // 0: kernel entry
+#endif
+    QV_STAMP();   // entry
 
     // ---- A strip: 6 k-tiles x 13 pieces of 1 KiB, dealt to the 8 waves; the swizzle goes on the SOURCE address (the DMA destination is lane-linear)
     {
@@ -137,13 +138,8 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
             b[j] = __builtin_bit_cast(i32x4, v);
         }
     };
-    // rotation: the 243 workgroups of a launch otherwise sweep the same weight bytes at the same time
-    const int rotk = ROT ? (int)(blockIdx.x % KT) : 0, rotn = ROT ? (int)((blockIdx.x / KT) % NTL) : 0;
-    auto kidx = [&](int kt) { const int k = kt + rotk; return k >= KT ? k - KT : k; };
-    auto nidx = [&](int nt) { const int n = nt + rotn; return n >= NTL ? n - NTL : n; };
-    i32x4 bb[BD + 1][TNT];
-    load_b(nidx(0), kidx(0), bb[0]);
-    if constexpr (BD == 2) load_b(nidx(0), kidx(1), bb[1]);
+    i32x4 bb[2][TNT];
+    load_b(0, 0, bb[0]);
 
     // per-column constants v = (float)(acc + corr[n]) * ca[n] + cb[n], once per workgroup into LDS (published by the barrier below): in the swapped
     // accumulator layout a lane needs 3 x 4 columns x 3 constants per column tile - as registers next to 156 accumulators they spill
@@ -156,10 +152,10 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
             sCb[c] = p.bias ? p.bias[nbase + c] : 0.0f;
         }
     }
-    struct Consts { int4 corr; float4 ca, cb; };
+    struct Consts { float4 ca, cb; };
     auto consts_of = [&](int nt, int j, int g) {
         const int c = nt * BN + wave * 48 + 16 * j + 4 * g;   // this lane's 4 columns of fragment j
-        return Consts{*reinterpret_cast<const int4*>(sCorr + c), *reinterpret_cast<const float4*>(sCa + c), *reinterpret_cast<const float4*>(sCb + c)};
+        return Consts{*reinterpret_cast<const float4*>(sCa + c), *reinterpret_cast<const float4*>(sCb + c)};
     };
 
     if constexpr (MODE == 4) {   // the two 256-entry tables of gelu(grid value) and the fp16 pair's scale: data-independent, one workgroup writes them
@@ -186,63 +182,70 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     }
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's A pieces have landed, its constants are written ...
-    stamp();   // 1: own DMA landed
-    __builtin_amdgcn_s_barrier();                        // ... and everybody else's
+    QV_STAMP();   // own DMA landed
+    __builtin_amdgcn_s_barrier();                        // ... and everybody else's: the ONLY workgroup barrier of the code passes
     asm volatile("" ::: "memory");
-    stamp();   // 2: strip complete
+    QV_STAMP();   // strip complete
 
     float mn = INFINITY, mx = -INFINITY;                 // MODE 3
     const bool ragged = m0 + BM > p.M;                   // (uniform) the last strip holds rows past M: they read as zero and must not be observed / stored
 
     i32x4 acc[TM][TNT];
 #pragma clang loop unroll(disable)
-    for (int nti = 0; nti < NTL; ++nti) {
-        const int nt = nidx(nti);
+    for (int nt = 0; nt < NTL; ++nt) {
+        // the zero-point correction (center - zp) * wsum[n] is the INITIAL accumulator: the first k-step's MFMAs read it as their C operand
+        // (one 4-register tuple per column fragment, shared by all 13 row fragments), so the epilogue adds nothing - the same integer either way
+        i32x4 cinit[TNT];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TNT; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
-        // ---- k-loop: no barrier, no LDS write; weight fragments BD k-steps ahead in registers
+        for (int j = 0; j < TNT; ++j) {
+            const int4 c = *reinterpret_cast<const int4*>(sCorr + nt * BN + wave * 48 + 16 * j + 4 * g);
+            cinit[j] = i32x4{c.x, c.y, c.z, c.w};
+        }
+        // ---- k-loop: no barrier, no LDS write; weight fragments one k-step ahead in registers
         auto kstep = [&](int kt, const i32x4 (&bc)[TNT]) {
             // (the strip is loop-invariant across column tiles: without this opaque zero in its address hipcc hoists all 78 fragment reads out of
             //  the nt loop - 312 registers, spilled to scratch)
             __builtin_amdgcn_sched_barrier(0);           // one scheduling region per k-step: merged regions rotate the accumulators through spare registers and spill
             int opaque = 0;
             asm volatile("" : "+v"(opaque));
-            const char* st = sA + opaque + kidx(kt) * IMGA;
+            // strip_off(16 i + r, g) == 1024 i + strip_off(r, g): one address register per k-step, the row fragment in the instruction's offset field
+            const char* st = sA + opaque + kt * IMGA + strip_off(r, g);
             i32x4 af[PF];
 #pragma unroll
-            for (int i = 0; i < PF - 1; ++i) af[i] = *reinterpret_cast<const i32x4*>(st + strip_off(16 * i + r, g));
+            for (int i = 0; i < PF - 1; ++i) af[i] = *reinterpret_cast<const i32x4*>(st + 1024 * i);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                // (pin the software pipeline: left to itself hipcc issues the fragment reads in pairs right in front of their MFMAs - lgkmcnt(1) after
-                //  two back-to-back reads - and the LDS latency of every fragment is exposed: 28 vs 17 us for the whole statistics pass)
-                if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
-                if (i + PF - 1 < TM && !NOA) af[(i + PF - 1) % PF] = *reinterpret_cast<const i32x4*>(st + strip_off(16 * (i + PF - 1) + r, g));
-                if constexpr (NOA) asm volatile("" : "+v"(af[i % (PF - 1)]));   // (timing-only arm: opaque, or the identical MFMA chains of different i are merged)
-                if constexpr (NOM) { asm volatile("" :: "v"(af[i % PF])); continue; }
+                // (pin the software pipeline: left to itself hipcc issues the fragment reads in pairs right in front of their MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + PF - 1 < TM) af[(i + PF - 1) % PF] = *reinterpret_cast<const i32x4*>(st + 1024 * (i + PF - 1));
 #pragma unroll
                 for (int j = 0; j < TNT; ++j)   // swapped roles: D[row = weight column 4 g + e][col = token r]
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bc[j], af[NOA ? i % (PF - 1) : i % PF], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bc[j], af[i % PF], kt == 0 ? cinit[j] : acc[i][j], 0, 0, 0);
             }
         };
+        // wave priorities (code passes): MFMA phase above every quantise phase, so a wave's k-loop runs dense under its SIMD partner's epilogue; between
+        // two waves that are both quantising, the one favoured alternates per column tile (at equal priority the older wave always wins and finishes
+        // ~20 k cycles before its partner, which then runs alone at the one-wave VALU rate): 45.1 -> 42.0 us (qkv), 57.0 -> 54.7 us (fc1)
+        if constexpr (MODE != 3) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            // request k-step kt + BD (of this column tile or the next); code passes request the next tile's first BD steps after their first
-            // staging round instead, when 84 accumulators are dead
-            if constexpr (!NOB) {
-                if (kt + BD < KT) load_b(nt, kidx(kt + BD), bb[(kt + BD) % (BD + 1)]);
-                else if (MODE == 3 && nti + 1 < NTL) load_b(nidx(nti + 1), kidx(kt + BD - KT), bb[(kt + BD) % (BD + 1)]);
-            }
-            kstep(kt, bb[NOB ? 0 : kt % (BD + 1)]);
-            if (kt == 2) stamp();   // half of the k-loop
+            // request k-step kt + 1 (of this column tile or the next: the next tile's first fragments are then in flight BEFORE the epilogue's
+            // stores - loads and stores complete in one in-order queue per wave)
+            if (kt + 1 < KT) load_b(nt, kt + 1, bb[(kt + 1) & 1]);
+            else if (nt + 1 < NTL) load_b(nt + 1, 0, bb[0]);
+            kstep(kt, bb[kt & 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        stamp();   // k-loop done
+        if constexpr (MODE != 3) {
+            if (((wave >> 2) ^ nt) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (wave is an SGPR: a scalar branch)
+        }
+        QV_STAMP();   // k-loop done
 
-        __builtin_amdgcn_sched_barrier(0);
         if constexpr (MODE == 3) {
             // integer min / max per column over this lane's 13 tokens, then the (monotone: ca > 0) float map once per column
+            int tid3 = threadIdx.x;                      // (opaque copy: the ragged strip's 13 row predicates are otherwise computed up front and spilled)
+            asm volatile("" : "+v"(tid3));
+            const int r3 = tid3 & 15, g3 = (tid3 & 63) >> 4;
 #pragma unroll
             for (int j = 0; j < TNT; ++j) {
                 int lo[4], hi[4];
@@ -256,20 +259,19 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
                     } else {
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
-                            const bool ok = m0 + 16 * i + r < p.M;
+                            const bool ok = m0 + 16 * i + r3 < p.M;
                             lo[e] = min(lo[e], ok ? acc[i][j][e] : 0x7fffffff);
                             hi[e] = max(hi[e], ok ? acc[i][j][e] : (int)0x80000000);
                         }
                     }
                 }
-                const Consts k = consts_of(nt, j, g);
-                const int kc[4] = {k.corr.x, k.corr.y, k.corr.z, k.corr.w};
+                const Consts k = consts_of(nt, j, g3);
                 const float ka[4] = {k.ca.x, k.ca.y, k.ca.z, k.ca.w}, kb[4] = {k.cb.x, k.cb.y, k.cb.z, k.cb.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (lo[e] <= hi[e]) {   // (this lane's token column holds at least one valid row)
-                        mn = fminf(mn, (float)(lo[e] + kc[e]) * ka[e] + kb[e]);
-                        mx = fmaxf(mx, (float)(hi[e] + kc[e]) * ka[e] + kb[e]);
+                        mn = fminf(mn, (float)lo[e] * ka[e] + kb[e]);
+                        mx = fmaxf(mx, (float)hi[e] * ka[e] + kb[e]);
                     }
             }
         } else {
@@ -277,97 +279,82 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
             // code = clamp(u, 0, qmax - qmin), in range <=> u == clamp(u)
             const float qinv = p.qp[1], zoff = p.qp[2] - (float)p.qmin, frange = (float)(p.qmax - p.qmin);
             const int tilebase = nbase + nt * BN;
-            // two staging rounds per column tile (rows 0 .. 111, then 112 .. 207): quantise in registers, 4 codes -> 1 dword -> LDS, barrier,
-            // 16-B copies into the output layout
-            auto round = [&](auto I0c, auto I1c) {
-                constexpr int I0 = decltype(I0c)::value, I1 = decltype(I1c)::value, ROWS = 16 * (I1 - I0);
-                strip_lds_barrier();                     // the previous round's store loop has read the staging area
-                // (lane-derived addresses are re-derived from an opaque copy of the thread id: kept live across the k-loop they are spilled, and every
-                //  reload from scratch is an s_waitcnt vmcnt(0) - a wait for all global stores in flight)
-                int tid = threadIdx.x;
-                asm volatile("" : "+v"(tid));
-                const int lane = tid & 63, r = lane & 15, g = lane >> 4;
+            // (lane-derived values are re-derived from an opaque copy of the thread id: kept live across the k-loop they are spilled, and every
+            //  reload from scratch is an s_waitcnt vmcnt(0) - a wait for all global stores in flight)
+            int tid2 = threadIdx.x;
+            asm volatile("" : "+v"(tid2));
+            const int lane2 = tid2 & 63, r2 = lane2 & 15, g2 = lane2 >> 4;
+            char* sW = sStage + wave * WSTG;             // this wave's staging area: [64][48 B] codes, then [64][16 B]: the 4 mask bits of fragment j, lane group g in byte 4 j + g
+            char* sWm = sW + 16 * CH * 48;
+            // output geometry of this wave's 48 columns
+            const int which = MODE == 7 ? tilebase / p.D : 0, cm0 = MODE == 7 ? tilebase % p.D + wave * 48 : 0, Hh = MODE == 7 ? p.D >> 6 : 0;
+            const float invT = MODE == 7 ? 1.0f / (float)p.code_T : 0.f;
+#pragma unroll
+            for (int c0 = 0; c0 < TM; c0 += CH) {        // chunks of 4 row fragments (64 rows); the last one holds 1 (16 rows)
+                const int nf = TM - c0 < CH ? TM - c0 : CH;
 #pragma unroll
                 for (int j = 0; j < TNT; ++j) {
-                    const Consts k = consts_of(nt, j, g);
-                    const int kc[4] = {k.corr.x, k.corr.y, k.corr.z, k.corr.w};
+                    const Consts k = consts_of(nt, j, g2);
                     const float ka[4] = {k.ca.x, k.ca.y, k.ca.z, k.ca.w}, kb[4] = {k.cb.x, k.cb.y, k.cb.z, k.cb.w};
 #pragma unroll
-                    for (int i = I0; i < I1; ++i) {
-                        const int rl = 16 * (i - I0) + r;
+                    for (int ii = 0; ii < CH; ++ii) {
+                        if (ii >= nf) continue;
+                        const int i = c0 + ii, rl = 16 * ii + r2;
                         uint32_t pk = 0, mk = 0;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = (float)(acc[i][j][e] + kc[e]) * ka[e] + kb[e];
+                        for (int e = 3; e >= 0; --e) {
+                            const float v = (float)acc[i][j][e] * ka[e] + kb[e];
                             const float u = rintf(v * qinv) + zoff, uc = __builtin_amdgcn_fmed3f(u, 0.0f, frange);
                             pk = __builtin_amdgcn_cvt_pk_u8_f32(uc, e, pk);
-                            mk |= (uint32_t)(u == uc) << e;
+                            // mk = 2 mk + (u == uc): the comparison's lane mask is the carry-in of ONE add (v_cndmask + v_or otherwise)
+                            const unsigned long long inr = __builtin_amdgcn_fcmpf(u, uc, 1 /* FCMP_OEQ */);
+                            asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(mk) : "s"(inr) : "vcc");
                         }
-                        if constexpr (NOSG) { asm volatile("" :: "v"(pk), "v"(mk)); continue; }
-                        *reinterpret_cast<uint32_t*>(sStage + rl * SROW + wave * 48 + 16 * j + 4 * g) = pk;
-                        // mask byte of 8 consecutive columns = the nibbles of lanes g = 2h (low) and 2h + 1 (high); BOTH lanes of a pair write the same
-                        // byte to the same address (a lane-dependent branch here would end the basic block after every fragment)
-                        const uint32_t other = (uint32_t)__shfl_xor((int)mk, 16, 64);
-                        const uint32_t lo4 = (g & 1) ? other : mk, hi4 = (g & 1) ? mk : other;
-                        reinterpret_cast<uint8_t*>(sMask)[rl * 48 + wave * 6 + 2 * j + (g >> 1)] = (uint8_t)(lo4 | (hi4 << 4));
+                        *reinterpret_cast<uint32_t*>(sW + rl * 48 + 16 * j + 4 * g2) = pk;
+                        // the lane's 4 mask bits as a byte of their own; the reader squeezes four of them into 16 bits.  (Pairing the nibbles of two
+                        // lanes here - ds_bpermute - put an LDS round trip with a full wait behind every fragment: 39 per tile, ~5 k cycles)
+                        reinterpret_cast<uint8_t*>(sWm)[rl * 16 + 4 * j + g2] = (uint8_t)mk;
                     }
                 }
-                stamp();   // staged (VALU + LDS writes issued)
-                if constexpr (NOSG || NOST) return;
-                strip_lds_barrier();
-                stamp();   // barrier passed
-                const int row0 = m0 + 16 * I0;
-                if constexpr (MODE == 4) {
-                    for (int idx = tid; idx < ROWS * 24; idx += 512) {
-                        const int rl = idx / 24, c = idx % 24, row = row0 + rl;
-                        const uint4 v = *reinterpret_cast<const uint4*>(sStage + rl * SROW + 16 * c);
-                        if (row < p.M) *reinterpret_cast<uint4*>(p.out8 + (int64_t)row * p.ldc + tilebase + 16 * c) = v;
-                    }
-                    for (int idx = tid; idx < ROWS * 3; idx += 512) {
-                        const int rl = idx / 3, c = idx % 3, row = row0 + rl;
-                        const uint4 v = *reinterpret_cast<const uint4*>(sMask + rl * 48 + 16 * c);
-                        if (row < p.M) *reinterpret_cast<uint4*>(p.out8_mask + (((int64_t)row * p.ldc + tilebase) >> 3) + 16 * c) = v;
-                    }
-                } else {
-                    // attention layout [b][h][q|k|v][t][d], head_dim 64: the tile's 384 columns are 6 whole heads of one of q / k / v
-                    const int which = tilebase / p.D, h0 = (tilebase % p.D) >> 6, Hh = p.D >> 6;
-                    const float invT = 1.0f / (float)p.code_T;
-                    for (int idx = tid; idx < ROWS * 24; idx += 512) {
-                        const int hh = idx / (ROWS * 4), rem = idx % (ROWS * 4), rl = rem >> 2, c4 = rem & 3, row = row0 + rl;
-                        const uint4 v = *reinterpret_cast<const uint4*>(sStage + rl * SROW + 64 * hh + 16 * c4);
-                        const int bb = (int)(((float)row + 0.5f) * invT), tt = row - bb * p.code_T;   // (exact for row < 2^22: checked by the launcher)
-                        const int64_t eo = ((((int64_t)bb * Hh + h0 + hh) * 3 + which) * p.code_T + tt) * 64 + 16 * c4;
-                        if (row < p.M) *reinterpret_cast<uint4*>(p.out8 + eo) = v;
-                    }
-                    for (int idx = tid; idx < ROWS * 6; idx += 512) {
-                        const int hh = idx / ROWS, rl = idx % ROWS, row = row0 + rl;
-                        const uint2 v = *reinterpret_cast<const uint2*>(sMask + rl * 48 + 8 * hh);
-                        const int bb = (int)(((float)row + 0.5f) * invT), tt = row - bb * p.code_T;
-                        const int64_t eo = ((((int64_t)bb * Hh + h0 + hh) * 3 + which) * p.code_T + tt) * 64;
-                        if (row < p.M) *reinterpret_cast<uint2*>(p.out8_mask + (eo >> 3)) = v;
+                // the wave's own LDS operations execute in order: the reads below see the writes above without a barrier (the wait + clobber keeps
+                // the compiler from reordering them)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int row0 = m0 + 16 * c0;
+#pragma unroll
+                for (int k3 = 0; k3 < 3; ++k3) {
+                    if (k3 * 64 >= nf * 48) continue;    // (16-row chunk: 48 pieces - the first instruction's lanes 0 .. 47)
+                    const int pc = lane2 + 64 * k3;      // 16-B piece: row pc / 3, chunk pc % 3 - the staging area read linearly
+                    const int rl = pc / 3, c = pc - 3 * rl, row = row0 + rl;
+                    const bool ok = pc < nf * 48 && row < p.M;
+                    const uint4 v = *reinterpret_cast<const uint4*>(sW + 16 * pc);   // (always inside the staging area)
+                    // mask bits of the same 16 columns: four nibble bytes (lane groups 0 .. 3 of fragment c) -> 16 bits
+                    uint32_t mx4 = *reinterpret_cast<const uint32_t*>(sWm + rl * 16 + 4 * c) & 0x0f0f0f0fu;
+                    mx4 = (mx4 | (mx4 >> 4)) & 0x00ff00ffu;
+                    const uint16_t mv = (uint16_t)((mx4 | (mx4 >> 8)) & 0xffffu);
+                    if constexpr (MODE == 4) {
+                        const int64_t eo = (int64_t)row * p.ldc + tilebase + wave * 48 + 16 * c;
+                        if (ok) {
+                            *reinterpret_cast<uint4*>(p.out8 + eo) = v;
+                            *reinterpret_cast<uint16_t*>(p.out8_mask + (eo >> 3)) = mv;
+                        }
+                    } else {
+                        // attention layout [b][h][q|k|v][t][d], head_dim 64: a 16-B piece lies inside one head's row
+                        const int cm = cm0 + 16 * c, hh = cm >> 6, d = cm & 63;
+                        const int bb_ = (int)(((float)row + 0.5f) * invT), tt = row - bb_ * p.code_T;   // (exact for row < 2^22: checked by the launcher)
+                        const int64_t eo = ((((int64_t)bb_ * Hh + hh) * 3 + which) * p.code_T + tt) * 64 + d;
+                        if (ok) {
+                            *reinterpret_cast<uint4*>(p.out8 + eo) = v;
+                            *reinterpret_cast<uint16_t*>(p.out8_mask + (eo >> 3)) = mv;
+                        }
                     }
                 }
-            };
-            if constexpr (NOEP) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TNT; ++j) asm volatile("" :: "v"(acc[i][j]));
-                if (nti + 1 < NTL) load_b(nidx(nti + 1), kidx(0), bb[0]);
-                continue;
+                asm volatile("" ::: "memory");           // (the next chunk's staging writes stay behind these reads)
             }
-            round(std::integral_constant<int, 0>{}, std::integral_constant<int, H0>{});
-            if (nti + 1 < NTL && !NOB) {
-#pragma unroll
-                for (int d = 0; d < BD; ++d) load_b(nidx(nti + 1), kidx(d), bb[d]);
-            }
-            stamp();   // stores of round 1 issued
-            round(std::integral_constant<int, H0>{}, std::integral_constant<int, TM>{});
-            stamp();   // stores of round 2 issued
+            QV_STAMP();   // tile's epilogue done
         }
     }
 
-    stamp();   // end
+    QV_STAMP();   // end
     if constexpr (MODE == 3) {
         float* sRed = reinterpret_cast<float*>(sStage);
         mn = wave_min(mn);
@@ -383,34 +370,17 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     }
 }
 
-template <int MODE, int NTL, int VAR>
-static void strip_launch_v(const I8StripArgs& a, hipStream_t st) {
-    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : 112 * 400 + 112 * 48);
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
-    (void)once;
-    k_i8_strip<MODE, NTL, VAR><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), 512, kLds, st>>>(a);
-}
 template <int MODE, int NTL>
-static void strip_launch(const I8StripArgs& a, hipStream_t st) {
+static void strip_launch(const I8StripArgs& a0, hipStream_t st) {
+    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : 8 * (64 * 48 + 64 * 16));
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+    (void)once;
+    I8StripArgs a = a0;
 #ifdef QV_STRIP_EXPERIMENTS
-    const char* e = getenv("QATVIT_STRIP_VAR");   // (read per launch: tools/bench_i8strip.py flips it between timed arms of one process)
-    const int v = e ? atoi(e) : 0;
-    if constexpr (NTL == 3) {
-        switch (v) {
-            case 32: return strip_launch_v<MODE, NTL, 32>(a, st);
-            case 36: return strip_launch_v<MODE, NTL, 36>(a, st);
-            case 16: return strip_launch_v<MODE, NTL, 16>(a, st);
-            case 96: return strip_launch_v<MODE, NTL, 96>(a, st);
-            case 104: return strip_launch_v<MODE, NTL, 104>(a, st);
-            case 128: return strip_launch_v<MODE, NTL, 128>(a, st);
-            case 256: return strip_launch_v<MODE, NTL, 256>(a, st);
-            case 512: return strip_launch_v<MODE, NTL, 512>(a, st);
-            case 1024: { I8StripArgs b = a; const char* d = getenv("QATVIT_STRIP_DBG"); b.dbg = d ? reinterpret_cast<unsigned long long*>(strtoull(d, nullptr, 0)) : nullptr; return strip_launch_v<MODE, NTL, 1024>(b, st); }
-            default: break;
-        }
-    }
+    const char* d = getenv("QATVIT_STRIP_DBG");   // (read per launch: tools/stamp_i8strip.py)
+    a.dbg = d ? reinterpret_cast<unsigned long long*>(strtoull(d, nullptr, 0)) : nullptr;
 #endif
-    strip_launch_v<MODE, NTL, 0>(a, st);
+    k_i8_strip<MODE, NTL><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), 512, kLds, st>>>(a);
 }
 
 // true when the strip kernel covers the request (the caller then launched it); false -> the general tall kernel

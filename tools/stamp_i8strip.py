@@ -31,11 +31,9 @@ qp = torch.tensor([0.35, 1 / 0.35, 120.0, 1.0], device=dev)
 out8 = torch.empty(M * N, dtype=torch.uint8, device=dev)
 mask = torch.empty(M * N // 8, dtype=torch.uint8, device=dev)
 dbg = torch.zeros(2 * 8 * 32, dtype=torch.int64, device=dev)
-os.environ["QATVIT_STRIP_VAR"] = "1024"
 os.environ["QATVIT_STRIP_DBG"] = hex(dbg.data_ptr())
-names = {3: ["entry", "own DMA", "strip ready"] + sum([[f"t{t} k-half", f"t{t} k-loop"] for t in range(3)], []) + ["end"],
-         7: ["entry", "own DMA", "strip ready"] + sum([[f"t{t} k-half", f"t{t} k-loop", f"t{t} r1 staged", f"t{t} r1 barrier", f"t{t} r1 stores", f"t{t} r2 staged", f"t{t} r2 barrier",
-                                                         f"t{t} r2 stores"] for t in range(3)], []) + ["end"]}
+names = {3: ["entry", "own DMA", "strip ready"] + [f"t{t} k-loop" for t in range(3)] + ["end"],
+         7: ["entry", "own DMA", "strip ready"] + sum([[f"t{t} k-loop", f"t{t} epilogue"] for t in range(3)], []) + ["end"]}
 for mode in (3, 7):
     for _ in range(5):   # warm
         dbg.zero_()
