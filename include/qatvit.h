@@ -28,6 +28,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define QATVIT_ABI_VERSION 3
 
@@ -161,13 +165,6 @@ int qatvit_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
  * them in a fixed order, applies scale and mask and adds to C: no atomics on C, bit-reproducible.  dbias always uses
  * atomics.  Q_lo, s1, W (fp32 [N,Kw], with w_scale/w_zp [1] or [N]), dbias, row_div may be NULL.  N % 128 == 0, Kw % 128 == 0. */
 int64_t qatvit_gemm_tn_scratch_bytes(void);
-/* qatvit_gemm_tn for a grid Q operand given as the int8 plane q - center that qatvit_gemm_nt_i8 reads (Qi8 [M,ldq], ldq in bytes; q_qp = {scale,
- * 1/scale, zero_point, enabled} of its quantizer on the device): the kernel widens it to the bf16 integers q - zero_point inside the workgroup -
- * bit-identical to qatvit_gemm_tn on that bf16 plane, half the bytes of the operand every N tile re-reads.  N % 128 == 0, Kw % 384 == 0, ldq % 16 == 0. */
-int qatvit_gemm_tn_i8q(const void* P_hi, const void* P_lo, const void* Qi8, const float* q_qp, int32_t center, float* C, int32_t M, int32_t N, int32_t Kw,
-                       int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp,
-                       int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes,
-                       void* stream);
 /* qatvit_gemm_tn for a Q operand that takes at most 256 distinct values (mlp.fc2's weight gradient: Q = gelu(fq(fc1 output))): Qc uint8 [M,ldq] =
  * table index per element (ldq in bytes), lutQ[256] = the bf16 (hi | lo << 16) pair per index.  The kernel expands the codes inside the workgroup:
  * bit-identical to qatvit_gemm_tn on the expanded (Q_hi, Q_lo) planes, 1 B instead of 4 B per Q element.  N % 128 == 0, Kw % 384 == 0, ldq % 16 == 0. */
@@ -341,6 +338,9 @@ int qatvit_profile_stop(const void* workspace, double* total_ms, int64_t* launch
 /* byte offset of a named intermediate tensor inside the workspace (tests); -1 if unknown */
 int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, int32_t block);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -126,7 +126,7 @@ int qatvit_i8_strip(int32_t mode, const void* A8, const void* B8f, const int32_t
     post.mode = mode;
     post.qp = out_qp; post.qmin = qmin; post.qmax = qmax; post.out8 = out8; post.out8_mask = out8_mask; post.code_T = code_T; post.code_hd = 64;
     post.lut_out = lut_out; post.lutq_out = lutq_out; post.out16_scale = out16_scale;
-    if (!launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, 384, lda, N, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream, &post, nullptr, true)) {
+    if (!launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, 384, lda, N, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream, &post, true)) {
         set_error("qatvit_i8_strip: unsupported arguments (mode %d M=%d N=%d lda=%d: need N %% 1152 == 0 or N %% 1536 == 0, lda %% 16 == 0, M < 2^22, "
                   "the mode's output pointers, qmax - qmin < 256; mode 7: (N / 3) %% 384 == 0, 0 < code_T < 1024)", mode, M, N, lda);
         return 1;
@@ -173,19 +173,6 @@ int qatvit_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, con
                              (hipStream_t)stream, scratch, scratch_bytes))
         return 1;
     QV_CHECK_LAUNCH("qatvit_gemm_tn_codes");
-    return 0;
-}
-
-int qatvit_gemm_tn_i8q(const void* P_hi, const void* P_lo, const void* Qi8, const float* q_qp, int32_t center, float* C, int32_t M, int32_t N, int32_t Kw,
-                       int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp,
-                       int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes,
-                       void* stream) {
-    QV_CHECK_ARG(P_hi && P_lo && Qi8 && q_qp && C, "qatvit_gemm_tn_i8q: null pointer argument");
-    QV_CHECK_ARG(!W || (w_scale && w_zp), "qatvit_gemm_tn_i8q: weight mask needs w_scale and w_zp");
-    if (launch_gemm_tn_i8q(P_hi, P_lo, Qi8, q_qp, center, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div,
-                           (hipStream_t)stream, scratch, scratch_bytes))
-        return 1;
-    QV_CHECK_LAUNCH("qatvit_gemm_tn_i8q");
     return 0;
 }
 

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
                                                           float* __restrict__ x_new, float* __restrict__ mean, float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           uint32_t* __restrict__ stats, int stat_slots, int64_t M, int D, int T,
-                                                          unsigned long long* __restrict__ maskbits, const QpTail tail) {
+                                                          unsigned long long* __restrict__ maskbits) {
     // maskbits (MODE 1, optional): the STE mask of fq(Y), one bit per element, as wave ballots - word [(row * NV + j) * 4 + e] holds in
     // bit `lane` the mask of column lane * 4 + 256 j + e.  k_ln_bwd_fq (same lane -> column mapping) reads it back with scalar loads,
     // so the backward never touches the fp32 Y again.
@@ -183,10 +183,7 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
     if (lane == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
     __syncthreads();
     const float bmn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3])), bmx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-    if (tail.counter) {   // (uniform) the last workgroup to get here also updates the observer of the LayerNorm output
-        __shared__ uint32_t s_last;
-        qparams_tail(tail, stats, stat_slots, gridDim.x, &s_last, bmn, bmx);
-    } else if (threadIdx.x == 0) stat_atomic(stats, stat_slots, bmn, bmx);
+    if (threadIdx.x == 0) stat_atomic(stats, stat_slots, bmn, bmx);
 }
 
 // h_q[row][c] = q(LN(x)[row][c]) - zp  as bf16 (the exact A operand of the following GEMM)
@@ -702,11 +699,10 @@ int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qm
 
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
                             float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
-                            int64_t M, int D, int T, hipStream_t st, void* maskbits, const QpTail* tail) {
+                            int64_t M, int D, int T, hipStream_t st, void* maskbits) {
     if (D % 4 != 0 || D > 256 * kMaxV) { set_error("resid_fq_lnstats: D=%d unsupported (need D%%4==0, D<=768)", D); return 1; }
-    const QpTail tl = tail ? *tail : QpTail{};
     unsigned long long* mbits = mode != 1 ? nullptr : reinterpret_cast<unsigned long long*>(maskbits);
-#define QV_RESID(MODE_, NV_) k_resid_fq_lnstats<MODE_, NV_><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T, mbits, tl)
+#define QV_RESID(MODE_, NV_) k_resid_fq_lnstats<MODE_, NV_><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T, mbits)
     const int nv = (D + 255) / 256;
     if (mode == 0) { if (nv == 1) QV_RESID(0, 1); else if (nv == 2) QV_RESID(0, 2); else QV_RESID(0, 3); }
     else if (mode == 1) { if (nv == 1) QV_RESID(1, 1); else if (nv == 2) QV_RESID(1, 2); else QV_RESID(1, 3); }

@@ -65,7 +65,6 @@ static int wparam(const Dims& d, int wi) {  // index of the weight tensor in par
 
 struct Plan {
     // byte offsets into the workspace
-    int64_t qp_cnt;   // one ticket counter per activation quantizer (producer tails)
     int64_t stats, qp_act, qp_w, imgq, Y0, meanF, rstdF, hq, logits_pre;
     int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1q, qkv, O_hi, O_lo, lse, Yproj, h2q, Y1, G_hi, G_lo, Y2, mproj, m2, qkv8, qkvm, G8, glut, Y1m, glutq;  // per-block base, stride blk (mproj / m2: STE mask bits of Yproj / Y2)
     int64_t blk_stride;
@@ -101,7 +100,6 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->stats = take(p->stats_words * 4);
     p->qp_act = take((int64_t)d.n_act * 4 * 4);
     p->qp_w = take(wqp_floats * 4);
-    p->qp_cnt = take((int64_t)d.n_act * 4);
     p->imgq = take((int64_t)d.B * d.np * d.Kpe * 2);
     p->Y0 = take((int64_t)d.B * d.np * D * 4);
     p->meanF = take(M * 4); p->rstdF = take(M * 4);
@@ -243,14 +241,6 @@ static bool fc2w_codes() {
     return on != 0;
 }
 
-// QATVIT_TNW_I8=1: the weight gradients with a grid X operand (qkv, fc1, patch embedding) read X as the int8 plane q - center the forward GEMM read,
-// widened inside the kernel (launch_gemm_tn_i8q: half the bytes of the operand every N tile re-reads; the same bits), instead of the bf16 integers
-// q - zp.  Default 0: measured 140 vs 118 us per launch - the widening and the second barrier cost more than the 24 KB of LDS-DMA per step they save
-static bool tnw_i8() {
-    static const int on = getenv("QATVIT_TNW_I8") ? atoi(getenv("QATVIT_TNW_I8")) : 0;
-    return on != 0;
-}
-
 // QATVIT_WBATCH=0: one launch triple per weight instead of three multi-tensor launches (tuning; also the path of models deeper than the
 // tables hold).  That path does not write the fp16 weight copies, so the fp16-pair forward GEMMs are off with it.
 static bool w_batched(const Dims& d) {
@@ -271,15 +261,6 @@ static bool qkv_2pass(const qatvit_cfg& c) {
     static const int on = getenv("QATVIT_QKV_2PASS") ? atoi(getenv("QATVIT_QKV_2PASS")) : 1;
     const int hd = c.embed_dim / c.num_heads;
     return on != 0 && attn_codes(c) && use_i8() && (3 * c.embed_dim) % 384 == 0 && c.embed_dim % 64 == 0 && hd % 32 == 0;
-}
-
-// QATVIT_QP_TAIL=1: the observer / qparams update of an activation quantizer inside the producer of its statistics (its last workgroup runs it:
-// qv_qparams.h) instead of as a single-wave launch of its own right behind that producer (74 per step, 4.9 us each).  Default 0: measured
-// 24.14 vs 23.84 ms - the returning atomics + ticket at the end of EVERY workgroup and the double-precision qparams arithmetic in the last one cost
-// what the launch costs (and a release fence in front of the ticket, an L2 write-back per workgroup on this multi-XCD part, cost 40 us per launch)
-static bool qp_tail() {
-    static const int on = getenv("QATVIT_QP_TAIL") ? atoi(getenv("QATVIT_QP_TAIL")) : 0;
-    return on != 0;
 }
 
 // QATVIT_LNB_FUSE=0: the LayerNorm backward as its own kernel behind the fc1 / qkv dgrad GEMM (re-reads the fp32 gradient those wrote) instead
@@ -310,22 +291,15 @@ struct Ctx {
     int a_norm() const { return A_BLOCK0 + AB_COUNT * d.depth; }
     int a_head() const { return a_norm() + 1; }
     int widx(int blk_i, int k) const { return 1 + WB_COUNT * blk_i + k; }
-    // the observer / qparams update of activation quantizer ai as the tail of the producer of its statistics
-    QpTail tail(int ai) const {
-        const qatvit_fq& f = act[ai];
-        return QpTail{at<uint32_t>(p.qp_cnt) + ai, f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const,
-                      c.act_qmin, c.act_qmax, act_qp(ai)};
-    }
-    // ... or as its own launch right behind that producer (QATVIT_QP_TAIL=0, and producers without a tail)
+    // the observer / qparams update of activation quantizer ai: its own single-wave launch right behind the producer of its statistics
     void qparams_after(int ai, bool produced_stats) const {
-        if (produced_stats && !qp_tail()) qparams_act(ai);
+        if (produced_stats) qparams_act(ai);
     }
-    // launch_resid_fq_lnstats with the LayerNorm-output quantizer ai_stats updated behind it (tail or own launch)
+    // launch_resid_fq_lnstats with the LayerNorm-output quantizer ai_stats updated behind it
     int resid_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, const float* cls, const float* pos, float* x_new, float* mean,
                       float* rstd, const float* gamma, const float* beta, int ai_stats, void* maskbits = nullptr) const {
-        const QpTail tl = tail(ai_stats);
         if (launch_resid_fq_lnstats(mode, x_prev, Y, qpY, c.act_qmin, c.act_qmax, cls, pos, x_new, mean, rstd, gamma, beta, c.ln_eps, act_stats(ai_stats),
-                                    kStatSlots, d.M, d.D, d.T, st, maskbits, qp_tail() ? &tl : nullptr))
+                                    kStatSlots, d.M, d.D, d.T, st, maskbits))
             return 1;
         qparams_after(ai_stats, true);
         return 0;
@@ -341,12 +315,10 @@ struct Ctx {
                    const NTPost* post = nullptr, bool with_stats = true) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        const QpTail tl = tail(ai_out);
         {
             ProfScope ps(prof, A_lo ? 1 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);   // a statistics-only pass is issued, not algorithmic, work
             if (launch_gemm_nt(A_hi, A_lo, at<void>(p.w_off[wi]), C, M, N, K, K, K, N, s_act, c.w_per_channel ? nullptr : f.scale,
-                               c.w_per_channel ? f.scale : nullptr, bias, with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, nullptr, post, false,
-                               with_stats && qp_tail() ? &tl : nullptr))
+                               c.w_per_channel ? f.scale : nullptr, bias, with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, nullptr, post, false))
                 return 1;
         }
         qparams_after(ai_out, with_stats);
@@ -357,11 +329,10 @@ struct Ctx {
     int linear_fwd_f16(const void* A16_hi, const void* A16_lo, const float* pair_scale, int M, int wi, const float* bias, float* C, int ai_out) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        const QpTail tl = tail(ai_out);
         {
             ProfScope ps(prof, 1, 2.0 * M * N * K, st);
             if (launch_gemm_nt(A16_hi, A16_lo, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
-                               c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, nullptr, nullptr, true, qp_tail() ? &tl : nullptr))
+                               c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, nullptr, nullptr, true))
                 return 1;
         }
         qparams_after(ai_out, true);
@@ -371,11 +342,10 @@ struct Ctx {
     int linear_fwd_codes(const void* A8, const uint32_t* lut, const float* pair_scale, int M, int wi, const float* bias, float* C, int ai_out) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
-        const QpTail tl = tail(ai_out);
         {
             ProfScope ps(prof, 1, 2.0 * M * N * K, st);
             if (launch_gemm_nt_codes(A8, lut, at<void>(p.w16_off[wi]), C, M, N, K, K, K, N, pair_scale, c.w_per_channel ? nullptr : f.scale,
-                                     c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st, qp_tail() ? &tl : nullptr))
+                                     c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, st))
                 return 1;
         }
         qparams_after(ai_out, true);
@@ -393,12 +363,11 @@ struct Ctx {
         int N, K; wshape(d, wi, &N, &K);
         if (!use_i8() || N % 384 != 0 || K % 64 != 0) return linear_fwd(A16, nullptr, M, wi, a_qp, bias, C, ai_out, post, with_stats);
         const qatvit_fq& f = wfq[wi];
-        const QpTail tl = tail(ai_out);
         {
             ProfScope ps(prof, !post ? 2 : post->mode == 3 ? 7 : post->mode == 4 ? 8 : post->mode == 7 ? 9 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);
             if (launch_gemm_nt_i8(A8, at<void>(p.w8_off[wi]), at<int32_t>(p.wsum_off[wi]), a_qp, center(), C, M, N, K, K, K, N, a_qp,
                                   c.w_per_channel ? nullptr : f.scale, c.w_per_channel ? f.scale : nullptr, bias,
-                                  with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, post, with_stats && qp_tail() ? &tl : nullptr,
+                                  with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, post,
                                   (w_batched(d) && p.w8f_off[wi] >= 0) ? at<void>(p.w8f_off[wi]) : nullptr))
                 return 1;
         }
@@ -424,15 +393,11 @@ struct Ctx {
                                     c.w_qmax, db, c.w_per_channel ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
     }
     // wgrad: dW[N,K] += sum_m dY[m,N] X[m,K] * s_x, masked by the weight FQ; db[N] += sum_m dY
-    // (X8: the grid operand once more as int8 q - center, with s_x = the qparams of its quantizer: read instead of X_hi when the tile allows it)
     int linear_wgrad(const void* dY_hi, const void* dY_lo, int M, int wi, const void* X_hi, const void* X_lo, const float* s_x, float* dW, float* db,
-                     bool dy_scaled = true, const void* X8 = nullptr) const {
+                     bool dy_scaled = true) const {
         int N, K; wshape(d, wi, &N, &K);
         const qatvit_fq& f = wfq[wi];
         ProfScope ps(prof, X_lo ? 6 : 3, 2.0 * M * N * K, st);   // grid X (qkv / fc1 / patch-embed wgrad) | split X (proj / fc2 wgrad)
-        if (X8 && !X_lo && s_x && tnw_i8() && use_i8() && N % 128 == 0 && K % 384 == 0)
-            return launch_gemm_tn_i8q(dY_hi, dY_lo, X8, s_x, center(), dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
-                                      c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
         return launch_gemm_tn(dY_hi, dY_lo, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
                               c.w_qmin, c.w_qmax, db, (c.w_per_channel && dy_scaled) ? f.scale : nullptr, st, at<float>(p.tn_scratch), kTnScratchBytes);
     }
@@ -724,7 +689,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 if (x.linear_dgrad(dYh, dYl, M, w_fc2, nullptr, &post)) return 1;
             }
             if (x.linear_wgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.blk<void>(p.h2q, i), nullptr, x.act_qp(x.aidx(i, AB_N2)),
-                               BG(i, B_FC1W), BG(i, B_FC1B), true, x.blk<void>(p.h2q8, i)))
+                               BG(i, B_FC1W), BG(i, B_FC1B)))
                 return 1;
             const LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dYh, dYl};
             const bool lnb = ln_fuse && lnb_fuse() && d.D == 384;   // the dgrad tile holds whole LayerNorm rows: its epilogue IS the LayerNorm backward
@@ -752,7 +717,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                                 attn_codes(c) ? x.blk<void>(p.qkvm, i) : nullptr))
                 return 1;
             if (x.linear_wgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.blk<void>(p.h1q, i), nullptr, x.act_qp(x.aidx(i, AB_N1)),
-                               BG(i, B_QKVW), BG(i, B_QKVB), true, x.blk<void>(p.h1q8, i)))
+                               BG(i, B_QKVW), BG(i, B_QKVB)))
                 return 1;
             const LnBwdNext nx_fc2{i > 0 ? x.blk<void>(p.m2, i - 1) : nullptr, i > 0 ? x.dy_colscale(x.widx(i - 1, WB_FC2)) : nullptr, dYh, dYl};
             if (lnb) {
@@ -775,7 +740,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                              d.T, d.D, st);
             // (no dgrad into the image, so dY0 is not pre-scaled by the per-channel weight scale)
             if (x.linear_wgrad(x.at<void>(p.dY0_hi), x.at<void>(p.dY0_lo), d.B * d.np, 0, x.at<void>(p.imgq), nullptr, x.act_qp(A_IN), G(P_PE_W),
-                               G(P_PE_B), false, x.at<void>(p.imgq8)))
+                               G(P_PE_B), false))
                 return 1;
         }
     }
@@ -805,7 +770,6 @@ int qatvit_student_init(const qatvit_cfg* cfg, void* workspace, void* stream) {
     Plan p;
     if (make_plan(*cfg, &p)) return 1;
     launch_ws_init(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + p.stats), p.stats_words / 2, (hipStream_t)stream);
-    launch_zero_i32(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + p.qp_cnt), dims_of(*cfg).n_act, (hipStream_t)stream);   // tail tickets
     QV_CHECK_LAUNCH("qatvit_student_init");
     return 0;
 }

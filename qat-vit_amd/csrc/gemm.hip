@@ -123,9 +123,6 @@ struct NTArgs {
     int embed_np;
     uint8_t* out8;
     int code_T, code_hd;
-    // 4-wave tiles, two workgroups per CU: delay the second workgroup of every CU (dispatch slots 256 .. 511) by this many shader cycles so
-    // that one workgroup's store-bound epilogue runs under the other's k-loop instead of both epilogues colliding (0 = off)
-    int stagger_cycles;
     // mode 8 (N == BN == D: the tile holds whole rows): the LayerNorm BACKWARD of the tensor this dgrad differentiates, fused - the fp32
     // gradient w.r.t. the fake-quantised LayerNorm output never goes to memory.  With dH = acc * alpha:
     //   g = dH * mask(LN(x)) ; dx_out = dx_in + LNbwd(g) ; dgamma += sum_rows g * xhat ; dbeta += sum_rows g ;
@@ -148,8 +145,6 @@ struct NTArgs {
     // mode 7 (optional, training): the STE mask bit of every element (t = rint(v / s) + zp inside [qmin, qmax]) next to the codes, one bit per
     // element in the same [b][h][which][t][d] order (bit d % 8 of byte (... * hd + d) / 8) - what the attention forward writes when it quantises itself
     uint8_t* out8_mask;
-    // with stats: the last workgroup of the launch also runs the observer / qparams update of the output's quantizer (qv_qparams.h)
-    QpTail tail;
     // mode 9 = mode 5 with the fc1 codes as ONE byte per element (the plane fc2's forward reads: post_code8 [M, ldc]) + the STE mask as one bit per
     // element (post_mask: bit c % 8 of byte (row * ldc + c) / 8) instead of the uint16 plane: 1.125 instead of 2 B per element read here, and the
     // fc1 storing pass (mode 4 with out8_mask) writes 0.125 instead of 2 B per element for the backward
@@ -436,14 +431,11 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
             }
             continue;   // next slab (the lds_barrier at its top orders these reads of sC before the next staging)
         }
-#ifndef QV_EPI_U
-#define QV_EPI_U 4
-#endif
-        if constexpr ((PM == 0 || P4 || P5 || PM == 7) && QV_EPI_U > 1) {
+        if constexpr (PM == 0 || P4 || P5 || PM == 7) {
             // Software-pipelined store loop: U iterations' LDS reads (staged values, codes), then their table lookups, then the stores.
             // The rolled loop below is one LDS round trip (two with a table) per 16 B stored at two waves per SIMD; the row guard moves
             // onto the stores so that no branch separates the reads.
-            constexpr int U = PM == 10 ? 2 : QV_EPI_U, NT_ = NW * 64;   // (the fp16-plane form keeps three lookups per element live: four iterations in flight spill)
+            constexpr int U = PM == 10 ? 2 : 4, NT_ = NW * 64;   // (the fp16-plane form keeps three lookups per element live: four iterations in flight spill)
             const int limit = rows_h * C4;
             for (int base = tid; base < limit; base += U * NT_) {
                 float4 v[U];
@@ -736,28 +728,12 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
         float* smx = smn + NW;
         if (lane == 0) { smn[wave] = mn; smx[wave] = mx; }
         lds_barrier();
-        bool tailed = false;
-        if constexpr (PM == 0 || PM == 3) tailed = p.tail.counter != nullptr;   // (uniform)
         if (tid == 0) {
 #pragma unroll
             for (int w = 1; w < NW; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); }
-            if (!tailed) stat_atomic(p.stats, p.stat_slots, mn, mx);
-        }
-        if constexpr (PM == 0 || PM == 3) {
-            if (tailed) qparams_tail(p.tail, p.stats, p.stat_slots, gridDim.x, reinterpret_cast<uint32_t*>(smem) + 2 * NW, mn, mx);
+            stat_atomic(p.stats, p.stat_slots, mn, mx);
         }
     }
-}
-
-// timing-only ablations: keep the accumulators alive without an epilogue
-template <int TM, int TNT, typename ACC>
-__device__ inline void nt_keep_alive(const NTArgs& p, ACC (&acc)[TM][TNT]) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TNT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t == 1.2345e-30f) p.C[1 << 20] = t;
 }
 
 // LDS image of a BK = 32 tile: two 64-B tile rows share one 128-B LDS row; chunk index ((row & 1) * 4 + k-chunk) XOR (LDS row & 7).
@@ -766,14 +742,10 @@ __device__ inline int nt_off32(int row, int chunk) {
     return R * 128 + (((((row & 1) << 2) | chunk) ^ (R & 7)) << 4);
 }
 
-// ABL: timing-only ablations (tools/bench_gemm.py, tools/stamp_nt.py): 1 = no LDS reads / MFMA, 2 = no DMA, 3 = no epilogue,
-// 5 = s_memtime stamps of the k-loop into p.C (no epilogue)
-// NWD: number of waves (the first NWD, the older wave of each SIMD pair) that issue the LDS-DMA pieces; 0 = all of them
 // F16: both operands hold fp16 bit patterns (a float A operand as an fp16 (hi, lo) pair pre-scaled by a power of two, the weight integers
 // as fp16): v_mfma_f32_16x16x32_f16 - same tile, same LDS images, same rate as the bf16 form, 2^-23 instead of 2^-17 per A element.
-template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int ABL = 0, int WN = 2, int TNT = 4, int BK = 64, int NWD_ = 0, int PM = 0, bool I8 = false,
-          bool F16 = false>
-__global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {   // two waves per SIMD (one 8-wave or two 4-wave workgroups)
+template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int WN = 2, int TNT = 4, int BK = 64, int PM = 0, bool I8 = false, bool F16 = false>
+__global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {   // two waves per SIMD
     // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
     static_assert(BK == 64 || BK == 32, "BK");
     static_assert(!I8 || (TA == 1 && TB == 1 && TM > 4 && BK == 32), "int8 operands: tall single-image tiles only");
@@ -787,7 +759,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows per piece");
     constexpr int PAI = BM / RPP, PBI = BN / RPP;   // pieces per A / B image
     constexpr int NP = TA * PAI + TB * PBI;         // pieces per k-tile, dealt round-robin to the waves
-    constexpr int NWD = NWD_ ? NWD_ : NW;
+    constexpr int NWD = NW;                         // every wave issues its share of the DMA pieces
     constexpr int NDF = NP / NWD, NDX = NP % NWD;   // every issuing wave issues NDF, waves < NDX one more
     constexpr int NPW = NDF + (NDX ? 1 : 0);        // DMA slots per wave per k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -798,10 +770,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     const int tilesN = p.N / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
-    if (WM * WN == 4 && p.stagger_cycles > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {   // (uniform; bounded: the clock always advances)
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)p.stagger_cycles) __builtin_amdgcn_s_sleep(32);
-    }
 
     const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(p.A0, (int64_t)p.M * p.lda * 2);
     const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(TA == 2 ? p.A1 : p.A0, (int64_t)p.M * p.lda * 2);
@@ -847,35 +815,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     const int nk = p.K / BK;
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-        if (ABL != 2 && ABL != 6 && s < nk) issue(s);
+        if (s < nk) issue(s);
 
     for (int kt = 0; kt < nk; ++kt) {
-        uint64_t t0 = 0, t1 = 0, t2 = 0;
-        if constexpr (ABL == 5 || ABL == 6) t0 = __builtin_amdgcn_s_memtime();
         // tile kt has landed once at most the (NSTAGE-2) younger tiles' DMAs are still outstanding
         if (NSTAGE >= 3 && kt + NSTAGE - 2 < nk) {
             if (NDX && wave < NDX) wait_vmcnt<(NSTAGE - 2) * (NDF + 1)>();
             else wait_vmcnt<(NSTAGE - 2) * NDF>();
         } else wait_vmcnt<0>();
-        if constexpr (ABL == 5 || ABL == 6) t1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone left buffer (kt-1)%NSTAGE
         asm volatile("" ::: "memory");
-        if constexpr (ABL == 5 || ABL == 6) {
-            t2 = __builtin_amdgcn_s_memtime();
-            if (lane == 0 && kt < 48 && (blockIdx.x == 0 || blockIdx.x == 100)) {
-                uint64_t* dbg = reinterpret_cast<uint64_t*>(p.C) + (((blockIdx.x ? 1 : 0) * NW + wave) * 48 + kt) * 3;
-                dbg[0] = t0; dbg[1] = t1; dbg[2] = t2;
-            }
-        }
         constexpr bool SPREAD = TM > 4 && TM >= NPW;   // tall tiles: DMA issue spread between the MFMA groups below
-        const bool more = ABL != 2 && ABL != 6 && kt + NSTAGE - 1 < nk;
+        const bool more = kt + NSTAGE - 1 < nk;
         if (!SPREAD && more) issue(kt + NSTAGE - 1);
         const char* st = smem + (kt % NSTAGE) * STAGE;
         const char* sB = st + TA * IMGA;
-        if constexpr (ABL == 1) {
-            if (SPREAD && more) issue(kt + NSTAGE - 1);
-            continue;
-        }
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 bfrag[TNT], blo[TB == 2 ? TNT : 1];
@@ -944,10 +898,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
         }
     }
     __syncthreads();  // all fragment reads done: the ring is free for the epilogue
-    if constexpr (ABL == 3 || ABL == 5 || ABL == 6) {
-        nt_keep_alive<TM, TNT>(p, acc);
-        return;
-    }
     // the staging slab (+ LUT, + the codes of mode 5) must fit inside the ring; mode 5 prefers 48 rows with two code buffers to 64 with one
     constexpr int RING_ = NSTAGE * STAGE;
     constexpr bool PM5_48 = PM == 5 && RING_ >= 48 * (BN + 4) * 4 + 1024 + 2 * 48 * BN * 2 && RING_ < 64 * (BN + 4) * 4 + 1024 + 2 * 64 * BN * 2;
@@ -960,16 +910,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {  
     nt_epilogue<WM, WN, TM, TNT, SLAB, PM, EPI_LDS, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
 }
 
-// ============================================================================ NT, B operand through registers
-// The same 208 x 384 tile (1 x 8 waves, each 208 rows x 48 columns), but only the A operand goes through LDS.  In the 1 x 8 wave layout a
-// B (weight) fragment belongs to ONE wave - wave wn needs rows 48 wn .. 48 wn + 47 of the weight and nobody else does - so staging the
-// 384-row B tile in LDS buys no reuse: it only pushes 24 KB per k-step through the LDS-DMA path, which delivers ~25 GB/s per CU (6.4 TB/s
-// chip-wide, L2 hits included) and was the bound of every K >= 1152 launch.  Here each lane fetches its 16 bytes of the next k-step's three B
-// fragments (MFMA B layout: row = lane & 15, 8-element k chunk = lane >> 4) straight from L2 into registers with buffer_load_dwordx4 one
-// k-step ahead (two register sets), and the ring holds A only: half the LDS-DMA bytes and instructions, no B fragment ds_reads, a deeper ring.
-// The loads are inline asm (beside LDS-DMA hipcc waits vmcnt(0) for every ordinary load result: the ring would drain each step); completion
-// is counted by hand in the one in-order vmcnt queue: B(kt) is issued at the top of step kt-1 BEFORE that step's A pieces, so "B(kt) and
-// everything older (A tile kt included, ring depth >= 3) has arrived" == "at most this wave's A pieces of step kt-1 are outstanding".
+// register-destination loads beside LDS-DMA: inline asm (hipcc waits vmcnt(0) for every ordinary load result while a DMA is in flight), counted by hand
 __device__ inline v4i32 load16_asm(v4i32 rsrc, uint32_t voff) {
     v4i32 v;
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
@@ -980,125 +921,6 @@ __device__ inline v4i32 load16_asm(v4i32 rsrc, uint32_t voff) {
 template <int N> __device__ inline void wait_vmcnt_b() {
     wait_vmcnt<N>();
     __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int TA, int NSTAGE, int PM, bool I8, bool F16, int LDSB>
-__global__ __launch_bounds__(512, 2) void k_gemm_nt_br(const NTArgs p) {
-    constexpr int TM = 13, TNT = 3, WN = 8, BM = 208, BN = 384;
-    constexpr int IMGA = BM * 64;                     // one [208][32 x 2 B] image
-    constexpr int STAGE = TA * IMGA;
-    constexpr int PAI = BM / 16;                      // 1-KiB pieces per image (16 tile rows of 64 B)
-    constexpr int NP = TA * PAI, NDF = NP / 8, NDX = NP % 8, NPW = NDF + (NDX ? 1 : 0);
-    static_assert(NSTAGE >= 3 && NSTAGE <= 4 && NSTAGE * STAGE <= LDSB, "ring");
-    static_assert(!(I8 && (TA != 1 || F16)), "operand kinds");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int tilesN = p.N / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tilesN) * BM, n0 = (tile % tilesN) * BN;
-    const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(p.A0, (int64_t)p.M * p.lda * 2);
-    const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(TA == 2 ? p.A1 : p.A0, (int64_t)p.M * p.lda * 2);
-    const v4i32 rB = make_rsrc_v(p.B, (int64_t)p.N * p.ldb * 2);
-    const int lR = lane >> 3, lL = (lane & 7) ^ lR;
-    const int prow = 2 * lR + (lL >> 2), pk = lL & 3;
-    uint32_t boff[TNT];
-#pragma unroll
-    for (int j = 0; j < TNT; ++j) boff[j] = (uint32_t)(((int64_t)(n0 + wave * (16 * TNT) + 16 * j + r) * p.ldb + 8 * g) * 2);
-
-    auto issue_piece = [&](int kt, int c) {   // this wave's c-th A piece of k-tile kt
-        char* st = smem + (kt % NSTAGE) * STAGE;
-        const int pc = c * 8 + wave;
-        if (c == NDF && wave >= NDX) return;
-        const int img = (TA == 2 && pc >= PAI) ? 1 : 0, q = pc - img * PAI;
-        const uint32_t off = (uint32_t)(((int64_t)(m0 + q * 16 + prow) * p.lda + kt * 32 + pk * 8) * 2);
-        if (img == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lds_void*)(st + q * 1024), 16, off, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (lds_void*)(st + IMGA + q * 1024), 16, off, 0, 0, 0);
-    };
-    auto load_b = [&](int kt, v4i32 (&b)[TNT]) {
-#pragma unroll
-        for (int j = 0; j < TNT; ++j) b[j] = load16_asm(rB, boff[j] + (uint32_t)kt * 64u);
-    };
-
-    using acc_t = std::conditional_t<I8, i32x4, f32x4>;
-    acc_t acc[TM][TNT];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TNT; ++j) acc[i][j] = acc_t{};
-
-    const int nk = p.K / 32;
-    v4i32 b0[TNT], b1[TNT];
-    // issue order (one in-order vmcnt queue per wave):  A(0) .. A(NSTAGE-3) B(0) A(NSTAGE-2) | step 0: B(1) A(NSTAGE-1) | step 1: B(2) A(NSTAGE) | ...
-    // so at the top of EVERY step kt, B(kt) and everything older (A tile kt included) has arrived once at most the ONE A tile issued after
-    // B(kt) - tile kt + NSTAGE - 2, if it exists - is outstanding
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 2; ++s)
-        if (s < nk) {
-#pragma unroll
-            for (int c = 0; c < NPW; ++c) issue_piece(s, c);
-        }
-    load_b(0, b0);
-    if (NSTAGE - 2 < nk) {
-#pragma unroll
-        for (int c = 0; c < NPW; ++c) issue_piece(NSTAGE - 2, c);
-    }
-
-    auto step = [&](int kt, v4i32 (&bc)[TNT], v4i32 (&bn)[TNT]) {
-        const bool big = NDX && wave < NDX;
-        if (kt + NSTAGE - 2 >= nk) wait_vmcnt_b<0>();
-        else if (big) wait_vmcnt_b<NDF + 1>();
-        else wait_vmcnt_b<NDF>();
-        __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in LDS; everyone left buffer (kt-1) % NSTAGE
-        asm volatile("" ::: "memory");
-        if (kt + 1 < nk) load_b(kt + 1, bn);
-        const bool more = kt + NSTAGE - 1 < nk;
-        const char* st = smem + (kt % NSTAGE) * STAGE;
-        constexpr int PF = 3;
-        bf16x8 af[PF][TA];
-        auto read_a = [&](int i) {
-#pragma unroll
-            for (int t = 0; t < TA; ++t) af[i % PF][t] = *reinterpret_cast<const bf16x8*>(st + t * IMGA + nt_off32(16 * i + r, g));
-        };
-#pragma unroll
-        for (int i = 0; i < PF - 1; ++i) read_a(i);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            // (pin the group order: without the LDS-DMA issues in between - the last NSTAGE-1 steps - hipcc hoists all 13 groups' fragment
-            //  reads to the top of the step, 52-104 live registers, and spills)
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-#pragma unroll
-                for (int c = 0; c < NPW; ++c)
-                    if ((c * TM) / NPW == i) issue_piece(kt + NSTAGE - 1, c);
-            }
-            if (i + PF - 1 < TM) read_a(i + PF - 1);
-#pragma unroll
-            for (int t = 0; t < TA; ++t)
-#pragma unroll
-                for (int j = 0; j < TNT; ++j) {
-                    if constexpr (I8) {
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[i % PF][t]), __builtin_bit_cast(i32x4, bc[j]), acc[i][j], 0, 0, 0);
-                    } else if constexpr (F16) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i % PF][t]), __builtin_bit_cast(f16x8, bc[j]), acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % PF][t], __builtin_bit_cast(bf16x8, bc[j]), acc[i][j], 0, 0, 0);
-                    }
-                }
-        }
-    };
-    // (nk is even for every shape of the step: K % 64 == 0 is checked by the launcher)
-#pragma clang loop unroll(disable)
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, b0, b1);
-        step(kt + 1, b1, b0);
-    }
-    __syncthreads();  // all fragment reads done: the LDS is free for the epilogue
-    constexpr bool PM5_48 = PM == 5 && LDSB >= 48 * (BN + 4) * 4 + 1024 + 2 * 48 * BN * 2 && LDSB < 64 * (BN + 4) * 4 + 1024 + 2 * 64 * BN * 2;
-    constexpr int SLAB = PM5_48 ? 48 : 64;
-    static_assert(LDSB >= SLAB * (BN + 4) * 4 + 2048, "LDS too small for the epilogue slab");
-    nt_epilogue<1, WN, TM, TNT, SLAB, PM, LDSB, I8>(p, acc, smem, m0, n0, tid, lane, wave, 0, wave, r, g);
 }
 
 
@@ -1210,7 +1032,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_ac(const NTArgs p) {
         for (int i = 0; i < PF - 1; ++i) read_a(i);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            __builtin_amdgcn_sched_barrier(0);        // pin the group order (see k_gemm_nt_br)
+            __builtin_amdgcn_sched_barrier(0);        // pin the group order: without it hipcc hoists all 13 groups' fragment reads to the top of the step and spills
             if (more) {
 #pragma unroll
                 for (int c = 0; c < NPW; ++c)
@@ -1247,18 +1069,16 @@ static void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-// one kernel instantiation per epilogue variant (NTArgs::pm); the timing-only ablations exist for the plain epilogue only
-template <int TA, int NS, int WM, int TM, int TB, int ABL, int WN, int TNT, int BK, int NWD, bool I8 = false, bool F16 = false>
+// one kernel instantiation per epilogue variant (NTArgs::pm)
+template <int TA, int NS, int WM, int TM, int TB, int WN, int TNT, int BK, bool I8 = false, bool F16 = false>
 static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
-#define QV_PM(PM_)                                                                                                       \
-    do {                                                                                                                 \
-        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16>, lds), true);   \
-        (void)once;                                                                                                      \
-        k_gemm_nt<TA, NS, WM, TM, TB, ABL, WN, TNT, BK, NWD, PM_, I8, F16><<<grid, WM * WN * 64, lds, st>>>(a);          \
+#define QV_PM(PM_)                                                                                             \
+    do {                                                                                                       \
+        static bool once = (allow_lds(k_gemm_nt<TA, NS, WM, TM, TB, WN, TNT, BK, PM_, I8, F16>, lds), true);   \
+        (void)once;                                                                                            \
+        k_gemm_nt<TA, NS, WM, TM, TB, WN, TNT, BK, PM_, I8, F16><<<grid, WM * WN * 64, lds, st>>>(a);          \
     } while (0)
-    if constexpr (ABL != 0) {
-        QV_PM(0);
-    } else if constexpr (F16) {   // proj / fc2 forward: plain epilogue (training: the observer needs the pre-FQ tensor) or the fused residual update (inference)
+    if constexpr (F16) {   // proj / fc2 forward: plain epilogue (training: the observer needs the pre-FQ tensor) or the fused residual update (inference)
         if (a.pm == 6) QV_PM(6); else QV_PM(0);
     } else if constexpr (I8) {   // the grid x grid forward GEMMs
         switch (a.pm) {
@@ -1289,41 +1109,9 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
 #undef QV_PM
 }
 
-// QATVIT_NT_BREG=1: the tall NT launches take their B operand through registers (k_gemm_nt_br).  Default 0 (both operands through LDS): measured
-// equal within +-3 % on every shape of the step (profiles/round2_gemm_structure_experiments.txt) - the LDS-DMA fill rate is NOT what bounds these kernels
-static int nt_breg() {
-    static const int on = getenv("QATVIT_NT_BREG") ? atoi(getenv("QATVIT_NT_BREG")) : 0;
-    return on;
-}
-template <int TA, int NS, bool I8, bool F16, int LDSB>
-static void nt_br_launch(const NTArgs& a, int grid, hipStream_t st) {
-#define QV_BR(PM_)                                                                                   \
-    do {                                                                                             \
-        static bool once = (allow_lds(k_gemm_nt_br<TA, NS, PM_, I8, F16, LDSB>, (size_t)LDSB), true); \
-        (void)once;                                                                                  \
-        k_gemm_nt_br<TA, NS, PM_, I8, F16, LDSB><<<grid, 512, LDSB, st>>>(a);                         \
-    } while (0)
-    if constexpr (F16) {
-        QV_BR(0);
-    } else if constexpr (I8 || TA == 1) {
-        switch (a.pm) {
-            case 3: QV_BR(3); break;
-            case 4: QV_BR(4); break;
-            case 10: QV_BR(10); break;
-            default: QV_BR(0); break;
-        }
-    } else {
-        switch (a.pm) {
-            case 5: QV_BR(5); break;
-            default: QV_BR(0); break;
-        }
-    }
-#undef QV_BR
-}
-
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                   const void* B_lo, const NTPost* post, bool f16, const QpTail* tail) {
+                   const void* B_lo, const NTPost* post, bool f16) {
     if (f16 && (!A_lo || B_lo || (post && post->mode != 6) || N % 384 != 0 || K % 32 != 0)) {
         set_error("gemm_nt: the fp16 form takes a split A operand, N %% 384 == 0, the plain or the residual (mode 6) epilogue (N=%d K=%d)", N, K);
         return 1;
@@ -1333,11 +1121,10 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                   lda, ldb, ldc);
         return 1;
     }
-    NTArgs a{reinterpret_cast<const __bf16*>(A_hi), reinterpret_cast<const __bf16*>(A_lo), reinterpret_cast<const __bf16*>(B),
-             reinterpret_cast<const __bf16*>(B_lo), C, M, N, K, lda, ldb, ldc, s1, s2, col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots,
-             0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-             nullptr, nullptr};
-    if (tail && stats) a.tail = *tail;
+    NTArgs a{};
+    a.A0 = reinterpret_cast<const __bf16*>(A_hi); a.A1 = reinterpret_cast<const __bf16*>(A_lo); a.B = reinterpret_cast<const __bf16*>(B);
+    a.B1 = reinterpret_cast<const __bf16*>(B_lo); a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.s1 = s1; a.s2 = s2; a.col_scale = col_scale; a.bias = bias; a.stats = stats; a.stat_slots = stat_slots < 1 ? 1 : stat_slots;
     if (post && post->mode >= 3) {
         a.post_mode = post->mode;
         a.pm = post->mode;
@@ -1359,7 +1146,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                 set_error("gemm_nt: epilogue mode 9 needs a split A operand, N %% 384 == 0, ldc %% 128 == 0, the uint8 codes and the mask bits");
                 return 1;
             }
-            nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), (size_t)160 * 1024, st);
+            nt_launch<2, 3, 1, 13, 1, 8, 3, 32>(a, cdiv(M, 208) * (N / 384), (size_t)160 * 1024, st);
             return 0;
         }
         if (post->mode == 8) {
@@ -1369,7 +1156,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
                 return 1;
             }
             constexpr size_t lds8 = 160 * 1024;   // ring 150 KiB; the epilogue's 96-row slab + row operands need 156 KiB
-            nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208), lds8, st);
+            nt_launch<2, 3, 1, 13, 1, 8, 3, 32>(a, cdiv(M, 208), lds8, st);
             return 0;
         }
         const bool ok6 = post->mode == 6 && f16 && a.post_qp && a.resid && C;
@@ -1392,128 +1179,36 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         set_error("gemm_nt: null output");
         return 1;
     }
-    if (B_lo) {  // float x float (teacher): A must be split too; 128 x 128 tile, 8 waves, 2 stages x 64 KiB
+    // Tiles.  M = B * 197 token rows over 256 CUs is 197 rows per CU, so the main tile is 208 rows x the whole 384-column weight panel (every N of
+    // ViT-S / B is a multiple of 384): 243 tiles fill the chip in ONE round for N = 384 and the A operand is streamed into LDS exactly once;
+    // 1 x 8 waves each 208 x 48, BK 32, 3-stage ring, DMA issue spread between the MFMA groups.  128 x 128 tiles cover the other shapes.
+    if (B_lo) {  // float x float (teacher): both operands split
         if (!A_lo) { set_error("gemm_nt: a split B operand needs a split A operand"); return 1; }
-        static const int tall2 = getenv("QATVIT_NT_TALL2") ? atoi(getenv("QATVIT_NT_TALL2")) : 1;
-        if (tall2 && N % 384 == 0 && K % 32 == 0) {   // 208 x 384 tall tile, both operands split: 2 stages x (2 x 208 + 2 x 384) x 64 B = 148 KiB
-            constexpr size_t ldst = 2 * (2 * 208 + 2 * 384) * 64;
-            nt_launch<2, 2, 1, 13, 2, 0, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), ldst, st);
+        if (N % 384 == 0) {   // 2 stages x (2 x 208 + 2 x 384) x 64 B = 148 KiB
+            nt_launch<2, 2, 1, 13, 2, 8, 3, 32>(a, cdiv(M, 208) * (N / 384), (size_t)2 * (2 * 208 + 2 * 384) * 64, st);
             return 0;
         }
-        constexpr size_t lds = 2 * 4 * 16384;
-        nt_launch<2, 2, 4, 2, 2, 0, 2, 4, 64, 0>(a, cdiv(M, 128) * (N / 128), lds, st);
+        nt_launch<2, 2, 4, 2, 2, 2, 4, 64>(a, cdiv(M, 128) * (N / 128), (size_t)2 * 4 * 16384, st);   // 128 x 128, 8 waves, 2 stages x 64 KiB
         return 0;
     }
-    // Tile/wave configurations (tools/bench_gemm.py picks per operand class; QATVIT_NT1 / QATVIT_NT2 override for tuning):
-    //   a: 128 x 128, 4 waves x (64x64)     b: 256 x 128, 8 waves x (64x64)     c: 128 x 128, 8 waves x (32x64)
-    static const int cfg1 = getenv("QATVIT_NT1") ? atoi(getenv("QATVIT_NT1")) : 3;   // measured best at B=256 (profiles/round1_gemm_configs.txt)
-    static const int cfg2 = getenv("QATVIT_NT2") ? atoi(getenv("QATVIT_NT2")) : 2;
-#define QV_NT_LAUNCH(TA_, NS_, WM_, TM_)                                                            \
-    do {                                                                                            \
-        constexpr int bm = 16 * TM_ * WM_;                                                          \
-        constexpr size_t lds = (size_t)NS_ * (TA_ * bm * 128 + 16384);                              \
-        nt_launch<TA_, NS_, WM_, TM_, 1, 0, 2, 4, 64, 0>(a, cdiv(M, bm) * (N / 128), lds, st);          \
-    } while (0)
-    // N-panel-wide tiles: 128 x 384, 2 x 4 waves each 64 x 96.  Every N of ViT-S/B (384, 1152, 1536, 768, 2304, 3072) is a
-    // multiple of 384, so for N = 384 the A operand is streamed into LDS exactly once (the kernels are bound by the
-    // fabric -> LDS-DMA rate, ~7 TB/s chip-wide, not by MFMA: profiles/round1_gemm_ablation.txt).
-    static const int wide = getenv("QATVIT_NT_WIDE") ? atoi(getenv("QATVIT_NT_WIDE")) : 1;
-    // Tall tiles for split-A operands: 208 x 384 (1 x 8 waves, each 208 x 48), BK 32, 3 stages, DMA issue spread between the MFMA
-    // groups.  M = B*197 rows over 256 CUs is 197 rows per CU: 243 tiles of 208 rows fill the chip in ONE round for N = 384
-    // (128-row tiles: 394 tiles = 2 rounds at 77 %), and a 208-row tile moves 7.7 B into LDS per row and k against 10 B for 128 rows.
-    static const int tall = getenv("QATVIT_NT_TALL") ? atoi(getenv("QATVIT_NT_TALL")) : 1;
-    static const int pm5_4w = getenv("QATVIT_NT_PM5_4W") ? atoi(getenv("QATVIT_NT_PM5_4W")) : 0;
-    static const int stagger = getenv("QATVIT_NT_STAGGER") ? atoi(getenv("QATVIT_NT_STAGGER")) : 0;   // shader cycles (4-wave tiles only)
-    if ((tall == 4 || (pm5_4w && a.pm == 5)) && A_lo && N % 384 == 0 && K % 32 == 0) {   // 112 x 384 tiles, 4 waves, 2 stages (76 KiB): two workgroups per CU
-        a.stagger_cycles = stagger;
-        constexpr size_t lds4 = 2 * (2 * 112 + 384) * 64;
-        nt_launch<2, 2, 1, 7, 1, 0, 4, 6, 32, 0>(a, cdiv(M, 112) * (N / 384), lds4, st);
-        return 0;
-    }
-    // LDS of the B-through-registers form: split A, 4 stages x 26 KiB = 104 KiB ring (the mode-5 epilogue needs 146 KiB: slab + two code buffers);
-    // grid A, 4 stages x 13 KiB, epilogue slab 99 KiB
-    constexpr int kLdsBr2 = 150 * 1024, kLdsBr1 = 100 * 1024;
     if (f16) {
-        if (nt_breg() && K % 64 == 0 && a.pm == 0) { nt_br_launch<2, 4, false, true, kLdsBr2>(a, cdiv(M, 208) * (N / 384), st); return 0; }
-        constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
-        nt_launch<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);
+        nt_launch<2, 3, 1, 13, 1, 8, 3, 32, false, true>(a, cdiv(M, 208) * (N / 384), (size_t)3 * (2 * 208 + 384) * 64, st);   // 150 KiB
         return 0;
     }
-    if (nt_breg() && !B_lo && N % 384 == 0 && K % 64 == 0 && (a.pm == 0 || (A_lo && a.pm == 5) || (!A_lo && (a.pm == 3 || a.pm == 4 || a.pm == 10)))) {
-        if (A_lo) nt_br_launch<2, 4, false, false, kLdsBr2>(a, cdiv(M, 208) * (N / 384), st);
-        else nt_br_launch<1, 4, false, false, kLdsBr1>(a, cdiv(M, 208) * (N / 384), st);
+    if (N % 384 == 0) {
+        if (A_lo) nt_launch<2, 3, 1, 13, 1, 8, 3, 32>(a, cdiv(M, 208) * (N / 384), (size_t)3 * (2 * 208 + 384) * 64, st);   // 150 KiB
+        else nt_launch<1, 3, 1, 13, 1, 8, 3, 32>(a, cdiv(M, 208) * (N / 384), (size_t)3 * (208 + 384) * 64, st);            // 111 KiB
         return 0;
     }
-    if (tall && A_lo && N % 384 == 0 && K % 32 == 0) {
-        constexpr size_t lds = 3 * (2 * 208 + 384) * 64;   // 150 KiB
-        static const int tabl = getenv("QATVIT_NT_ABL") ? atoi(getenv("QATVIT_NT_ABL")) : 0;   // timing-only ablations
-#define QV_TALL(ABL_)                                                                                         \
-        do {                                                                                                  \
-            if (tall == 2) {                                                                                  \
-                nt_launch<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 4>(a, cdiv(M, 208) * (N / 384), lds, st);  \
-            } else {                                                                                          \
-                nt_launch<2, 3, 1, 13, 1, ABL_, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), lds, st);     \
-            }                                                                                                 \
-        } while (0)
-        if (tabl == 1) QV_TALL(1);
-        else if (tabl == 2) QV_TALL(2);
-        else if (tabl == 3) QV_TALL(3);
-        else if (tabl == 5) QV_TALL(5);
-        else if (tabl == 6) QV_TALL(6);
-        else QV_TALL(0);
-#undef QV_TALL
-        return 0;
-    }
-    static const int tall1 = getenv("QATVIT_NT_TALL1") ? atoi(getenv("QATVIT_NT_TALL1")) : 1;
-    if (tall1 && !A_lo && N % 384 == 0 && K % 32 == 0) {   // grid A operand on the tall tile
-        if (tall1 == 3) {   // experiment: 112 x 384, 4 waves, 2 stages (62 KiB): two workgroups per CU, epilogue of one over the k-loop of the other
-            constexpr size_t lds3 = 2 * (112 + 384) * 64;
-            nt_launch<1, 2, 1, 7, 1, 0, 4, 6, 32, 0>(a, cdiv(M, 112) * (N / 384), lds3, st);
-            return 0;
-        }
-        if (tall1 == 2 && K % 64 == 0) {   // experiment: BK 64, 2 stages (148 KiB): half the barriers
-            constexpr size_t lds2 = 2 * (208 + 384) * 128;
-            nt_launch<1, 2, 1, 13, 1, 0, 8, 3, 64, 0>(a, cdiv(M, 208) * (N / 384), lds2, st);
-            return 0;
-        }
-        constexpr size_t lds1 = 3 * (208 + 384) * 64;       // 111 KiB
-        nt_launch<1, 3, 1, 13, 1, 0, 8, 3, 32, 0>(a, cdiv(M, 208) * (N / 384), lds1, st);
-        return 0;
-    }
-    if (((wide == 1 && A_lo) || wide == 2) && N % 384 == 0) {   // grid-A GEMMs (K = 384, store-bound) measured equal or better on 128^2 tiles
-        const int nwg = cdiv(M, 128) * (N / 384);
-        if (A_lo) {
-            constexpr size_t lds = 2 * (2 * 16384 + 49152);   // 2 stages x (A_hi, A_lo [128x64], B [384x64]) = 160 KiB
-            nt_launch<2, 2, 2, 4, 1, 0, 4, 6, 64, 0>(a, nwg, lds, st);
-        } else {
-            constexpr size_t lds = 2 * (16384 + 49152);       // 2 stages x (A, B) = 128 KiB
-            nt_launch<1, 2, 2, 4, 1, 0, 4, 6, 64, 0>(a, nwg, lds, st);
-        }
-        return 0;
-    }
-    static const int abl = getenv("QATVIT_NT_ABL") ? atoi(getenv("QATVIT_NT_ABL")) : 0;
-    if (abl == 1 && A_lo) {  // timing-only: DMA ring + barriers + epilogue, no math (tools/bench_gemm.py)
-        constexpr size_t lds = 3 * (2 * 16384 + 16384);
-        nt_launch<2, 3, 4, 2, 1, 1, 2, 4, 64, 0>(a, cdiv(M, 128) * (N / 128), lds, st);
-        return 0;
-    }
-    if (A_lo) {
-        if (cfg2 == 1) QV_NT_LAUNCH(2, 3, 2, 4);        // a, 3 stages (144 KiB)
-        else if (cfg2 == 2) QV_NT_LAUNCH(2, 3, 4, 2);   // c, 3 stages (144 KiB)
-        else QV_NT_LAUNCH(2, 2, 4, 4);                  // (cfg 0) b, 2 stages (160 KiB: the whole LDS)
-    } else {
-        if (cfg1 == 1) QV_NT_LAUNCH(1, 3, 4, 4);        // b, 3 stages (144 KiB)
-        else if (cfg1 == 2) QV_NT_LAUNCH(1, 3, 4, 2);   // c, 3 stages (96 KiB)
-        else if (cfg1 == 3) QV_NT_LAUNCH(1, 2, 4, 2);   // c, 2 stages (64 KiB, two workgroups per CU)
-        else QV_NT_LAUNCH(1, 2, 2, 4);                  // (cfg 0) a, 2 stages (64 KiB, two workgroups per CU)
-    }
-#undef QV_NT_LAUNCH
+    // 128 x 128 tiles, 8 waves x (32 x 64) (measured best of three wave layouts at B = 256: profiles/round1_gemm_configs.txt)
+    if (A_lo) nt_launch<2, 3, 4, 2, 1, 2, 4, 64>(a, cdiv(M, 128) * (N / 128), (size_t)3 * (2 * 16384 + 16384), st);   // 3 stages, 144 KiB
+    else nt_launch<1, 2, 4, 2, 1, 2, 4, 64>(a, cdiv(M, 128) * (N / 128), (size_t)2 * (16384 + 16384), st);           // 2 stages, 64 KiB: two workgroups per CU
     return 0;
 }
 
 // fc2 forward from codes: A8 [M, lda] uint8 grid indices, lut[256] packed fp16 (hi | lo << 16) pairs, B16 [N, ldb] the weight integers as fp16
 int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st, const QpTail* tail) {
+                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st) {
     if (M < 1 || N % 384 != 0 || K % 64 != 0 || lda % 16 != 0 || ldb % 8 != 0 || ldc % 4 != 0 || !A8 || !lut || !B16 || !C) {
         set_error("gemm_nt_codes: unsupported arguments M=%d N=%d K=%d lda=%d ldb=%d ldc=%d (need N%%384==0, K%%64==0, lda%%16==0)", M, N, K, lda, ldb, ldc);
         return 1;
@@ -1523,7 +1218,6 @@ int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, f
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.s1 = s1; a.s2 = s2; a.col_scale = col_scale; a.bias = bias; a.stats = stats; a.stat_slots = stat_slots < 1 ? 1 : stat_slots;
     a.a_lut = lut;
-    if (tail && stats) a.tail = *tail;
     constexpr int kLds = 3 * (2 * 208 + 384) * 64 + 1024;   // 151 KiB
     static bool once = (allow_lds(k_gemm_nt_ac<3, 0, kLds>, (size_t)kLds), true);
     (void)once;
@@ -1536,15 +1230,15 @@ int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, f
 // bit for bit (both accumulate the same integers exactly).  Tall 208 x 384 tiles only: N % 384 == 0, K % 64 == 0.
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
-                      hipStream_t st, const NTPost* post, const QpTail* tail, const void* B8f) {
+                      hipStream_t st, const NTPost* post, const void* B8f) {
     if (M < 1 || N % 384 != 0 || K % 64 != 0 || lda % 16 != 0 || ldb % 16 != 0 || ldc % 4 != 0 || !wsum || !a_qp) {
         set_error("gemm_nt_i8: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d (need N%%384==0, K%%64==0, ld%%16==0)", M, N, K, lda, ldb);
         return 1;
     }
-    NTArgs a{reinterpret_cast<const __bf16*>(A8), nullptr, reinterpret_cast<const __bf16*>(B8), nullptr, C, M, N, K / 2, lda / 2, ldb / 2, ldc, s1, s2,
-             col_scale, bias, stats, stat_slots < 1 ? 1 : stat_slots, 0, 0, wsum, a_qp, center, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr,
-             nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (tail && stats) a.tail = *tail;
+    NTArgs a{};   // (int8 operands: the k extent and the operand strides are counted in 2-byte units)
+    a.A0 = reinterpret_cast<const __bf16*>(A8); a.B = reinterpret_cast<const __bf16*>(B8); a.C = C; a.M = M; a.N = N; a.K = K / 2; a.lda = lda / 2; a.ldb = ldb / 2;
+    a.ldc = ldc; a.s1 = s1; a.s2 = s2; a.col_scale = col_scale; a.bias = bias; a.stats = stats; a.stat_slots = stat_slots < 1 ? 1 : stat_slots;
+    a.i8_wsum = wsum; a.i8_aqp = a_qp; a.i8_center = center;
     if (post) {
         if (post->mode != 3 && post->mode != 4 && post->mode != 6 && post->mode != 7) { set_error("gemm_nt_i8: epilogue mode %d not available", post->mode); return 1; }
         a.post_mode = a.pm = post->mode;
@@ -1570,18 +1264,8 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
     }
     // the K = 384 two-pass GEMMs (qkv, fc1: statistics pass, code passes) on the A-stationary strip kernel (i8strip.hip) when the weight came in
     // fragment order too; everything else (plain fp32 output, K != 384, the inference epilogues) on the general tall tile below
-    if (post && launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, K, lda, ldc, s1, s2, col_scale, bias, stats, stat_slots, st, post, tail)) return 0;
-    static const int i8_4w = getenv("QATVIT_NT_I8_4W") ? atoi(getenv("QATVIT_NT_I8_4W")) : 0;   // 112 x 384 tiles, 4 waves, 2 stages (62 KiB): two workgroups per CU
-    if (i8_4w) {
-        static const int stagger = getenv("QATVIT_NT_STAGGER") ? atoi(getenv("QATVIT_NT_STAGGER")) : 0;
-        a.stagger_cycles = stagger;
-        constexpr size_t lds4 = 2 * (112 + 384) * 64;
-        nt_launch<1, 2, 1, 7, 1, 0, 4, 6, 32, 0, true>(a, cdiv(M, 112) * (N / 384), lds4, st);
-        return 0;
-    }
-    if (nt_breg() && a.K % 64 == 0 && a.pm != 6 && a.pm != 7) { nt_br_launch<1, 4, true, false, 100 * 1024>(a, cdiv(M, 208) * (N / 384), st); return 0; }
-    constexpr size_t lds = 3 * (208 + 384) * 64;
-    nt_launch<1, 3, 1, 13, 1, 0, 8, 3, 32, 0, true>(a, cdiv(M, 208) * (N / 384), lds, st);
+    if (post && launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, K, lda, ldc, s1, s2, col_scale, bias, stats, stat_slots, st, post)) return 0;
+    nt_launch<1, 3, 1, 13, 1, 8, 3, 32, true>(a, cdiv(M, 208) * (N / 384), (size_t)3 * (208 + 384) * 64, st);
     return 0;
 }
 
@@ -1606,17 +1290,11 @@ struct TNArgs {
     const int32_t* w_zp;  // [1] or [N]
     int w_per_channel, w_qmin, w_qmax;
     float* dbias;         // optional [N]: += sum_m P[m, n]  (bias gradient, ones-fragment MFMA)
-    int abl;              // timing-only ablation (tools/bench_gemm.py): 1 = skip the atomic epilogue
     const float* row_div; // optional [N]: results (and dbias) are divided by row_div[n] (P was pre-multiplied by the per-channel weight scale)
     float* partial;       // optional scratch [splits][tiles][tile elements]: splits store raw accumulators here, k_tn_reduce sums them in order
     // QC form (fc2 weight gradient): the Q operand gelu(fq(fc1 output)) as ONE byte per element + a 256-entry table of bf16 (hi | lo << 16) pairs
     const uint8_t* Qc;    // [M, ldq] uint8 table indices (ldq in bytes)
     const uint32_t* lutQ;
-    // QI form (weight gradients with a grid X operand: qkv, fc1): Q as int8 [M, ldq] = q - center (the plane the int8 forward GEMM reads);
-    // the kernel widens it to the bf16 integer q - zp = int8 + q_off (q_off = center - zero_point, read from q_qp[2])
-    const int8_t* Qi;
-    const float* q_qp;    // {scale, 1/scale, zp, on} of X's quantizer
-    int q_center;
 };
 
 template <int ROWB>  // ROWB: bytes per LDS row of the image (256 for a 128-column tile, 768 for a 384-column tile)
@@ -1640,9 +1318,7 @@ __device__ inline bf16x8 tr_frag(const char* img, int row0, int col0, int lane) 
 // kernels) and is expanded through a 256-entry table of bf16 (hi, lo) pairs INSIDE the workgroup: codes of tile s+1 land in a staging buffer by
 // LDS-DMA during step s-1, every thread expands 24 of them between the MFMA groups of step s (8-B code read, eight table gathers, two 16-B writes
 // into the hi / lo images in the layout the LDS-DMA of the plane form produces), the MFMAs of step s+1 read them: same fragments, same bits.
-// QI: the grid Q operand (bf16 integers q - zp) comes in as the int8 plane q - center the forward GEMM read (24 instead of 48 KB of LDS-DMA per
-// 64-token step) and is widened inside the workgroup - the QC scheme without table: one pair-free image, two staging buffers, arithmetic only.
-template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK, bool SPREAD = false, bool QC = false, bool QI = false>
+template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK, bool QC = false>
 __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     constexpr int BN = 128, NW = WM * WNK;
     constexpr int TM = BN / WM / 16;                // 16-row fragments of P per wave
@@ -1654,7 +1330,7 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
     static_assert((IMGP / 1024) % NW == 0 && (IMGQ / 1024) % NW == 0, "pieces must divide evenly over the waves");
     constexpr int NDMA = 2 * PP + TQ * PQ;
     constexpr int QCH = QROWB / 16;                 // 16-B chunks per Q row
-    static_assert(!QC || (TQ == 2 && NSTAGE == 2 && BK == 32 && BKW == 384 && NW == 8 && !SPREAD), "codes form: the 128 x 384 tile, 32-token steps");
+    static_assert(!QC || (TQ == 2 && NSTAGE == 2 && BK == 32 && BKW == 384 && NW == 8), "codes form: the 128 x 384 tile, 32-token steps");
     // QC LDS map: [3 x (P hi, P lo)] [(Q hi, Q lo) images written by the expansion] [3 x code staging] [table]
     constexpr int QC_PST = 2 * IMGP, QC_QIMG = 3 * QC_PST, QC_QST = 2 * IMGQ, QC_CB = QC_QIMG + QC_QST, QC_CBS = BK * BKW, QC_LUT = QC_CB + 3 * QC_CBS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1718,91 +1394,7 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    static_assert(!QI || (TQ == 1 && NSTAGE == 2 && BK == 64 && BKW == 384 && NW == 8 && !SPREAD && !QC), "int8-Q form: the 128 x 384 tile, 64-token steps");
-    if constexpr (QI) {
-        // LDS map: [2 x (P hi, P lo)] 64 KB | [Q image] 48 KB | [2 x int8 staging] 48 KB = 160 KB
-        constexpr int QI_PST = 2 * IMGP, QI_QIMG = 2 * QI_PST, QI_CB = QI_QIMG + IMGQ, QI_CBS = BK * BKW;
-        const v4i32 rQi = make_rsrc_v(p.Qi, (int64_t)p.M * p.ldq);
-        const float qsub = 8388736.0f - ((float)p.q_center - p.q_qp[2]);   // 2^23 + 128 - (center - zp)
-        auto issue_p = [&](int s) {
-            char* st = smem + (s & 1) * QI_PST;
-            const int mrow0 = (s_begin + s) * BK;
-#pragma unroll
-            for (int c = 0; c < PP; ++c) {
-                const int piece = wave * PP + c, row = piece * 4 + (lane >> 4);
-                const int src_chunk = (lane & 15) ^ tn_sw(row);
-                const uint32_t offP = (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + src_chunk * 8) * 2);
-                dma16_asm(rP0, st + piece * 1024, offP);
-                dma16_asm(rP1, st + IMGP + piece * 1024, offP);
-            }
-        };
-        auto issue_c = [&](int s) {      // 24 KiB of int8 = 24 pieces: three per wave, linear [64 tokens][384]
-            char* cb = smem + QI_CB + (s & 1) * QI_CBS;
-            const int mrow0 = (s_begin + s) * BK;
-#pragma unroll
-            for (int c = 0; c < QI_CBS / 1024 / NW; ++c) {
-                const int piece = wave + NW * c, L = piece * 64 + lane, row = L / (BKW / 16), cp = L % (BKW / 16);
-                dma16_asm(rQi, cb + piece * 1024, (uint32_t)((int64_t)(mrow0 + row) * p.ldq + k0 + cp * 16));
-            }
-        };
-        // 8 int8 (chunk c8: token c8 / 48, columns 8 (c8 % 48) ..) -> one 16-B chunk of bf16 integers in the image (exact: |q - zp| <= 255)
-        auto widen = [&](int s, int i) {
-            const char* cb = smem + QI_CB + (s & 1) * QI_CBS;
-            char* qi = smem + QI_QIMG;
-            const int c8 = tid + NW * 64 * i, row = c8 / (BKW / 8), col8 = c8 % (BKW / 8);
-            const uint2 cd = *reinterpret_cast<const uint2*>(cb + row * BKW + col8 * 8);
-            const uint32_t x[2] = {cd.x ^ 0x80808080u, cd.y ^ 0x80808080u};
-            bf16x8 f;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    f[4 * d + e] = (__bf16)(__builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, x[d], 0x07040400u + (uint32_t)e)) - qsub);
-            *reinterpret_cast<bf16x8*>(qi + row * QROWB + ((col8 ^ tn_sw(row)) << 4)) = f;
-        };
-        constexpr int NEXP = BK * BKW / 8 / (NW * 64);   // 6
-        constexpr int NGRP = (BK / 32) * TM;             // 8 MFMA groups per step
-        static_assert(NEXP <= NGRP, "one widening round per MFMA group");
-        if (nsteps > 0) { issue_p(0); issue_c(0); }
-        wait_vmcnt<0>();
-        __syncthreads();
-        if (nsteps > 0) {
-#pragma unroll
-            for (int i = 0; i < NEXP; ++i) widen(0, i);
-        }
-        if (nsteps > 1) issue_c(1);
-        for (int s = 0; s < nsteps; ++s) {
-            wait_vmcnt<0>();                             // this wave's pieces of P(s) and of the int8 tile s+1
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // A: ... and its share of the image of tile s; everyone left step s-1
-            if (s + 1 < nsteps) issue_p(s + 1);
-            if (s + 2 < nsteps) issue_c(s + 2);
-            const char* st = smem + (s & 1) * QI_PST;
-            const char* sq = smem + QI_QIMG;
-            bf16x8 qf[BK / 32][TNT];
-#pragma unroll
-            for (int kk = 0; kk < BK / 32; ++kk)
-#pragma unroll
-                for (int j = 0; j < TNT; ++j) qf[kk][j] = tr_frag<QROWB>(sq, 32 * kk, wn * (16 * TNT) + 16 * j, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B: every wave holds its Q fragments: the image is free
-#pragma unroll
-            for (int kk = 0; kk < BK / 32; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    if (s + 1 < nsteps && kk * TM + i < NEXP) widen(s + 1, kk * TM + i);
-                    const bf16x8 ph = tr_frag<PROWB>(st, 32 * kk, wm * (16 * TM) + 16 * i, lane);
-                    const bf16x8 pl = tr_frag<PROWB>(st + IMGP, 32 * kk, wm * (16 * TM) + 16 * i, lane);
-                    if (do_bias) {
-                        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ones, accb[i], 0, 0, 0);
-                        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, ones, accb[i], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < TNT; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[kk][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, qf[kk][j], acc[i][j], 0, 0, 0);
-                    }
-                }
-        }
-    } else if constexpr (QC) {
+    if constexpr (QC) {
         uint32_t* sLutQ = reinterpret_cast<uint32_t*>(smem + QC_LUT);
         if (tid < 256) sLutQ[tid] = p.lutQ[tid];
         const v4i32 rQc = make_rsrc_v(p.Qc, (int64_t)p.M * p.ldq);
@@ -1919,8 +1511,7 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const bool more = s + NSTAGE - 1 < nsteps;
-        constexpr int NSLOT = (BK / 32) * TM;              // MFMA groups per k-step: the next tile's DMA issue can be spread between them
-        if (!SPREAD && more) issue(s + NSTAGE - 1);
+        if (more) issue(s + NSTAGE - 1);
         const char* st = smem + (s % NSTAGE) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -1931,11 +1522,6 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
                 for (int j = 0; j < TNT; ++j) qf[t][j] = tr_frag<QROWB>(st + 2 * IMGP + t * IMGQ, 32 * kk, wn * (16 * TNT) + 16 * j, lane);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if (SPREAD && more) {
-#pragma unroll
-                    for (int c = 0; c < NGRP; ++c)
-                        if ((c * NSLOT) / NGRP == kk * TM + i) issue_group(s + NSTAGE - 1, c);
-                }
                 const bf16x8 ph = tr_frag<PROWB>(st, 32 * kk, wm * (16 * TM) + 16 * i, lane);
                 const bf16x8 pl = tr_frag<PROWB>(st + IMGP, 32 * kk, wm * (16 * TM) + 16 * i, lane);
                 if (do_bias) {
@@ -1954,13 +1540,6 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
 
     }   // !QC
     // ---- epilogue: scale, weight-FQ STE mask, accumulate
-    if (p.abl == 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TNT; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
     const float alpha = p.s1 ? *p.s1 : 1.f;
     const int r = lane & 15, g = lane >> 4;
     if (p.partial) {
@@ -2079,6 +1658,28 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, i
         if (nbase + e < p.N) p.C[(int64_t)(nbase + e) * p.ldc + kw] = outv[e];
 }
 
+// token-split plan shared by the weight-gradient launchers: one round of <= 256 long-running workgroups (the 128 - 160 KiB stage ring admits ONE
+// workgroup per CU, so one round beats two rounds of short ones: same MFMA time, half the prologues and half the partial tiles), >= 256 tokens per split
+static int tn_plan(TNArgs& a, int M, int bk, int tiles) {
+    const int steps = (M + bk - 1) / bk;
+    int splits = 256 / tiles;
+    const int min_steps = 256 / bk;
+    if (splits > steps / min_steps) splits = steps / min_steps > 0 ? steps / min_steps : 1;
+    if (splits < 1) splits = 1;
+    a.steps_per_split = (steps + splits - 1) / splits;
+    a.tiles = tiles;
+    return (steps + a.steps_per_split - 1) / a.steps_per_split;
+}
+static TNArgs tn_args(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                      const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
+                      const float* row_div) {
+    TNArgs a{};
+    a.P0 = reinterpret_cast<const __bf16*>(P_hi); a.P1 = reinterpret_cast<const __bf16*>(P_lo); a.Q0 = reinterpret_cast<const __bf16*>(Q_hi);
+    a.Q1 = reinterpret_cast<const __bf16*>(Q_lo); a.C = C; a.M = M; a.N = N; a.Kw = Kw; a.ldp = ldp; a.ldq = ldq; a.ldc = ldc; a.s1 = s1;
+    a.W = W; a.w_scale = w_scale; a.w_zp = w_zp; a.w_per_channel = w_per_channel; a.w_qmin = w_qmin; a.w_qmax = w_qmax; a.dbias = dbias; a.row_div = row_div;
+    return a;
+}
+
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                    const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
                    float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
@@ -2086,49 +1687,25 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
         set_error("gemm_tn: unsupported shape M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%128==0, ld%%8==0)", M, N, Kw, ldp, ldq);
         return 1;
     }
-    TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), reinterpret_cast<const __bf16*>(Q_hi),
-             reinterpret_cast<const __bf16*>(Q_lo), C, M, N, Kw, ldp, ldq, ldc, 0, 0, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, 0, row_div, nullptr};
-    static const int tn_abl = getenv("QATVIT_TN_ABL") ? atoi(getenv("QATVIT_TN_ABL")) : 0;
-    a.abl = tn_abl;
-    // Kw-panel-wide tiles (128 x 384) read the heavy operand P = dY (hi, lo) once per N tile when Kw = 384; every Kw of
-    // ViT-S/B (384, 1536, 768, 3072) is a multiple of 384.  QATVIT_TN_WIDE=0 forces the 128 x 128 tile (tuning).
-    static const int wide_env = getenv("QATVIT_TN_WIDE") ? atoi(getenv("QATVIT_TN_WIDE")) : 1;
-    // (measured at B=256: wide wins for a grid Q operand, 110/133 us vs 113/148; with a split Q (32-row steps) it wins when there
-    //  are enough wide tiles - fc2 wgrad, 12 tiles: 169 vs 181 us - and loses when few tiles mean many splits, each adding a full
-    //  tile of fp32 atomics - proj wgrad, 3 tiles: 84 vs 56 us; wide_env == 2 forces it)
-    const bool wide = (Kw % 384 == 0) && (wide_env == 2 || (wide_env == 1 && (!Q_lo || (N / 128) * (Kw / 384) >= 8)));
+    TNArgs a = tn_args(P_hi, P_lo, Q_hi, Q_lo, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div);
+    // Kw-panel-wide tiles (128 x 384) read the heavy operand P = dY (hi, lo) once per N tile when Kw = 384; every Kw of ViT-S/B (384, 1536, 768, 3072)
+    // is a multiple of 384.  (Measured at B=256: wide wins for a grid Q operand, 110/133 us vs 113/148; with a split Q (32-row steps) it wins when
+    // there are enough wide tiles - fc2 wgrad, 12 tiles: 169 vs 181 us - and loses when few tiles mean many splits - proj wgrad, 3 tiles: 84 vs 56 us)
+    const bool wide = (Kw % 384 == 0) && (!Q_lo || (N / 128) * (Kw / 384) >= 8);
     const int bk = (wide && Q_lo) ? 32 : 64;        // the split-Q wide stage only fits with 32-row steps
-    const int steps = (M + bk - 1) / bk;
     const int tiles = (N / 128) * (Kw / (wide ? 384 : 128));
-    // Split the token reduction so that the grid fills the 256 CUs once.
-    // (the 128-160 KiB stage ring admits ONE workgroup per CU, so one round of <= 256 long-running workgroups beats two rounds
-    //  of short ones: same MFMA time, half the prologues and half the fp32 atomics of the epilogue, which run at ~1.3 TB/s chip-wide)
-    int splits = 256 / tiles;
-    const int min_steps = 256 / bk;                 // >= 256 token rows per split
-    if (splits > steps / min_steps) splits = steps / min_steps > 0 ? steps / min_steps : 1;
-    if (splits < 1) splits = 1;
-    a.steps_per_split = (steps + splits - 1) / splits;
-    splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
-    a.tiles = tiles;
+    const int splits = tn_plan(a, M, bk, tiles);
     const int grid = tiles * splits;
-    static const int tn_spread = getenv("QATVIT_TN_SPREAD") ? atoi(getenv("QATVIT_TN_SPREAD")) : 0;
-    static const int tn_atomic = getenv("QATVIT_TN_ATOMIC") ? atoi(getenv("QATVIT_TN_ATOMIC")) : 0;   // 1: fp32 atomics even when scratch is given (tuning)
 #define QV_TN_LAUNCH(TQ_, NS_, WM_, WNK_, TNT_, BK_)                                                               \
     do {                                                                                                           \
         constexpr size_t lds = (size_t)NS_ * (2 * BK_ * 256 + TQ_ * BK_ * (WNK_ * TNT_ * 32));                      \
         constexpr int tm = 128 / WM_ / 16;                                                                         \
         const int64_t tile_f4 = (int64_t)WM_ * WNK_ * tm * TNT_ * 64;                                              \
-        const bool two_phase = partial && splits > 1 && tn_atomic == 0 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;  \
+        const bool two_phase = partial && splits > 1 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;             \
         a.partial = two_phase ? partial : nullptr;                                                                 \
-        if (tn_spread) {                                                                                           \
-            static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, true>, lds), true);            \
-            (void)once;                                                                                            \
-            k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, true><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);                \
-        } else {                                                                                                   \
-            static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, false>, lds), true);           \
-            (void)once;                                                                                            \
-            k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, false><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);               \
-        }                                                                                                          \
+        static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_>, lds), true);                      \
+        (void)once;                                                                                                \
+        k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);                          \
         if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, WM_, WNK_, tm, TNT_); \
     } while (0)
     if (wide) {
@@ -2151,61 +1728,19 @@ int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, con
         set_error("gemm_tn_codes: unsupported arguments M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%384==0, ldp%%8==0, ldq%%16==0)", M, N, Kw, ldp, ldq);
         return 1;
     }
-    TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), nullptr, nullptr, C, M, N, Kw, ldp, ldq, ldc, 0, 0, s1, W, w_scale, w_zp,
-             w_per_channel, w_qmin, w_qmax, dbias, 0, row_div, nullptr, reinterpret_cast<const uint8_t*>(Qc), lutQ};
-    constexpr int bk = 32;
-    const int steps = (M + bk - 1) / bk;
+    TNArgs a = tn_args(P_hi, P_lo, nullptr, nullptr, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div);
+    a.Qc = reinterpret_cast<const uint8_t*>(Qc); a.lutQ = lutQ;
     const int tiles = (N / 128) * (Kw / 384);
-    int splits = 256 / tiles;
-    const int min_steps = 256 / bk;
-    if (splits > steps / min_steps) splits = steps / min_steps > 0 ? steps / min_steps : 1;
-    if (splits < 1) splits = 1;
-    a.steps_per_split = (steps + splits - 1) / splits;
-    splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
-    a.tiles = tiles;
+    const int splits = tn_plan(a, M, 32, tiles);
     const int grid = tiles * splits;
     constexpr size_t lds = 3 * (2 * 32 * 256) + (2 * 32 * 768) + 3 * (32 * 384) + 1024;   // 133 KiB
     constexpr int tm = 4;
     const int64_t tile_f4 = (int64_t)2 * 4 * tm * 6 * 64;
     const bool two_phase = partial && splits > 1 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;
     a.partial = two_phase ? partial : nullptr;
-    static bool once = (allow_lds(k_gemm_tn<2, 2, 2, 4, 6, 32, false, true>, lds), true);
+    static bool once = (allow_lds(k_gemm_tn<2, 2, 2, 4, 6, 32, true>, lds), true);
     (void)once;
-    k_gemm_tn<2, 2, 2, 4, 6, 32, false, true><<<grid, 512, lds, st>>>(a);
-    if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, 2, 4, tm, 6);
-    return 0;
-}
-
-// Weight gradient with a grid Q operand given as the int8 plane q - center (what the int8 forward GEMM read) instead of the bf16 integers q - zp:
-// the 128 x 384 tile / 64-token steps of launch_gemm_tn's grid-Q form, the same MFMAs in the same order - bit-identical to it.
-int launch_gemm_tn_i8q(const void* P_hi, const void* P_lo, const void* Qi8, const float* q_qp, int center, float* C, int M, int N, int Kw, int ldp, int ldq,
-                       int ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
-                       float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
-    if (M < 1 || N % 128 != 0 || Kw % 384 != 0 || ldp % 8 != 0 || ldq % 16 != 0 || !P_hi || !P_lo || !Qi8 || !q_qp || !C) {
-        set_error("gemm_tn_i8q: unsupported arguments M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%384==0, ldp%%8==0, ldq%%16==0)", M, N, Kw, ldp, ldq);
-        return 1;
-    }
-    TNArgs a{reinterpret_cast<const __bf16*>(P_hi), reinterpret_cast<const __bf16*>(P_lo), nullptr, nullptr, C, M, N, Kw, ldp, ldq, ldc, 0, 0, s1, W, w_scale, w_zp,
-             w_per_channel, w_qmin, w_qmax, dbias, 0, row_div, nullptr, nullptr, nullptr, reinterpret_cast<const int8_t*>(Qi8), q_qp, center};
-    constexpr int bk = 64;
-    const int steps = (M + bk - 1) / bk;
-    const int tiles = (N / 128) * (Kw / 384);
-    int splits = 256 / tiles;
-    const int min_steps = 256 / bk;
-    if (splits > steps / min_steps) splits = steps / min_steps > 0 ? steps / min_steps : 1;
-    if (splits < 1) splits = 1;
-    a.steps_per_split = (steps + splits - 1) / splits;
-    splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
-    a.tiles = tiles;
-    const int grid = tiles * splits;
-    constexpr size_t lds = 2 * (2 * 64 * 256) + 64 * 768 + 2 * (64 * 384);   // 160 KiB
-    constexpr int tm = 4;
-    const int64_t tile_f4 = (int64_t)2 * 4 * tm * 6 * 64;
-    const bool two_phase = partial && splits > 1 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;
-    a.partial = two_phase ? partial : nullptr;
-    static bool once = (allow_lds(k_gemm_tn<1, 2, 2, 4, 6, 64, false, false, true>, lds), true);
-    (void)once;
-    k_gemm_tn<1, 2, 2, 4, 6, 64, false, false, true><<<grid, 512, lds, st>>>(a);
+    k_gemm_tn<2, 2, 2, 4, 6, 32, true><<<grid, 512, lds, st>>>(a);
     if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, 2, 4, tm, 6);
     return 0;
 }

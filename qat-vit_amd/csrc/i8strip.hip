@@ -54,7 +54,6 @@ struct I8StripArgs {
     // MODE 3
     uint32_t* stats;
     int stat_slots;
-    QpTail tail;
     // MODE 7 / 4
     const float* qp;        // {scale, 1 / scale, zp, on} of the OUTPUT's quantizer (fresh from the statistics pass)
     int qmin, qmax;
@@ -365,8 +364,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
 #pragma unroll
             for (int w = 1; w < 8; ++w) { mn = fminf(mn, sRed[w]); mx = fmaxf(mx, sRed[8 + w]); }
         }
-        if (p.tail.counter) qparams_tail(p.tail, p.stats, p.stat_slots, gridDim.x * gridDim.y, reinterpret_cast<uint32_t*>(sRed) + 32, mn, mx);
-        else if (tid == 0) stat_atomic(p.stats, p.stat_slots, mn, mx);
+        if (tid == 0) stat_atomic(p.stats, p.stat_slots, mn, mx);
     }
 }
 
@@ -386,7 +384,7 @@ static void strip_launch(const I8StripArgs& a0, hipStream_t st) {
 // true when the strip kernel covers the request (the caller then launched it); false -> the general tall kernel
 bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                     const NTPost* post, const QpTail* tail, bool force) {
+                     const NTPost* post, bool force) {
     static const int on = getenv("QATVIT_I8_STRIP") ? atoi(getenv("QATVIT_I8_STRIP")) : 1;   // 0: the general tall kernel (A/B arm of the bit-identity test)
     if ((!on && !force) || !B8f || !post || K != 384 || lda % 16 != 0 || !s1 || M >= (1 << 22)) return false;
     const int ntl = N % (4 * 384) == 0 ? 4 : N % (3 * 384) == 0 ? 3 : 0;
@@ -397,7 +395,6 @@ bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const
     if (post->mode == 3) {
         if (!stats) return false;
         a.stats = stats; a.stat_slots = stat_slots < 1 ? 1 : stat_slots;
-        if (tail) a.tail = *tail;
         if (ntl == 4) strip_launch<3, 4>(a, st); else strip_launch<3, 3>(a, st);
         return true;
     }

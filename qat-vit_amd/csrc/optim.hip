@@ -9,6 +9,7 @@
 // HBM-bound: 28 B per parameter for the update (p, g, m, v read; p, m, v written), 4 B for the norm.
 // Tensors are separate allocations (the parameters belong to torch), so work is dealt in fixed-size chunks through a
 // (tensor, chunk) table the host builds once; no atomics: chunk partials are reduced in a fixed order (deterministic).
+#include "../../include/qatvit.h"
 #include "qv_common.h"
 #include "qv_kernels.h"
 

@@ -25,22 +25,7 @@ int launch_qparams(uint32_t* ws, float* running_min, float* running_max, float* 
                    const int64_t* fake_quant_on, float c, int qmin, int qmax, int64_t channels, int symmetric, float* qp_out, int reset_ws,
                    int nslots, hipStream_t st);
 
-// fused consumer of an NT GEMM: store split(C * gelu'(fq(Y)) * mask(Y) * colscale[col]) instead of C (fc2 dgrad -> GELU backward)
-// One per-tensor activation quantizer's state, as the tail of a producer needs it (ws / nslots are the producer's statistics arguments;
-// device side: qv_qparams.h).
-struct QpTail {
-    uint32_t* counter;   // device word, zero between launches (the last workgroup re-zeroes it); nullptr = no tail
-    float* rmin;
-    float* rmax;
-    float* scale;
-    int32_t* zp;
-    const int64_t* obs_on;
-    const int64_t* fq_on;
-    float c;
-    int qmin, qmax;
-    float* qp_out;       // {scale, 1/scale, zp, enabled}
-};
-
+// fused consumers of an NT GEMM's accumulators (epilogue modes)
 struct NTPost {
     // mode 1 (Y != nullptr): store (hi, lo) of C * gelu'(fq(Y)) * mask(Y) * colscale   (fc2 dgrad -> GELU backward)
     // mode 2 (Y == nullptr): store (hi, lo) of gelu(C)                                  (teacher fc1 -> GELU forward)
@@ -99,16 +84,15 @@ struct NTPost {
 // ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                   const void* B_lo = nullptr, const NTPost* post = nullptr, bool f16 = false,    // f16: A_hi / A_lo / B hold fp16 bit patterns
-                   const QpTail* tail = nullptr);   // tail (with stats): the last workgroup also runs the observer / qparams update of the output's quantizer
+                   const void* B_lo = nullptr, const NTPost* post = nullptr, bool f16 = false);   // f16: A_hi / A_lo / B hold fp16 bit patterns
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
-                      hipStream_t st, const NTPost* post = nullptr, const QpTail* tail = nullptr,
+                      hipStream_t st, const NTPost* post = nullptr,
                       const void* B8f = nullptr);   // B8f: the same weight integers in fragment order (launch_w8_fragment_order): enables the strip kernel
 // ---- i8strip.hip: the K = 384 two-pass forward GEMMs (qkv, fc1), A-stationary; returns true when it covered (and launched) the request
 bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                     const NTPost* post, const QpTail* tail, bool force = false);
+                     const NTPost* post, bool force = false);
 // byte offset of element (n, k) of an [N, K] int8 weight in fragment order: [48-column group][64-deep k-step][16-column fragment][lane = 16 (k % 64 / 16) + n % 16][k % 16]
 __host__ __device__ inline int64_t w8f_offset(int n, int k, int K) {
     const int cg = n / 48, cr = n % 48, j = cr / 16, r = cr % 16, kt = k / 64, kk = k % 64;
@@ -117,8 +101,7 @@ __host__ __device__ inline int64_t w8f_offset(int n, int k, int K) {
 int launch_w8_fragment_order(const void* B8, void* B8f, int N, int K, hipStream_t st);   // N % 48 == 0, K % 64 == 0
 // A operand = uint8 grid indices [M, lda] expanded through lut[256] (packed fp16 hi | lo << 16 pairs) inside the kernel; B16 = weight integers as fp16
 int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                         const QpTail* tail = nullptr);
+                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st);
 // scratch that lets every wgrad shape take the two-phase (non-atomic, bit-reproducible) reduction: 256 workgroups x the largest tile
 constexpr int64_t kTnScratchBytes = 256ll * 128 * 384 * 4;
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
@@ -128,16 +111,12 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
 int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                          const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
                          const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
-// grid Q operand as the int8 plane q - center [M, ldq bytes] (+ its quantizer's qparams and the centre), widened inside the kernel (qkv / fc1 weight gradient)
-int launch_gemm_tn_i8q(const void* P_hi, const void* P_lo, const void* Qi8, const float* q_qp, int center, float* C, int M, int N, int Kw, int ldp, int ldq,
-                       int ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
-                       float* dbias, const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st,
                        void* out8 = nullptr, int center = 0);
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
                             float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
-                            int64_t M, int D, int T, hipStream_t st, void* maskbits = nullptr, const QpTail* tail = nullptr);
+                            int64_t M, int D, int T, hipStream_t st, void* maskbits = nullptr);
 // STE mask of an [M, D] tensor as wave ballots: ceil(D / 256) * 4 64-bit words per row (written by launch_resid_fq_lnstats mode 1)
 inline int64_t ln_maskbits_bytes(int64_t M, int D) { return M * ((D + 255) / 256) * 32; }
 // optional second output of launch_ln_bwd_fq: split(dx_out * mask * colscale) for the next branch's GEMMs

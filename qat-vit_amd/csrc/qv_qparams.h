@@ -1,6 +1,6 @@
-// The observer / qparams arithmetic of one fake-quantizer (device side), shared by the stand-alone k_qparams launch (fq.hip) and by the
-// TAILS of the producers that accumulate a quantizer's min/max (GEMM epilogues, k_resid_fq_lnstats): the last workgroup of the producer to
-// finish runs it, so the 5-us single-wave launch between every producer and its consumer (78 per student step) disappears.
+// The observer / qparams arithmetic of one fake-quantizer (device side): the body of the k_qparams launch (fq.hip) that runs right behind every
+// producer of a quantizer's min / max.  (Round 2 also ran it in the tail of the producer - last workgroup by ticket; the returning atomics at the end
+// of every workgroup cost what the 4.9-us launch costs: profiles/round2_gemm_structure_experiments.txt, experiment 5 - removed in round 3.)
 #pragma once
 #include "qv_common.h"
 #include "qv_kernels.h"
@@ -117,26 +117,6 @@ __device__ inline void qparams_body(uint32_t* ws, float* running_min, float* run
         qp_out[4 * i + 1] = __fdiv_rn(1.0f, s);
         qp_out[4 * i + 2] = (float)z;
         qp_out[4 * i + 3] = fq_on ? 1.f : 0.f;
-    }
-}
-
-// Called by ALL threads of a workgroup INSTEAD of thread 0's stat_atomic(): thread 0 issues the statistics atomics in their returning form, waits
-// for the old values (an atomic whose return has arrived has been performed at the device-wide coherence point) and only then draws its ticket -
-// ordering without a release fence (at agent scope that is an L2 write-back per workgroup on this multi-XCD part: measured +40 us per launch).
-// The workgroup that draws the last ticket therefore sees every accumulator final (device-scope atomic loads inside qparams_body) and runs the
-// update with its first wave; the accumulators are re-armed, the ticket counter re-zeroed.  `flag`: a shared-memory word nobody else touches
-// until the call returns.
-__device__ inline void qparams_tail(const QpTail& t, uint32_t* ws, int nslots, unsigned nblocks, uint32_t* flag, float mn, float mx) {
-    if (threadIdx.x == 0) {
-        uint32_t* s = ws + (nslots > 1 ? (int)(blockIdx.x & (nslots - 1)) * kStatStride : 0);
-        uint32_t r0 = atomicMin(&s[0], f2ord(mn)), r1 = atomicMax(&s[1], f2ord(mx));
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory");
-        *flag = atomicAdd(t.counter, 1u) == nblocks - 1u ? 1u : 0u;
-    }
-    __syncthreads();
-    if (*flag) {              // (uniform per workgroup)
-        if (threadIdx.x < 64) qparams_body(ws, t.rmin, t.rmax, t.scale, t.zp, t.obs_on, t.fq_on, t.c, t.qmin, t.qmax, 1, 0, t.qp_out, 1, nslots, 0);
-        if (threadIdx.x == 0) atomicExch(t.counter, 0u);
     }
 }
 

@@ -48,7 +48,6 @@ __global__ __launch_bounds__(256) void k_patches_split(const float* __restrict__
 
 // MODE 0: x[b,0,:] = cls + pos[0]; x[b,1+p,:] = Y[b*np+p,:] + pos[1+p,:]     MODE 1: x = x_prev + Y
 // then h = LayerNorm(x) written as a (hi, lo) pair (one wave per row, row kept in registers: single pass over HBM)
-constexpr int kTV = 3;  // float4 per lane per row: D <= 768
 __device__ inline void t_pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 // NV = ceil(D / 256) column groups per lane.  All loads of the row are issued first, branch-free and pinned (a lane past D reads column 0
 // and is masked out): one `if (c < D)` region per group let LLVM sink each group's loads to its uses - three dependent HBM round trips

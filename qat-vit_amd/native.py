@@ -38,7 +38,6 @@ SIGNATURES = {
     "qatvit_gemm_nt_i8": (c_int, [c_void_p] * 4 + [c_int32, c_void_p] + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_tn_scratch_bytes": (c_int64, []),
     "qatvit_gemm_tn": (c_int, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
-    "qatvit_gemm_tn_i8q": (c_int, [c_void_p] * 4 + [c_int32, c_void_p] + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
     "qatvit_gemm_tn_codes": (c_int, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
     "qatvit_attn_padded_tokens": (c_int32, [c_int32]),
     "qatvit_attn_forward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 4),

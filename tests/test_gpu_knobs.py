@@ -18,10 +18,7 @@ KNOBS = {
     "QATVIT_FC2W_CODES=0": "bits",         # fc2 weight gradient from the bf16 planes
     "QATVIT_QKV_2PASS=0": "bits",          # qkv GEMM once, fp32 output, attention quantises on load
     "QATVIT_I8_STRIP=0": "bits",           # the two-pass K = 384 GEMMs (qkv, fc1) on the general tall tile instead of the A-stationary strip kernel
-    "QATVIT_TNW_I8=1": "bits",             # qkv / fc1 weight gradients with X as int8 widened in the kernel
-    "QATVIT_QP_TAIL=1": "bits",            # k_qparams in the tail of its producer
     "QATVIT_I8=0": "bits",                 # grid x grid GEMMs on bf16 MFMA
-    "QATVIT_NT_BREG=1": "bits",            # B operand through registers
     "QATVIT_ATTN_CODES=0": "bits",         # attention backward re-quantises the fp32 qkv (implies the one-pass qkv GEMM)
     "QATVIT_LNB_FUSE=0": 2e-5,             # LayerNorm backward as its own kernel (another summation order for dgamma / dbeta)
     "QATVIT_FC1_RECOMPUTE=0": 2e-3,        # fc1 once, fp32 output, separate fq + GELU pass; fc2 forward then on the bf16 pair (as with QATVIT_F16=0)

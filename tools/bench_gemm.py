@@ -60,7 +60,6 @@ def tn(q_f32, N, Kw):
     passes = 3 if q_f32 else 2
     return t, 2.0 * M * N * Kw / t / 1e6, 2.0 * M * N * Kw * passes / t / 1e6
 
-print("cfg NT1=%s NT2=%s" % (os.environ.get("QATVIT_NT1"), os.environ.get("QATVIT_NT2")))
 print("NT shapes (us, algorithmic TF/s, issued-MFMA TF/s)")
 for name, a, N, K in [("qkv fwd", 0, 1152, 384), ("fc1 fwd", 0, 1536, 384), ("proj fwd", 1, 384, 384), ("fc2 fwd", 1, 384, 1536),
                       ("qkv dgrad", 1, 384, 1152), ("fc1 dgrad", 1, 384, 1536), ("fc2 dgrad", 1, 1536, 384)]:

@@ -9,7 +9,7 @@ kf = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)
 mf = glob.glob(out + "/**/*memory_copy_trace.csv", recursive=True)
 if not kf or not mf:
     print("missing traces", kf, mf)
-    sys.exit(0)
+    sys.exit(1)
 K = list(csv.DictReader(open(kf[0])))
 Mc = list(csv.DictReader(open(mf[0])))
 print("kernel trace columns:", list(K[0].keys()))

@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes over the NT GEMM micro-benchmark (one counter set per run; no tracing domains besides kernel-trace)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/pmc_nt
 mkdir -p $OUT
 i=0

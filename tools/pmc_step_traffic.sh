@@ -1,8 +1,10 @@
 #!/bin/bash
 # HBM-side traffic per launch of every kernel of the C2 step from rocprofv3 PMC counters, one counter per pass (MI355X_MICROARCH.md, HBM section:
 # FETCH_SIZE / WRITE_SIZE in KiB-units of 1024 B; gfx950: FETCH_SIZE counts half of a wide streaming read -> doubled below).
-# Writes gpurun_out/pmc_step/summary.json (copy to profiles/round2_gemm_pmc_traffic.json: bench.py reads roofline.traffic from it, labelled static).
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# Writes gpurun_out/pmc_step/summary.json (copy to profiles/round3_gemm_pmc_traffic.json: bench.py reads roofline.traffic from it, labelled static).
+set -eu
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/pmc_step
 rm -rf $OUT && mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -22,14 +24,25 @@ out = {}
 for k, v in acc.items():
     m = lambda c: sum(v[c]) / max(1, len(v[c]))
     out[k] = {"launches": len(v["FETCH_SIZE"]), "fetch_MB": round(2 * m("FETCH_SIZE") * 1024 / 1e6, 1), "write_MB": round(m("WRITE_SIZE") * 1024 / 1e6, 1)}
-kinds = {"4": "qv::k_gemm_nt<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, 8, false, false>", "5": "qv::k_gemm_nt<2, 3, 1, 13, 1, 0, 8, 3, 32, 0, 5, false, false>"}
+# the dominant GEMM classes by their epilogue mode (9th template argument of k_gemm_nt<TA, NS, WM, TM, TB, WN, TNT, BK, PM, I8, F16>), not by a full template string
+def pm_of(name):
+    if not name.startswith("qv::k_gemm_nt<"):
+        return None
+    args = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
+    return int(args[8]) if len(args) >= 9 and args[8].lstrip("-").isdigit() else None
 res = {"kernels": out}
-for kind, name in kinds.items():
-    if name in out:
+found = 0
+for kind, modes in (("4", (8,)), ("5", (9, 5))):
+    names = [k for k in out if pm_of(k) in modes]
+    if names:
+        name = max(names, key=lambda k: out[k]["launches"])
         o = out[name]
+        found += 1
         res[kind] = {"bytes_per_launch": (o["fetch_MB"] + o["write_MB"]) * 1e6, "fetch_MB": o["fetch_MB"], "write_MB": o["write_MB"],
                      "note": f"mean FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch of {name} over {o['launches']} launches of the C2 step at batch 256, "
-                             "separate rocprofv3 --pmc passes (tools/pmc_step_traffic.sh): profiles/round2_gemm_pmc_traffic.json"}
+                             "separate rocprofv3 --pmc passes (tools/pmc_step_traffic.sh)"}
+if not found:
+    print("no k_gemm_nt launch with epilogue mode 8 / 9 found"); raise SystemExit(1)
 json.dump(res, open("gpurun_out/pmc_step/summary.json", "w"), indent=1)
 for k, o in sorted(out.items(), key=lambda kv: -(kv[1]["fetch_MB"] + kv[1]["write_MB"]) * kv[1]["launches"])[:24]:
     print(f'{o["launches"]:5d} x  fetch {o["fetch_MB"]:8.1f} MB  write {o["write_MB"]:8.1f} MB   {k[:100]}')

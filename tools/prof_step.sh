@@ -1,11 +1,13 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the default bench workload (C2): tools/prof_step.sh <tag> [extra bench args]
 # writes gpurun_out/prof_<tag>/ and prints per-kernel time per STEP (steps in the trace = launches of k_kd_ce: warm-up + timed + per-class legs)
-TAG=$1; shift
+set -eu
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:?tag}; shift
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o c2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-kernel-rates --no-extras "$@" > $OUT/bench.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o c2 -- python3 $ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-kernel-rates --no-extras "$@" > $OUT/bench.log 2>&1
 echo "rc=$?"
 grep '"metric"' $OUT/bench.log | cut -c1-200
 python3 - "$OUT" <<'PY'
