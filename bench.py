@@ -129,34 +129,12 @@ def cpu_baseline(seconds=12.0):
 
 
 def spawn_workers(n, argv):
-    """``bench.py --gpus N`` started directly: run N workers (one per GPU, RCCL rendezvous on 127.0.0.1), relay rank 0's stdout.
+    """``bench.py --gpus N`` started directly: run N workers (one per GPU, RCCL rendezvous on 127.0.0.1) under the watchdog of
+    qat_vit_amd.launch (first failing rank stops the rest; wall-clock limit), relay rank 0's stdout.
     Nothing in this process has touched the GPU (importing torch does not)."""
-    import socket
-    import subprocess
+    from qat_vit_amd.launch import run_workers
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, rc = "", 0
-    try:
-        out0, _ = procs[0].communicate()
-        for q in procs:
-            q.wait()
-    finally:
-        for q in procs:
-            if q.poll() is None:
-                q.kill()
-    for r, q in enumerate(procs):
-        if q.returncode != 0:
-            print(f"bench.py: worker rank {r} exited with {q.returncode}", file=sys.stderr)
-            rc = 1
+    rc, out0 = run_workers(n, [sys.executable, os.path.abspath(__file__)] + argv, wall_limit_s=float(os.environ.get("BENCH_WALL_LIMIT_S", "3000")))
     sys.stdout.write(out0)
     sys.stdout.flush()
     if rc == 0 and '"metric"' not in out0:
@@ -225,10 +203,13 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+
+        tmo = datetime.timedelta(seconds=float(os.environ.get("BENCH_DIST_TIMEOUT_S", "180")))   # a dead peer ends the run in minutes, not in c10d's default 10 - 30
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     import qat_vit_amd
     from qat_vit_amd import functional as F

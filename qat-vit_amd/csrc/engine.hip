@@ -8,6 +8,7 @@
 // device state (backward runs on autograd's worker thread).
 #include <string.h>
 
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -174,17 +175,22 @@ static int check_cfg(const qatvit_cfg& c) {
 }
 
 // ---- optional in-situ timing of one GEMM class with HIP events on the launch stream (bench.py only).  The state belongs to ONE engine:
-// it is keyed by that engine's workspace pointer, so two engines in one process (student + a second model, two threads) never see each
-// other's events; an engine without an active profile pays one map lookup per forward / backward call.
+// it is keyed by that engine's workspace pointer, so two engines in one process never see each other's events.  A forward / backward call holds a
+// shared_ptr to the session for its whole duration (backward runs on autograd's worker thread while the main thread may call
+// qatvit_profile_stop): stop only marks the session closed and unlinks it - the object dies with its last holder; qatvit_student_init drops a
+// session whose workspace is being re-bound (a re-allocated workspace must not inherit it).
 struct Prof {
-    int kind = 0;  // 0 off, 1 NT split-A plain epilogue, 2 NT grid-A (int8), 3 TN, 4 NT split-A dgrad + fused LayerNorm backward, 5 fc2 dgrad + fused GELU'
+    int kind = 0;  // 1 NT split-A plain epilogue, 2 NT grid-A (int8), 3 TN, 4 NT split-A dgrad + fused LayerNorm backward, 5 fc2 dgrad + fused GELU', 6 TN split X, 7 / 8 / 9 int8 passes
     std::vector<hipEvent_t> ev;
     size_t used = 0;
     double flops = 0.0;
+    bool closed = false;
+    std::mutex mu;
+    ~Prof() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
 };
 static std::mutex g_prof_mu;
-static std::unordered_map<const void*, Prof*> g_profs;
-static Prof* prof_of(const void* workspace) {
+static std::unordered_map<const void*, std::shared_ptr<Prof>> g_profs;
+static std::shared_ptr<Prof> prof_of(const void* workspace) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     auto it = g_profs.find(workspace);
     return it == g_profs.end() ? nullptr : it->second;
@@ -192,12 +198,20 @@ static Prof* prof_of(const void* workspace) {
 struct ProfScope {
     Prof* pr;
     hipStream_t st;
-    bool on;
-    ProfScope(Prof* p, int kind, double flops, hipStream_t s) : pr(p), st(s), on(p && p->kind == kind && p->used + 2 <= p->ev.size()) {
-        if (on) { (void)hipEventRecord(pr->ev[pr->used], st); pr->flops += flops; }
+    size_t slot = 0;
+    bool on = false;
+    ProfScope(const std::shared_ptr<Prof>& p, int kind, double flops, hipStream_t s) : pr(p.get()), st(s) {
+        if (!pr || pr->kind != kind) return;
+        std::lock_guard<std::mutex> lk(pr->mu);
+        if (pr->closed || pr->used + 2 > pr->ev.size()) return;
+        slot = pr->used;
+        pr->used += 2;
+        pr->flops += flops;
+        on = true;
+        (void)hipEventRecord(pr->ev[slot], st);
     }
     ~ProfScope() {
-        if (on) { (void)hipEventRecord(pr->ev[pr->used + 1], st); pr->used += 2; }
+        if (on) (void)hipEventRecord(pr->ev[slot + 1], st);
     }
 };
 
@@ -279,7 +293,7 @@ struct Ctx {
     const qatvit_fq* act;
     const qatvit_fq* wfq;
     hipStream_t st;
-    Prof* prof;
+    std::shared_ptr<Prof> prof;
     template <typename T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
     template <typename T> T* blk(int64_t off, int i) const { return reinterpret_cast<T*>(ws + off + p.blk_stride * i); }
     const float* prm(int i) const { return reinterpret_cast<const float*>(params[i]); }
@@ -769,6 +783,12 @@ int qatvit_student_init(const qatvit_cfg* cfg, void* workspace, void* stream) {
     if (check_cfg(*cfg)) return 1;
     Plan p;
     if (make_plan(*cfg, &p)) return 1;
+    {   // a timing session keyed by this address belongs to whatever was bound to it before
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        auto it = g_profs.find(workspace);
+        if (it != g_profs.end()) { std::lock_guard<std::mutex> l2(it->second->mu); it->second->closed = true; }
+        g_profs.erase(workspace);
+    }
     launch_ws_init(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + p.stats), p.stats_words / 2, (hipStream_t)stream);
     QV_CHECK_LAUNCH("qatvit_student_init");
     return 0;
@@ -842,22 +862,19 @@ int qatvit_student_backward_stages(const qatvit_cfg* cfg, void* const* params, c
 // bench.py: time every launch of one GEMM class of ONE engine (identified by its workspace) with HIP events on the stream it is launched on
 int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launches) {
     QV_CHECK_ARG(workspace && kind >= 1 && kind <= 9 && max_launches > 0, "qatvit_profile_start: bad arguments");
-    Prof* pr = new Prof();
+    auto pr = std::make_shared<Prof>();
     pr->ev.assign((size_t)max_launches * 2, nullptr);
     for (auto& e : pr->ev)
         if (hipEventCreate(&e) != hipSuccess) {
-            for (hipEvent_t d : pr->ev) if (d) (void)hipEventDestroy(d);
-            delete pr;
             set_error("qatvit_profile_start: hipEventCreate failed");
-            return 2;
+            return 2;   // (~Prof destroys the events created so far)
         }
     pr->kind = kind;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     auto it = g_profs.find(workspace);
-    if (it != g_profs.end()) {   // restart: drop the previous session of this engine
-        for (hipEvent_t e : it->second->ev) (void)hipEventDestroy(e);
-        delete it->second;
-        g_profs.erase(it);
+    if (it != g_profs.end()) {   // restart: close the previous session of this engine (it dies with its last holder)
+        std::lock_guard<std::mutex> l2(it->second->mu);
+        it->second->closed = true;
     }
     g_profs[workspace] = pr;
     return 0;
@@ -865,25 +882,28 @@ int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launch
 
 int qatvit_profile_stop(const void* workspace, double* total_ms, int64_t* launches, double* flops) {
     QV_CHECK_ARG(workspace && total_ms && launches && flops, "qatvit_profile_stop: null argument");
-    Prof* pr = nullptr;
+    std::shared_ptr<Prof> pr;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         auto it = g_profs.find(workspace);
-        if (it != g_profs.end()) { pr = it->second; g_profs.erase(it); }   // no forward / backward of this engine records from here on
+        if (it != g_profs.end()) { pr = it->second; g_profs.erase(it); }
     }
     QV_CHECK_ARG(pr, "qatvit_profile_stop: no profile is active for this workspace");
+    size_t used;
+    {
+        std::lock_guard<std::mutex> lk(pr->mu);   // no forward / backward of this engine opens a bracket from here on; open ones finish on their own events
+        pr->closed = true;
+        used = pr->used;
+        *flops = pr->flops;
+    }
     double ms = 0.0;
-    for (size_t i = 0; i + 1 < pr->used; i += 2) {
-        (void)hipEventSynchronize(pr->ev[i + 1]);
+    for (size_t i = 0; i + 1 < used; i += 2) {
+        if (hipEventSynchronize(pr->ev[i + 1]) != hipSuccess) continue;   // (a bracket still open on another thread: its end event is not recorded yet)
         float t = 0.f;
-        (void)hipEventElapsedTime(&t, pr->ev[i], pr->ev[i + 1]);
-        ms += t;
+        if (hipEventElapsedTime(&t, pr->ev[i], pr->ev[i + 1]) == hipSuccess) ms += t;
     }
     *total_ms = ms;
-    *launches = (int64_t)(pr->used / 2);
-    *flops = pr->flops;
-    for (hipEvent_t e : pr->ev) (void)hipEventDestroy(e);
-    delete pr;
+    *launches = (int64_t)(used / 2);
     return 0;
 }
 

@@ -38,13 +38,32 @@ class GraphedStudentStep:
         # the graph records raw addresses of the engine's workspace and fake-quant arena: keep the engine alive and pin its workspace
         # (a later, larger batch would otherwise re-allocate it under the graph)
         self.engine = eng
-        eng.frozen = True
+        eng._reserve(images.shape[0])             # (already true after the warm-up; explicit: the graph is bound to THIS workspace)
         for p in model.parameters():
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out, self.loss, self.parts = self._eager()
-        self._grads = [p.grad for p in model.parameters()]
+        eng.frozen = True                          # no re-allocation during capture ...
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out, self.loss, self.parts = self._eager()
+        except BaseException:
+            eng.frozen = False                     # ... a failed capture leaves the engine as it was
+            self.graph = None
+            raise
+        self._grads = [p.grad for p in model.parameters()]   # from here on the pin lasts as long as this object (close() / __del__ release it)
+
+    def close(self) -> None:
+        """Drops the graph and un-pins the engine's workspace (it may grow again for a larger batch)."""
+        self.graph = None
+        if getattr(self, "engine", None) is not None:
+            self.engine.frozen = False
+            self.engine = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def _eager(self):
         for p in self.model.parameters():
@@ -57,6 +76,8 @@ class GraphedStudentStep:
     @torch.no_grad()
     def __call__(self, images: torch.Tensor, labels: torch.Tensor, teacher_out: Optional[torch.Tensor] = None):
         """Copies the batch into the captured buffers and replays; returns (logits, loss, parts) - tensors owned by the graph."""
+        if self.graph is None or self.engine is None:
+            raise RuntimeError("GraphedStudentStep: closed")
         if engine_of(self.model) is not self.engine:
             raise RuntimeError("GraphedStudentStep: the model was re-bound to another native engine after capture; capture again")
         if images.shape != self.x.shape:

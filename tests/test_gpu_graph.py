@@ -53,3 +53,9 @@ def test_graphed_step_matches_eager(native_lib):
     assert torch.equal(out_a, out_b)
     with pytest.raises(RuntimeError, match="exceeds the workspace"):
         b(torch.cat([xs[0], xs[1]]))                                     # growing would re-allocate under the captured graph
+    # dropping the graph un-pins the workspace: the same forward now grows it
+    step.close()
+    with torch.no_grad():
+        assert b(torch.cat([xs[0], xs[1]])).shape == (8, 10)
+    with pytest.raises(RuntimeError, match="closed"):
+        step(xs[0], ys[0])

@@ -20,9 +20,12 @@ KNOBS = {
     "QATVIT_I8_STRIP=0": "bits",           # the two-pass K = 384 GEMMs (qkv, fc1) on the general tall tile instead of the A-stationary strip kernel
     "QATVIT_I8=0": "bits",                 # grid x grid GEMMs on bf16 MFMA
     "QATVIT_ATTN_CODES=0": "bits",         # attention backward re-quantises the fp32 qkv (implies the one-pass qkv GEMM)
-    "QATVIT_LNB_FUSE=0": 2e-5,             # LayerNorm backward as its own kernel (another summation order for dgamma / dbeta)
-    "QATVIT_FC1_RECOMPUTE=0": 2e-3,        # fc1 once, fp32 output, separate fq + GELU pass; fc2 forward then on the bf16 pair (as with QATVIT_F16=0)
-    "QATVIT_F16=0": 2e-3,                  # bf16 pairs for the forward float operands (2^-17 instead of 2^-23: one-step flips possible)
+    # float tolerance: (logits relative L2, worst parameter-gradient relative L2).  These forms change the arithmetic of a forward float operand by
+    # <= 2^-17 per element; on this depth-2 step that shows up as a handful of one-step code flips downstream - the bounds are ~10x the values
+    # measured (LNB_FUSE: 0 / 3e-7; FC1_RECOMPUTE, F16: 1.2e-4 / 2.5e-3), far below the 0.1 a wrong fallback path would produce
+    "QATVIT_LNB_FUSE=0": (1e-6, 1e-5),      # LayerNorm backward as its own kernel (another summation order for dgamma / dbeta)
+    "QATVIT_FC1_RECOMPUTE=0": (2e-3, 2e-2), # fc1 once, fp32 output, separate fq + GELU pass; fc2 forward then on the bf16 pair (as with QATVIT_F16=0)
+    "QATVIT_F16=0": (2e-3, 2e-2),           # bf16 pairs for the forward float operands (2^-17 instead of 2^-23: one-step flips possible)
 }
 ATOMIC = ("bias", "norm", "cls_token", "pos_embed")
 
@@ -51,7 +54,7 @@ def test_knob_forms_match_the_default(native_lib, tmp_path, backend):
     ref = run(tmp_path, "default", None, backend)
     again = run(tmp_path, "default2", None, backend)
     assert torch.equal(ref["logits"], again["logits"])                      # the step itself is reproducible across processes
-    bad = []
+    bad, measured = [], {}
     for kv, how in KNOBS.items():
         got = run(tmp_path, kv.replace("=", "_"), kv, backend)
         if how == "bits":
@@ -69,9 +72,11 @@ def test_knob_forms_match_the_default(native_lib, tmp_path, backend):
                 elif not torch.equal(got["grads"][n], g):
                     bad.append((kv, "gradient differs", n, rel(got["grads"][n], g)))
         else:
-            if rel(got["logits"], ref["logits"]) > how * 50:
-                bad.append((kv, "logits", rel(got["logits"], ref["logits"])))
-            worst = max(rel(got["grads"][n], g) for n, g in ref["grads"].items())
-            if worst > how * 50:
-                bad.append((kv, "gradients", worst))
+            tol_logits, tol_grads = how
+            measured[kv] = (rel(got["logits"], ref["logits"]), max(rel(got["grads"][n], g) for n, g in ref["grads"].items()))
+            if measured[kv][0] > tol_logits:
+                bad.append((kv, "logits", measured[kv][0]))
+            if measured[kv][1] > tol_grads:
+                bad.append((kv, "gradients", measured[kv][1]))
+    print("float-tolerance knobs (logits rel L2, worst gradient rel L2):", measured)
     assert not bad, bad

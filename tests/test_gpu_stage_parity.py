@@ -23,7 +23,7 @@ A second, informational table repeats the forward with ONE injection per block (
 on the stock torch tree on this GPU - the live fp32 floor of that coarser granularity; it must stay within 3x that floor.
 
 Reference call sites: forward ``ddp_model(images)`` qat_trainer.py:341, loss :343-349, ``loss.backward()`` :359.
-Tables are written to gpurun_out/ (committed copies: profiles/round2_stage_flip_table_*.txt)."""
+Tables are written to gpurun_out/ (committed copies: profiles/round3_stage_flip_table_*.txt)."""
 import copy
 import os
 
@@ -143,12 +143,17 @@ def _fq_of_codes(pre, fqmod, qmin, qmax):
     return torch.clamp(torch.round(pre * inv) + zp, qmin, qmax) - zp
 
 
-def _run(backend, seed, teacher, golden_tag):
-    B, T = 8, 197
-    w = step_ref.build_student("vit_small_patch16_224", seed=seed)
+def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, blocks=None):
+    """arch / B: model and batch of the harness; blocks: the blocks whose stages are executed and compared (None = all; the embedding, head and
+    the whole oracle step always run)."""
+    T = 197
+    w = step_ref.build_student(arch, seed=seed)
     po = step_ref.enable_qat(w, backend)
     po0 = copy.deepcopy(po)                                             # never-observed copy: source of the stock-torch-on-GPU floor blocks
-    stu = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True)
+    if arch == "vit_small_patch16_224":
+        stu = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True)
+    else:   # the reference's ViT-B factory (model_registry.py:152-175) without the checkpoint fetch
+        stu = qat_vit_amd.create_model("vit_base_patch16_224_teacher", pretrained=False, num_classes=10, qat_wrapper=True)
     stu.load_state_dict(w.state_dict())
     p = prepare(stu.cuda(), backend)
     g = torch.Generator().manual_seed(77)
@@ -157,6 +162,7 @@ def _run(backend, seed, teacher, golden_tag):
     t = torch.randn(B, 10, generator=g) * 2 if teacher else None
     tr = OracleTrace(po, x, y, t)
     depth, D = tr.depth, p.model.embed_dim
+    blocks = list(range(depth)) if blocks is None else list(blocks)
     M = B * T
     eng = E.bind(p, B)
     c = eng.cfg
@@ -271,8 +277,9 @@ def _run(backend, seed, teacher, golden_tag):
     # ---- (informational) ONE injection per block, next to the same experiment on the stock torch tree on this GPU: the live floor of
     # that granularity (in-block amplification: a flipped key perturbs a whole head; a flipped norm2 element ~5 % of its row's fc1 codes)
     coarse = Table()
+    coarse_bad = []
     n_cmp = n_within = 0
-    for i in range(depth):
+    for i in blocks:
         st, pre = f"block{i}", f"model.blocks.{i}"
         reset_act_observers(range(2 + 6 * i, 8 + 6 * i))
         eng.tensor("x_in", i, (M, D)).copy_(tr.block_in[i].reshape(M, D).cuda())
@@ -295,16 +302,20 @@ def _run(backend, seed, teacher, golden_tag):
             if r[1] in floor:
                 coarse.rows[k] = r + (floor[r[1]],)
                 n_cmp += 1
-                n_within += r[4] <= 3 * floor[r[1]] + 1e-4
+                ok = r[4] <= 3 * floor[r[1]] + 1e-4
+                n_within += ok
+                if not ok:
+                    coarse_bad.append((st, r[1], r[4], floor[r[1]]))
         del blk
-    coarse.bad = []   # informational: at this granularity a quantizer's codes also move with its SCALE (a different max element after an upstream
-    #                   flip), for the stock tree exactly as for ours - asserted only in aggregate below
-    coarse.write(os.path.join(ROOT, "gpurun_out", f"round2_block_level_vs_floor_{golden_tag}.txt"),
+    # at this granularity a quantizer's codes also move with its SCALE (a different max element after an upstream flip), for the stock tree exactly as
+    # for ours: every row is asserted against 3x the stock-torch-on-this-GPU floor of the same row (+ 1e-4), not against the fine table's limits
+    coarse.bad = []
+    coarse.write(os.path.join(ROOT, "gpurun_out", f"round3_block_level_vs_floor_{golden_tag}.txt"),
                  f"# ONE injection per block (coarse): native block on the oracle's block input vs the oracle, and the same for the stock torch tree on the same GPU "
-                 f"(last column = that floor); ViT-S batch {B}, {backend}; native within 3x floor + 1e-4 in {n_within} of {n_cmp} rows")
+                 f"(last column = that floor); {arch} batch {B}, {backend}; native within 3x floor + 1e-4 in {n_within} of {n_cmp} rows")
 
     # ---- the asserted run: injection at every fake-quantizer input that follows an amplifier (four parts per block)
-    for i in range(depth):
+    for i in blocks:
         st = f"block{i}"
         reset_act_observers([2 + 6 * i])
         eng.tensor("x_in", i, (M, D)).copy_(tr.block_in[i].reshape(M, D).cuda())
@@ -384,6 +395,8 @@ def _run(backend, seed, teacher, golden_tag):
     tab.close("bwd head", f"d x_in[{depth}]", dxA, tr.g_block_in[depth].reshape(M, D))
     for s in range(1, depth + 1):
         i = depth - s
+        if i not in blocks:
+            continue
         dxA.copy_(tr.g_block_in[i + 1].reshape(M, D).cuda())
         v = eng.backward_stages(None, s, s, inject=True)
         check_grads(f"bwd block{i}", v, range(4 + 12 * i, 4 + 12 * i + 12))
@@ -392,11 +405,11 @@ def _run(backend, seed, teacher, golden_tag):
     v = eng.backward_stages(None, depth + 1, depth + 1, inject=True)
     check_grads("bwd embed", v, range(0, 4))
     assert len(names) == n_par
-    path = os.path.join(ROOT, "gpurun_out", f"round2_stage_flip_table_{golden_tag}.txt")
-    tab.write(path, f"# teacher-forced stage parity, ViT-S batch {B}, {backend} qconfig, {'KD' if teacher else 'CE only'}; native stage on the oracle's input vs the oracle "
+    path = os.path.join(ROOT, "gpurun_out", f"round3_stage_flip_table_{golden_tag}.txt")
+    tab.write(path, f"# teacher-forced stage parity, {arch} batch {B}, {backend} qconfig, {'KD' if teacher else 'CE only'}; native stage on the oracle's input vs the oracle "
                     f"(torch {torch.__version__} CPU eager QAT); produced by tests/test_gpu_stage_parity.py")
     tab.check()
-    assert n_within >= 0.8 * n_cmp, (n_within, n_cmp)      # one injection per block: within 3x the stock-torch-on-this-GPU floor almost everywhere
+    assert not coarse_bad, ("one injection per block: rows beyond 3x the stock-torch-on-this-GPU floor", coarse_bad[:8], n_within, n_cmp)
     return tab
 
 
@@ -408,3 +421,18 @@ def test_stage_parity_c1_qnnpack(native_lib):
 def test_stage_parity_c3_x86(native_lib):
     """BASELINE config C3 semantics at batch 8: x86 qconfig (per-channel weights, [0,127] activations), KD loss on."""
     _run("x86", 22, True, "c3_x86")
+
+
+@pytest.mark.timeout(1200)
+def test_stage_parity_c5_vitb_x86(native_lib):
+    """BASELINE config C5's student (vit_base_patch16_224, /root/reference/src/models/model_registry.py:152-175) at batch 4, x86 qconfig: the D = 768
+    kernel variants - K = 768 int8 GEMMs on the general tile (statistics / code / storing passes), N = 768 / 2304 / 3072 tiles, per-channel scales at
+    3072 channels, the unfused LayerNorm backward (k_ln_bwd_fq), 12 heads - through the same harness as ViT-S."""
+    _run("x86", 23, False, "c5_vitb_x86", arch="vit_base_patch16_224", B=4)
+
+
+@pytest.mark.timeout(1500)
+def test_stage_parity_vits_b64_one_block(native_lib):
+    """Batch 64 (M = 12,608 rows: 61 row tiles, ragged last tile) for blocks 0 and 6 + embedding + head: the row-sum length effects the batch-8 harness
+    cannot see - bias gradients, LayerNorm dgamma / dbeta, the weight gradients' token splits (qat_trainer.py:337-359 at a realistic batch)."""
+    _run("qnnpack", 24, False, "c2_b64_blocks_0_6", B=64, blocks=[0, 6])

@@ -362,3 +362,30 @@ def test_native_teacher_forward_vs_fp64(native_lib, arch, B):
         m64.blocks[0].mlp.fc1.weight.mul_(1.5)
         ref2 = m64.head(m64.forward_features(x.double())[:, 0])
     assert rel_l2(out2.cpu(), ref2.cpu()) < 2e-4
+
+
+def test_native_teacher_forward_at_b256_vs_fp64(native_lib):
+    """The teacher at the batch it is benchmarked at (config C3: qat_trainer.py:337-338 runs it on the training batch, 256 per GPU): the native forward at
+    B = 256 against the fp64 tree on sampled images (no batch statistics anywhere in a ViT, so image i's logits do not depend on the other images) -
+    first / middle / last image and the row-tile boundaries of the 208-row GEMM tiles."""
+    torch.manual_seed(1)
+    m = qat_vit_amd.create_teacher("vit", num_classes=10).cuda().eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+        m.cls_token.normal_(std=0.02)
+    B = 256
+    x = torch.randn(B, 3, 224, 224, device="cuda")
+    with torch.no_grad():
+        out = m(x)
+    from qat_vit_amd.teacher import _ENGINES as T_ENGINES
+
+    assert m in T_ENGINES and out.shape == (B, 10) and torch.isfinite(out).all()
+    idx = [0, 1, 17, 127, 128, 200, 254, 255]
+    m64 = copy.deepcopy(m).double()
+    with torch.no_grad():
+        ref = m64.head(m64.forward_features(x[idx].double())[:, 0])
+    assert rel_l2(out[idx].cpu(), ref.cpu()) < 2e-4
+    for k, i in enumerate(idx):   # per image too: one wrong row tile must not hide in the average
+        assert rel_l2(out[i].cpu(), ref[k].cpu()) < 5e-4, i
