@@ -20,12 +20,13 @@ KNOBS = {
     "QATVIT_I8_STRIP=0": "bits",           # the two-pass K = 384 GEMMs (qkv, fc1) on the general tall tile instead of the A-stationary strip kernel
     "QATVIT_I8=0": "bits",                 # grid x grid GEMMs on bf16 MFMA
     "QATVIT_ATTN_CODES=0": "bits",         # attention backward re-quantises the fp32 qkv (implies the one-pass qkv GEMM)
-    # float tolerance: (logits relative L2, worst parameter-gradient relative L2).  These forms change the arithmetic of a forward float operand by
-    # <= 2^-17 per element; on this depth-2 step that shows up as a handful of one-step code flips downstream - the bounds are ~10x the values
-    # measured (LNB_FUSE: 0 / 3e-7; FC1_RECOMPUTE, F16: 1.2e-4 / 2.5e-3), far below the 0.1 a wrong fallback path would produce
-    "QATVIT_LNB_FUSE=0": (1e-6, 1e-5),      # LayerNorm backward as its own kernel (another summation order for dgamma / dbeta)
-    "QATVIT_FC1_RECOMPUTE=0": (2e-3, 2e-2), # fc1 once, fp32 output, separate fq + GELU pass; fc2 forward then on the bf16 pair (as with QATVIT_F16=0)
-    "QATVIT_F16=0": (2e-3, 2e-2),           # bf16 pairs for the forward float operands (2^-17 instead of 2^-23: one-step flips possible)
+    # float tolerance: (logits relative L2, worst parameter-gradient relative L2).  LNB_FUSE only reorders two fp32 sums.  The other two change a
+    # forward float operand by <= 2^-17 per element, which on this depth-2 step flips a handful of codes by one step (measured 1.6e-2 .. 4.6e-2 on
+    # the logits, 1e-2 .. 2.4e-2 on the gradients): at network level they can only be bounded at flip level, so the gradient DIRECTION is asserted
+    # next to it, and the bf16-pair forward is checked tensor by tensor in test_stage_parity_under_f16_knob below.
+    "QATVIT_LNB_FUSE=0": (1e-6, 5e-6),      # LayerNorm backward as its own kernel (another summation order for dgamma / dbeta)
+    "QATVIT_FC1_RECOMPUTE=0": (0.1, 0.06),  # fc1 once, fp32 output, separate fq + GELU pass; fc2 forward then on the bf16 pair (as with QATVIT_F16=0)
+    "QATVIT_F16=0": (0.1, 0.06),            # bf16 pairs for the forward float operands (2^-17 instead of 2^-23: one-step flips possible)
 }
 ATOMIC = ("bias", "norm", "cls_token", "pos_embed")
 
@@ -78,5 +79,20 @@ def test_knob_forms_match_the_default(native_lib, tmp_path, backend):
                 bad.append((kv, "logits", measured[kv][0]))
             if measured[kv][1] > tol_grads:
                 bad.append((kv, "gradients", measured[kv][1]))
+            ga = torch.cat([got["grads"][n].double().flatten() for n in ref["grads"]])
+            gb = torch.cat([g.double().flatten() for g in ref["grads"].values()])
+            cosv = (ga @ gb / (ga.norm() * gb.norm())).item()
+            if cosv < 0.999:
+                bad.append((kv, "gradient cosine", cosv))
     print("float-tolerance knobs (logits rel L2, worst gradient rel L2):", measured)
     assert not bad, bad
+
+
+@pytest.mark.timeout(900)
+def test_stage_parity_under_f16_knob(native_lib):
+    """QATVIT_F16=0 (bf16 pairs as the float operands of the proj / fc2 FORWARD GEMMs) through the teacher-forced stage harness: every tensor of every
+    stage within the fine table's limits (codes: < 1e-4 differing, one step; rel L2 <= 1e-3) - the check the network-level bound above cannot give."""
+    env = dict(os.environ, QATVIT_F16="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_stage_parity.py"), "-q", "-m", "gpu", "-x", "-k", "c1_qnnpack"],
+                       env=env, capture_output=True, text=True, timeout=850, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]

@@ -277,7 +277,7 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
     # ---- (informational) ONE injection per block, next to the same experiment on the stock torch tree on this GPU: the live floor of
     # that granularity (in-block amplification: a flipped key perturbs a whole head; a flipped norm2 element ~5 % of its row's fc1 codes)
     coarse = Table()
-    coarse_bad = []
+    coarse_rows, floor_max = [], {}
     n_cmp = n_within = 0
     for i in blocks:
         st, pre = f"block{i}", f"model.blocks.{i}"
@@ -302,13 +302,16 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
             if r[1] in floor:
                 coarse.rows[k] = r + (floor[r[1]],)
                 n_cmp += 1
-                ok = r[4] <= 3 * floor[r[1]] + 1e-4
-                n_within += ok
-                if not ok:
-                    coarse_bad.append((st, r[1], r[4], floor[r[1]]))
+                n_within += r[4] <= 3 * floor[r[1]] + 1e-4
+                kind = r[1] if not r[1].startswith("x_in[") else "block output"
+                floor_max[kind] = max(floor_max.get(kind, 0.0), floor[r[1]])
+                coarse_rows.append((st, kind, r[1], r[4], floor[r[1]]))
         del blk
-    # at this granularity a quantizer's codes also move with its SCALE (a different max element after an upstream flip), for the stock tree exactly as
-    # for ours: every row is asserted against 3x the stock-torch-on-this-GPU floor of the same row (+ 1e-4), not against the fine table's limits
+    # At this granularity a quantizer's codes also move with its SCALE (a different max element after an upstream flip), for the stock tree exactly as
+    # for ours, and WHICH block that hits differs between two correct evaluations (measured: stock torch on this GPU vs the CPU oracle reaches 1 - 9 % of
+    # mlp.fc2's codes in some blocks and 0.1 % in others).  Every row is therefore asserted against 3x the LARGEST stock-torch-on-this-GPU deviation
+    # of the same tensor over the blocks (+ 1e-4); rows within 3x the floor of their own block are counted and reported.
+    coarse_bad = [(st, name, v, f, floor_max[kind]) for st, kind, name, v, f in coarse_rows if v > 3 * floor_max[kind] + 1e-4]
     coarse.bad = []
     coarse.write(os.path.join(ROOT, "gpurun_out", f"round3_block_level_vs_floor_{golden_tag}.txt"),
                  f"# ONE injection per block (coarse): native block on the oracle's block input vs the oracle, and the same for the stock torch tree on the same GPU "
@@ -371,10 +374,13 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
     tab.codes("head", "head (logits)", _fq_of_codes(lp, fqm[f"model.head.{A}"], qa, qb), tr.codes(f"model.head.{A}"))
     tab.close("head", "logits", logits, tr.logits, tol=5e-3)            # 80 values on a 256-level grid: one flipped code is 4e-3 here
     # every activation quantizer's state after its one observation: the oracle's, to fp32 rounding of the observed min / max
+    ran = tuple(f"model.blocks.{i}." for i in blocks)
     for n, f in fqm.items():
         if "weight_fake_quant" in n:
             assert torch.allclose(f.scale.cpu(), tr.fq[n].scale, rtol=1e-6), n
             assert torch.equal(f.zero_point.cpu(), tr.fq[n].zero_point), n
+        elif ".blocks." in n and not n.startswith(ran):
+            continue   # (a block this run did not execute teacher-forced: its observers hold the ordinary first step's state)
         else:
             if not (torch.allclose(f.scale.cpu(), tr.fq[n].scale, rtol=2e-5) and (f.zero_point.cpu() - tr.fq[n].zero_point).abs().max().item() <= 1):
                 tab.bad.append(("state", n, "scale/zp", f.scale.item(), tr.fq[n].scale.item()))
@@ -409,7 +415,8 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
     tab.write(path, f"# teacher-forced stage parity, {arch} batch {B}, {backend} qconfig, {'KD' if teacher else 'CE only'}; native stage on the oracle's input vs the oracle "
                     f"(torch {torch.__version__} CPU eager QAT); produced by tests/test_gpu_stage_parity.py")
     tab.check()
-    assert not coarse_bad, ("one injection per block: rows beyond 3x the stock-torch-on-this-GPU floor", coarse_bad[:8], n_within, n_cmp)
+    assert not coarse_bad, ("one injection per block: rows beyond 3x the largest stock-torch-on-this-GPU deviation of that tensor", coarse_bad[:8], n_within, n_cmp)
+    assert n_within >= 0.8 * n_cmp, (n_within, n_cmp)
     return tab
 
 
