@@ -745,7 +745,7 @@ __device__ inline int nt_off32(int row, int chunk) {
 // F16: both operands hold fp16 bit patterns (a float A operand as an fp16 (hi, lo) pair pre-scaled by a power of two, the weight integers
 // as fp16): v_mfma_f32_16x16x32_f16 - same tile, same LDS images, same rate as the bf16 form, 2^-23 instead of 2^-17 per A element.
 template <int TA, int NSTAGE, int WM, int TM, int TB = 1, int WN = 2, int TNT = 4, int BK = 64, int PM = 0, bool I8 = false, bool F16 = false>
-__global__ __launch_bounds__(WM * WN * 64, 2) void k_gemm_nt(const NTArgs p) {   // two waves per SIMD
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void k_gemm_nt(const NTArgs p) {   // one workgroup per CU: two (8 waves) or three (12 waves) waves per SIMD
     // WM x WN waves, each a (16*TM) x (16*TNT) output sub-tile: BM = 16*TM*WM rows x BN = 16*TNT*WN columns per workgroup
     static_assert(BK == 64 || BK == 32, "BK");
     static_assert(!I8 || (TA == 1 && TB == 1 && TM > 4 && BK == 32), "int8 operands: tall single-image tiles only");
@@ -1098,10 +1098,10 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
             case 10: QV_PM(10); break;
             case 5: QV_PM(5); break;
             case 8:
-                if constexpr (TA == 2 && TB == 1 && WM == 1 && WN == 8 && TM == 13 && TNT == 3) QV_PM(8);   // (whole 384-column rows per tile only)
+                if constexpr (TA == 2 && TB == 1 && WM == 1 && WN * TNT == 24 && TM == 13) QV_PM(8);   // (whole 384-column rows per tile only)
                 break;
             case 9:
-                if constexpr (TA == 2 && TB == 1 && WM == 1 && WN == 8 && TM == 13 && TNT == 3) QV_PM(9);   // (the tall tile only)
+                if constexpr (TA == 2 && TB == 1 && WM == 1 && WN * TNT == 24 && TM == 13) QV_PM(9);   // (the tall tile only)
                 break;
             default: QV_PM(0); break;
         }
@@ -1506,7 +1506,8 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
         if (s < nsteps) issue(s);
 
     for (int s = 0; s < nsteps; ++s) {
-        if (NSTAGE == 3 && s + 1 < nsteps) wait_vmcnt<NDMA>();
+        // tile s has landed once at most the NSTAGE - 2 younger tiles' DMAs (this wave's share) are still outstanding
+        if (NSTAGE >= 3 && s + NSTAGE - 2 < nsteps) wait_vmcnt<(NSTAGE - 2) * NDMA>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1692,7 +1693,7 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     // is a multiple of 384.  (Measured at B=256: wide wins for a grid Q operand, 110/133 us vs 113/148; with a split Q (32-row steps) it wins when
     // there are enough wide tiles - fc2 wgrad, 12 tiles: 169 vs 181 us - and loses when few tiles mean many splits - proj wgrad, 3 tiles: 84 vs 56 us)
     const bool wide = (Kw % 384 == 0) && (!Q_lo || (N / 128) * (Kw / 384) >= 8);
-    const int bk = (wide && Q_lo) ? 32 : 64;        // the split-Q wide stage only fits with 32-row steps
+    const int bk = wide ? 32 : 64;                  // wide tiles: 32-token steps (split Q: the stage only fits that way; grid Q: a 4-deep ring)
     const int tiles = (N / 128) * (Kw / (wide ? 384 : 128));
     const int splits = tn_plan(a, M, bk, tiles);
     const int grid = tiles * splits;
@@ -1710,7 +1711,7 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     } while (0)
     if (wide) {
         if (Q_lo) QV_TN_LAUNCH(2, 2, 2, 4, 6, 32);   // 2 x (16 + 48) KiB = 128 KiB
-        else QV_TN_LAUNCH(1, 2, 2, 4, 6, 64);        // 2 x (32 + 48) KiB = 160 KiB
+        else QV_TN_LAUNCH(1, 4, 2, 4, 6, 32);        // 4 x (16 + 24) KiB = 160 KiB: three 32-token tiles in flight (2 x 64-token stages: 117.5 -> 109 us)
     } else {
         if (Q_lo) QV_TN_LAUNCH(2, 2, 4, 2, 4, 64);   // 2 x 64 KiB
         else QV_TN_LAUNCH(1, 3, 4, 2, 4, 64);        // 3 x 48 KiB

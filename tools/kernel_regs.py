@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-c", src, "-o", "/tmp/kernel_regs.o",
+r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-c", src, "-o", "/tmp/kernel_regs.o"] + sys.argv[3:] + [
                     "-Rpass-analysis=kernel-resource-usage"], cwd=os.path.join(ROOT, "qat-vit_amd", "csrc"), capture_output=True, text=True)
 cur, rows = None, {}
 for ln in r.stderr.splitlines():
