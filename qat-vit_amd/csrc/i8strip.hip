@@ -11,7 +11,7 @@
 //   MODE 4   fc1:  uint8 grid indices [M, ldc] + STE mask bits [M, ldc / 8] (+ the two 256-entry gelu tables fc2's forward / weight gradient expand them through)
 // Structure (one workgroup = 8 waves = one 208-row strip of A, M = B * 197 rows -> 243 strips = one round on 256 CUs):
 //   * the strip's int8 A rows (208 x 384 B = 78 KiB) are fetched ONCE by LDS-DMA and stay in LDS for all 3 - 4 column tiles of 384;
-//   * wave w owns columns 48 w .. 48 w + 47 of every column tile.  Its weight fragments belong to nobody else, so they never touch LDS: the
+//   * wave w owns columns WC w .. WC w + WC - 1 of every column tile (WC = 48 with 8 waves, 32 with 12).  Its weight fragments belong to nobody else, so they never touch LDS: the
 //     weight prepared once per step in FRAGMENT ORDER (w8f: [48-column group][k-step][fragment][lane] x 16 B, written by k_w_quant_all) is
 //     read straight into registers, 1 KiB contiguous per wave-instruction, one k-step ahead;
 //   * hence the k-loop has NO barrier and NO LDS write: 13 A-fragment ds_read_b128 + 39 MFMAs per k-step per wave, waves run freely;
@@ -80,13 +80,14 @@ __device__ inline void strip_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\
 #define QV_STAMP() ((void)0)
 #endif
 
-template <int MODE, int NTL>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384
-__global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
-    constexpr int TM = 13, TNT = 3, BM = 208, BN = 384, KT = 6, PF = 3;
+template <int MODE, int NTL, int NWV = 8>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384; NWV waves, each 208 rows x WC = 384 / NWV columns
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArgs p) {
+    constexpr int TM = 13, TNT = 24 / NWV, WC = 16 * TNT, BM = 208, BN = 384, KT = 6, PF = 3, NT_ = NWV * 64;
+    static_assert(NWV == 8 || NWV == 12, "8 waves x 48 columns or 12 waves x 32 columns");
     constexpr int IMGA = BM * 64, LA = KT * IMGA;        // 79,872 B
     constexpr int NC = NTL * BN;                         // columns of this workgroup
     constexpr int CH = 4;                                // row fragments per staging chunk: 64 rows x 48 columns of codes + 64 x 8 B of mask bits per wave
-    constexpr int WSTG = 16 * CH * 48 + 16 * CH * 16;    // 4 KiB per wave: [64][48 B] codes + [64][16 B] mask nibbles
+    constexpr int WSTG = 16 * CH * WC + 16 * CH * 16;    // per wave: [64][WC B] codes + [64][16 B] mask nibbles
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
     int* sCorr = reinterpret_cast<int*>(smem + LA);      // per-column constants of the epilogue: corr | ca | cb, [NC] each
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     auto stamp = [&]() {   // s_memtime stamps of workgroups 0 and 100 (tools/stamp_i8strip.py); p.dbg is NULL outside that tool
         if (p.dbg && (blockIdx.x == 0 || blockIdx.x == 100) && blockIdx.y == 0) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (lane == 0 && nstamp < 32) p.dbg[((blockIdx.x ? 1 : 0) * 8 + wave) * 32 + nstamp] = t;
+            if (lane == 0 && nstamp < 32) p.dbg[((blockIdx.x ? 1 : 0) * 8 + (wave & 7)) * 32 + nstamp] = t;
             ++nstamp;
         }
     };
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int q = c * 8 + wave;
+                const int q = c * NWV + wave;
                 if (q < TM) {
                     const uint32_t off = (uint32_t)((int64_t)(m0 + q * 16 + prow) * p.lda + kt * 64 + pk * 16);   // rows past M read as zero
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(sA + kt * IMGA + q * 1024), 16, off, 0, 0, 0);
@@ -129,11 +130,13 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     // this wave's weight fragments: group (nbase / 48 + 8 nt + wave), k-step kt, fragment j: 1 KiB each, lane * 16 B inside.  Buffer loads with the
     // fragment's offset in an SGPR (one VGPR of address for all 18 fragments of a column tile: as 64-bit global addresses they were 36 registers)
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4*>(p.Bf), 0, (uint32_t)((int64_t)p.N * 384), 0x00020000);
-    const int bgrp = (nbase / 48 + wave) * (KT * TNT);   // (uniform) fragment index of (nt = 0, kt = 0, j = 0)
+    // (w8f order: 16-column fragment f = column / 16 lives at ((f / 3) * KT + kt) * 3 + f % 3, in units of 1 KiB)
+    const int f0 = nbase / 16 + wave * TNT;              // (uniform) this wave's first fragment of column tile 0
     auto load_b = [&](int nt, int kt, i32x4 (&b)[TNT]) {
 #pragma unroll
         for (int j = 0; j < TNT; ++j) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rB, lane * 16, (bgrp + nt * 8 * (KT * TNT) + kt * TNT + j) * 1024, 0);
+            const int f = f0 + nt * 24 + j;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rB, lane * 16, (((f / 3) * KT + kt) * 3 + f % 3) * 1024, 0);
             b[j] = __builtin_bit_cast(i32x4, v);
         }
     };
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     {
         const float alpha = *p.s1 * (p.s2 ? *p.s2 : 1.0f);
         const int zc = p.center - (int)p.aqp[2];
-        for (int c = tid; c < NC; c += 512) {
+        for (int c = tid; c < NC; c += NT_) {
             sCorr[c] = zc * p.wsum[nbase + c];
             sCa[c] = alpha * (p.col_scale ? p.col_scale[nbase + c] : 1.0f);
             sCb[c] = p.bias ? p.bias[nbase + c] : 0.0f;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
     }
     struct Consts { float4 ca, cb; };
     auto consts_of = [&](int nt, int j, int g) {
-        const int c = nt * BN + wave * 48 + 16 * j + 4 * g;   // this lane's 4 columns of fragment j
+        const int c = nt * BN + wave * WC + 16 * j + 4 * g;   // this lane's 4 columns of fragment j
         return Consts{*reinterpret_cast<const float4*>(sCa + c), *reinterpret_cast<const float4*>(sCb + c)};
     };
 
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
         i32x4 cinit[TNT];
 #pragma unroll
         for (int j = 0; j < TNT; ++j) {
-            const int4 c = *reinterpret_cast<const int4*>(sCorr + nt * BN + wave * 48 + 16 * j + 4 * g);
+            const int4 c = *reinterpret_cast<const int4*>(sCorr + nt * BN + wave * WC + 16 * j + 4 * g);
             cinit[j] = i32x4{c.x, c.y, c.z, c.w};
         }
         // ---- k-loop: no barrier, no LDS write; weight fragments one k-step ahead in registers
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MODE != 3) {
-            if (((wave >> 2) ^ nt) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (wave is an SGPR: a scalar branch)
+            if (((wave >> 2) + nt) % (NWV / 4) == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (wave is an SGPR: a scalar branch)
         }
         QV_STAMP();   // k-loop done
 
@@ -284,9 +287,9 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
             asm volatile("" : "+v"(tid2));
             const int lane2 = tid2 & 63, r2 = lane2 & 15, g2 = lane2 >> 4;
             char* sW = sStage + wave * WSTG;             // this wave's staging area: [64][48 B] codes, then [64][16 B]: the 4 mask bits of fragment j, lane group g in byte 4 j + g
-            char* sWm = sW + 16 * CH * 48;
+            char* sWm = sW + 16 * CH * WC;
             // output geometry of this wave's 48 columns
-            const int which = MODE == 7 ? tilebase / p.D : 0, cm0 = MODE == 7 ? tilebase % p.D + wave * 48 : 0, Hh = MODE == 7 ? p.D >> 6 : 0;
+            const int which = MODE == 7 ? tilebase / p.D : 0, cm0 = MODE == 7 ? tilebase % p.D + wave * WC : 0, Hh = MODE == 7 ? p.D >> 6 : 0;
             const float invT = MODE == 7 ? 1.0f / (float)p.code_T : 0.f;
 #pragma unroll
             for (int c0 = 0; c0 < TM; c0 += CH) {        // chunks of 4 row fragments (64 rows); the last one holds 1 (16 rows)
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
                             const unsigned long long inr = __builtin_amdgcn_fcmpf(u, uc, 1 /* FCMP_OEQ */);
                             asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(mk) : "s"(inr) : "vcc");
                         }
-                        *reinterpret_cast<uint32_t*>(sW + rl * 48 + 16 * j + 4 * g2) = pk;
+                        *reinterpret_cast<uint32_t*>(sW + rl * WC + 16 * j + 4 * g2) = pk;
                         // the lane's 4 mask bits as a byte of their own; the reader squeezes four of them into 16 bits.  (Pairing the nibbles of two
                         // lanes here - ds_bpermute - put an LDS round trip with a full wait behind every fragment: 39 per tile, ~5 k cycles)
                         reinterpret_cast<uint8_t*>(sWm)[rl * 16 + 4 * j + g2] = (uint8_t)mk;
@@ -320,18 +323,18 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const int row0 = m0 + 16 * c0;
 #pragma unroll
-                for (int k3 = 0; k3 < 3; ++k3) {
-                    if (k3 * 64 >= nf * 48) continue;    // (16-row chunk: 48 pieces - the first instruction's lanes 0 .. 47)
-                    const int pc = lane2 + 64 * k3;      // 16-B piece: row pc / 3, chunk pc % 3 - the staging area read linearly
-                    const int rl = pc / 3, c = pc - 3 * rl, row = row0 + rl;
-                    const bool ok = pc < nf * 48 && row < p.M;
+                for (int k3 = 0; k3 < TNT; ++k3) {
+                    if (k3 * 64 >= nf * 16 * TNT) continue;   // (16-row chunk: 16 TNT pieces - the first instruction's lanes only)
+                    const int pc = lane2 + 64 * k3;      // 16-B piece: row pc / TNT, chunk pc % TNT - the staging area read linearly
+                    const int rl = pc / TNT, c = pc - TNT * rl, row = row0 + rl;
+                    const bool ok = pc < nf * 16 * TNT && row < p.M;
                     const uint4 v = *reinterpret_cast<const uint4*>(sW + 16 * pc);   // (always inside the staging area)
                     // mask bits of the same 16 columns: four nibble bytes (lane groups 0 .. 3 of fragment c) -> 16 bits
                     uint32_t mx4 = *reinterpret_cast<const uint32_t*>(sWm + rl * 16 + 4 * c) & 0x0f0f0f0fu;
                     mx4 = (mx4 | (mx4 >> 4)) & 0x00ff00ffu;
                     const uint16_t mv = (uint16_t)((mx4 | (mx4 >> 8)) & 0xffffu);
                     if constexpr (MODE == 4) {
-                        const int64_t eo = (int64_t)row * p.ldc + tilebase + wave * 48 + 16 * c;
+                        const int64_t eo = (int64_t)row * p.ldc + tilebase + wave * WC + 16 * c;
                         if (ok) {
                             *reinterpret_cast<uint4*>(p.out8 + eo) = v;
                             *reinterpret_cast<uint16_t*>(p.out8_mask + (eo >> 3)) = mv;
@@ -358,27 +361,35 @@ __global__ __launch_bounds__(512, 2) void k_i8_strip(const I8StripArgs p) {
         float* sRed = reinterpret_cast<float*>(sStage);
         mn = wave_min(mn);
         mx = wave_max(mx);
-        if (lane == 0) { sRed[wave] = mn; sRed[8 + wave] = mx; }
+        if (lane == 0) { sRed[wave] = mn; sRed[16 + wave] = mx; }
         strip_lds_barrier();
         if (tid == 0) {
 #pragma unroll
-            for (int w = 1; w < 8; ++w) { mn = fminf(mn, sRed[w]); mx = fmaxf(mx, sRed[8 + w]); }
+            for (int w = 1; w < NWV; ++w) { mn = fminf(mn, sRed[w]); mx = fmaxf(mx, sRed[16 + w]); }
         }
         if (tid == 0) stat_atomic(p.stats, p.stat_slots, mn, mx);
     }
 }
 
+template <int MODE, int NTL, int NWV>
+static void strip_launch_w(const I8StripArgs& a, hipStream_t st) {
+    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : NWV * (64 * (384 / NWV) + 64 * 16));
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+    (void)once;
+    k_i8_strip<MODE, NTL, NWV><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), NWV * 64, kLds, st>>>(a);
+}
 template <int MODE, int NTL>
 static void strip_launch(const I8StripArgs& a0, hipStream_t st) {
-    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : 8 * (64 * 48 + 64 * 16));
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
-    (void)once;
     I8StripArgs a = a0;
 #ifdef QV_STRIP_EXPERIMENTS
     const char* d = getenv("QATVIT_STRIP_DBG");   // (read per launch: tools/stamp_i8strip.py)
     a.dbg = d ? reinterpret_cast<unsigned long long*>(strtoull(d, nullptr, 0)) : nullptr;
 #endif
-    k_i8_strip<MODE, NTL><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), 512, kLds, st>>>(a);
+    // statistics pass: 8 waves x 48 columns (two per SIMD); code passes: 12 waves x 32 columns (three per SIMD, 104 accumulator registers) - their
+    // quantise phase is VALU-issue-bound per wave, and a third wave per SIMD fills it: qkv 45.5 -> 42.9 us, fc1 54.4 -> 50.4 us (the statistics
+    // pass does not gain: 27.4 -> 28.0)
+    if constexpr (MODE == 3) strip_launch_w<MODE, NTL, 8>(a, st);
+    else strip_launch_w<MODE, NTL, 12>(a, st);
 }
 
 // true when the strip kernel covers the request (the caller then launched it); false -> the general tall kernel
