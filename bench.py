@@ -367,7 +367,7 @@ def main():
         hbm_bound = g.get("roofline_bound") == "hbm"
         traffic, traffic_note = None, None
         try:   # HBM-side bytes per launch: NOT measured by this run - offline rocprofv3 --pmc passes at B=256 shapes (tools/pmc_traffic.sh)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round2_gemm_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round3_gemm_pmc_traffic.json")))
             if args.batch == 256 and args.student == "vit_small" and str(dom) in pm:
                 traffic = round(pm[str(dom)]["bytes_per_launch"])
                 traffic_note = "STATIC, not measured in this run: " + pm[str(dom)]["note"]

@@ -80,7 +80,8 @@ __device__ inline void strip_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\
 #define QV_STAMP() ((void)0)
 #endif
 
-template <int MODE, int NTL, int NWV = 8>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384; NWV waves, each 208 rows x WC = 384 / NWV columns
+// R255: the output quantizer has 256 levels (qmax - qmin == 255): v_cvt_pk_u8_f32's own saturation is the clamp
+template <int MODE, int NTL, int NWV = 8, bool R255 = false>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384; NWV waves, each 208 rows x WC = 384 / NWV columns
 __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArgs p) {
     constexpr int TM = 13, TNT = 24 / NWV, WC = 16 * TNT, BM = 208, BN = 384, KT = 6, PF = 3, NT_ = NWV * 64;
     static_assert(NWV == 8 || NWV == 12, "8 waves x 48 columns or 12 waves x 32 columns");
@@ -278,8 +279,11 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
             }
         } else {
             // u = rint(v / s) + (zp - qmin) = q - qmin (small-integer float arithmetic: exact, the same value as (rint(v / s) + zp) - qmin);
-            // code = clamp(u, 0, qmax - qmin), in range <=> u == clamp(u)
+            // code = clamp(u, 0, qmax - qmin).  In range <=> 0 <= u <= range <=> the BIT PATTERN of u, as an unsigned integer, is <= that of range:
+            // non-negative floats order like their bits, a negative u has the sign bit set (u is never -0: rint(.) + zoff with zoff >= +0), a NaN
+            // is above every finite pattern - one integer compare, no clamp needed for the test
             const float qinv = p.qp[1], zoff = p.qp[2] - (float)p.qmin, frange = (float)(p.qmax - p.qmin);
+            const uint32_t range_bits = __builtin_bit_cast(uint32_t, frange);
             const int tilebase = nbase + nt * BN;
             // (lane-derived values are re-derived from an opaque copy of the thread id: kept live across the k-loop they are spilled, and every
             //  reload from scratch is an s_waitcnt vmcnt(0) - a wait for all global stores in flight)
@@ -306,10 +310,10 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
 #pragma unroll
                         for (int e = 3; e >= 0; --e) {
                             const float v = (float)acc[i][j][e] * ka[e] + kb[e];
-                            const float u = rintf(v * qinv) + zoff, uc = __builtin_amdgcn_fmed3f(u, 0.0f, frange);
-                            pk = __builtin_amdgcn_cvt_pk_u8_f32(uc, e, pk);
-                            // mk = 2 mk + (u == uc): the comparison's lane mask is the carry-in of ONE add (v_cndmask + v_or otherwise)
-                            const unsigned long long inr = __builtin_amdgcn_fcmpf(u, uc, 1 /* FCMP_OEQ */);
+                            const float u = rintf(v * qinv) + zoff;
+                            pk = __builtin_amdgcn_cvt_pk_u8_f32(R255 ? u : fminf(u, frange), e, pk);   // (the conversion saturates at 0 and 255 itself)
+                            // mk = 2 mk + (in range): the comparison's lane mask is the carry-in of ONE add (v_cndmask + v_or otherwise)
+                            const unsigned long long inr = __builtin_amdgcn_uicmp(__builtin_bit_cast(uint32_t, u), range_bits, 37 /* ICMP_ULE */);
                             asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(mk) : "s"(inr) : "vcc");
                         }
                         *reinterpret_cast<uint32_t*>(sW + rl * WC + 16 * j + 4 * g2) = pk;
@@ -334,7 +338,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
                     mx4 = (mx4 | (mx4 >> 4)) & 0x00ff00ffu;
                     const uint16_t mv = (uint16_t)((mx4 | (mx4 >> 8)) & 0xffffu);
                     if constexpr (MODE == 4) {
-                        const int64_t eo = (int64_t)row * p.ldc + tilebase + wave * WC + 16 * c;
+                        // (24-bit multiplies: row < 2^22 and ldc < 2^24 are checked by the launcher; the 32-bit forms run at a quarter of the rate)
+                        const uint32_t eo = __umul24((uint32_t)row, (uint32_t)p.ldc) + (uint32_t)(tilebase + wave * WC + 16 * c);
                         if (ok) {
                             *reinterpret_cast<uint4*>(p.out8 + eo) = v;
                             *reinterpret_cast<uint16_t*>(p.out8_mask + (eo >> 3)) = mv;
@@ -342,8 +347,9 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
                     } else {
                         // attention layout [b][h][q|k|v][t][d], head_dim 64: a 16-B piece lies inside one head's row
                         const int cm = cm0 + 16 * c, hh = cm >> 6, d = cm & 63;
-                        const int bb_ = (int)(((float)row + 0.5f) * invT), tt = row - bb_ * p.code_T;   // (exact for row < 2^22: checked by the launcher)
-                        const int64_t eo = ((((int64_t)bb_ * Hh + hh) * 3 + which) * p.code_T + tt) * 64 + d;
+                        const int bb_ = (int)(((float)row + 0.5f) * invT), tt = row - (int)__umul24((uint32_t)bb_, (uint32_t)p.code_T);   // (exact for row < 2^22: checked by the launcher)
+                        // (every factor below 2^24 and the element offset below 2^32 - checked by the launcher: 24-bit multiplies, 32-bit offset)
+                        const uint32_t eo = ((__umul24(__umul24((uint32_t)(bb_ * Hh + hh), 3u) + (uint32_t)which, (uint32_t)p.code_T) + (uint32_t)tt) << 6) + (uint32_t)d;
                         if (ok) {
                             *reinterpret_cast<uint4*>(p.out8 + eo) = v;
                             *reinterpret_cast<uint16_t*>(p.out8_mask + (eo >> 3)) = mv;
@@ -371,12 +377,17 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
     }
 }
 
+template <int MODE, int NTL, int NWV, bool R255>
+static void strip_launch_r(const I8StripArgs& a, hipStream_t st) {
+    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : NWV * (64 * (384 / NWV) + 64 * 16));
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, NWV, R255>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+    (void)once;
+    k_i8_strip<MODE, NTL, NWV, R255><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), NWV * 64, kLds, st>>>(a);
+}
 template <int MODE, int NTL, int NWV>
 static void strip_launch_w(const I8StripArgs& a, hipStream_t st) {
-    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : NWV * (64 * (384 / NWV) + 64 * 16));
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
-    (void)once;
-    k_i8_strip<MODE, NTL, NWV><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), NWV * 64, kLds, st>>>(a);
+    if (MODE != 3 && a.qmax - a.qmin == 255) strip_launch_r<MODE, NTL, NWV, true>(a, st);
+    else strip_launch_r<MODE, NTL, NWV, false>(a, st);
 }
 template <int MODE, int NTL>
 static void strip_launch(const I8StripArgs& a0, hipStream_t st) {
@@ -397,7 +408,7 @@ bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
                      const NTPost* post, bool force) {
     static const int on = getenv("QATVIT_I8_STRIP") ? atoi(getenv("QATVIT_I8_STRIP")) : 1;   // 0: the general tall kernel (A/B arm of the bit-identity test)
-    if ((!on && !force) || !B8f || !post || K != 384 || lda % 16 != 0 || !s1 || M >= (1 << 22)) return false;
+    if ((!on && !force) || !B8f || !post || K != 384 || lda % 16 != 0 || !s1 || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24)) return false;
     const int ntl = N % (4 * 384) == 0 ? 4 : N % (3 * 384) == 0 ? 3 : 0;
     if (!ntl) return false;
     I8StripArgs a{};
