@@ -285,6 +285,11 @@ int qatvit_student_backward_stages(const qatvit_cfg* cfg, void* const* params, c
 int64_t qatvit_teacher_workspace_bytes(const qatvit_cfg* cfg);
 int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* const* w_hi, void* const* w_lo,
                            const float* images, float* logits, void* workspace, void* stream);
+/* The same forward on fp16 MFMA (v_mfma_f32_16x16x32_f16): w16 = the 2-D weights rounded to fp16 (same order as w_hi; the caller checks
+ * |w| < 65504), activations as an fp16 (hi, lo) pair (passes == 2: 22 significant bits x 11) or as fp16 alone (passes == 1).  Same workspace.
+ * embed_dim and mlp_hidden multiples of 384.  Error against the fp64 tree and time per form: profiles/round3_teacher_precision.txt. */
+int qatvit_teacher_forward_f16(const qatvit_cfg* cfg, void* const* params, void* const* w16, int32_t passes,
+                               const float* images, float* logits, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Integer inference forward of the trained student from its exported integers.

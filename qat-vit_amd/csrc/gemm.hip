@@ -97,6 +97,7 @@ struct NTArgs {
     // Optional fused consumer (fc2 dgrad -> GELU backward): instead of storing C, store the (hi, lo) bf16 pair of
     //   C * gelu'(fq(Y)) * mask(Y) * post_colscale[col],  Y = the pre-FQ fc1 output [M,ldc], post_qp = {scale, 1/scale, zp, enabled}
     int post_gelu_fwd;       // 1: store (hi, lo) of gelu(C) to out_hi / out_lo instead of C (no Y, no mask)
+    int out_f16;             // with post_gelu_fwd: the pair in fp16 (out_lo may be NULL) - the fp16 teacher forward
     int post_mode;           // NTPost::mode 3 / 4 / 5 (0 otherwise)
     // int8 operands (template flag I8): A holds q - center, B the weight integers; the k extent / strides are then counted in 2-byte units
     const int32_t* i8_wsum;  // [N] row sums of the int8 weight: C = (acc + (center - zp) * wsum[n]) * alpha + bias
@@ -682,17 +683,30 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         if ((lane & 7) == 0) *reinterpret_cast<uint32_t*>(p.out8_mask + eo / 8) = mk;
                     }
                 } else if constexpr (PM == 2) {
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     const float cv[4] = {v.x, v.y, v.z, v.w};
-                    bf16x4 oh, ol;
+                    if (p.out_f16) {   // (uniform) the fp16 teacher forward: the pair (or, out_lo == NULL, the hi part alone) in fp16
+                        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                        f16x4 oh, ol;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float o = gelu_fwd_fast(cv[e]);
-                        oh[e] = (__bf16)o;
-                        ol[e] = (__bf16)(o - (float)oh[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            const float o = gelu_fwd_fast(cv[e]);
+                            oh[e] = (_Float16)o;
+                            ol[e] = (_Float16)(o - (float)oh[e]);
+                        }
+                        *reinterpret_cast<f16x4*>(p.out_hi + off) = oh;
+                        if (p.out_lo) *reinterpret_cast<f16x4*>(p.out_lo + off) = ol;
+                    } else {
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 oh, ol;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float o = gelu_fwd_fast(cv[e]);
+                            oh[e] = (__bf16)o;
+                            ol[e] = (__bf16)(o - (float)oh[e]);
+                        }
+                        *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
+                        *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
                     }
-                    *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
-                    *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
                 } else {
                     *reinterpret_cast<float4*>(p.C + off) = v;
                 }
@@ -1079,7 +1093,7 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
         k_gemm_nt<TA, NS, WM, TM, TB, WN, TNT, BK, PM_, I8, F16><<<grid, WM * WN * 64, lds, st>>>(a);          \
     } while (0)
     if constexpr (F16) {   // proj / fc2 forward: plain epilogue (training: the observer needs the pre-FQ tensor) or the fused residual update (inference)
-        if (a.pm == 6) QV_PM(6); else QV_PM(0);
+        if (a.pm == 6) QV_PM(6); else if (a.pm == 2) QV_PM(2); else QV_PM(0);
     } else if constexpr (I8) {   // the grid x grid forward GEMMs
         switch (a.pm) {
             case 3: QV_PM(3); break;
@@ -1112,8 +1126,9 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
 int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                    const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
                    const void* B_lo, const NTPost* post, bool f16) {
-    if (f16 && (!A_lo || B_lo || (post && post->mode != 6) || N % 384 != 0 || K % 32 != 0)) {
-        set_error("gemm_nt: the fp16 form takes a split A operand, N %% 384 == 0, the plain or the residual (mode 6) epilogue (N=%d K=%d)", N, K);
+    const bool f16_gelu = f16 && post && post->mode == 0 && !post->Y && post->out_f16;   // the teacher's fc1: fp16 gelu pair out
+    if (f16 && (B_lo || (post && post->mode != 6 && !f16_gelu) || (!A_lo && post && !f16_gelu) || N % 384 != 0 || K % 32 != 0)) {
+        set_error("gemm_nt: the fp16 form takes N %% 384 == 0 and the plain, the residual (mode 6) or the fp16 GELU epilogue (N=%d K=%d)", N, K);
         return 1;
     }
     if (M < 1 || N % 128 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) {
@@ -1168,8 +1183,10 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     } else if (post && !post->Y) {
         a.post_gelu_fwd = 1;
         a.pm = 2;
+        a.out_f16 = post->out_f16;
         a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
-        if (!a.out_hi || !a.out_lo) { set_error("gemm_nt: fused GELU epilogue needs out_hi / out_lo"); return 1; }
+        if (!a.out_hi || (!a.out_lo && !f16_gelu)) { set_error("gemm_nt: fused GELU epilogue needs out_hi / out_lo"); return 1; }
+        if (post->out_f16 && !f16) { set_error("gemm_nt: the fp16 GELU pair is written by the fp16 form only"); return 1; }
     } else if (post) {
         a.pm = 1;
         a.postY = post->Y; a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.post_colscale = post->colscale;
@@ -1192,7 +1209,8 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         return 0;
     }
     if (f16) {
-        nt_launch<2, 3, 1, 13, 1, 8, 3, 32, false, true>(a, cdiv(M, 208) * (N / 384), (size_t)3 * (2 * 208 + 384) * 64, st);   // 150 KiB
+        if (A_lo) nt_launch<2, 3, 1, 13, 1, 8, 3, 32, false, true>(a, cdiv(M, 208) * (N / 384), (size_t)3 * (2 * 208 + 384) * 64, st);   // 150 KiB
+        else nt_launch<1, 3, 1, 13, 1, 8, 3, 32, false, true>(a, cdiv(M, 208) * (N / 384), (size_t)3 * (208 + 384) * 64, st);        // 111 KiB (one-pass teacher)
         return 0;
     }
     if (N % 384 == 0) {

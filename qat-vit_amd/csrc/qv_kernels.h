@@ -79,6 +79,8 @@ struct NTPost {
     float* lnb_dgamma = nullptr;
     float* lnb_dbeta = nullptr;
     const void* lnb_nmask = nullptr;
+    // mode 2 only: the gelu(C) pair as fp16 instead of bf16 (the fp16 teacher forward); out_lo may then be NULL (one-pass form)
+    int out_f16 = 0;
 };
 
 // ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)

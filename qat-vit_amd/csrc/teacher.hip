@@ -22,7 +22,21 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ inline void st_split4(__bf16* hi, __bf16* lo, int64_t off, float a, float b, float c, float d) {
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// (hi, lo) pair of four values: bf16 (8 + 8 significant bits) or, f16 != 0 (uniform), fp16 (11 + 11; unscaled: the teacher's GEMM inputs - LayerNorm
+// outputs, attention outputs, GELU outputs, image patches - are far inside fp16's range).  lo == nullptr: the one-pass form keeps the hi part only.
+__device__ inline void st_split4(__bf16* hi, __bf16* lo, int64_t off, float a, float b, float c, float d, int f16 = 0) {
+    if (f16) {
+        f16x4 h, l;
+        h[0] = (_Float16)a; h[1] = (_Float16)b; h[2] = (_Float16)c; h[3] = (_Float16)d;
+        *reinterpret_cast<f16x4*>(hi + off) = h;
+        if (lo) {
+            l[0] = (_Float16)(a - (float)h[0]); l[1] = (_Float16)(b - (float)h[1]); l[2] = (_Float16)(c - (float)h[2]); l[3] = (_Float16)(d - (float)h[3]);
+            *reinterpret_cast<f16x4*>(lo + off) = l;
+        }
+        return;
+    }
     bf16x4 h, l;
     h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
     l[0] = (__bf16)(a - (float)h[0]); l[1] = (__bf16)(b - (float)h[1]); l[2] = (__bf16)(c - (float)h[2]); l[3] = (__bf16)(d - (float)h[3]);
@@ -32,7 +46,7 @@ __device__ inline void st_split4(__bf16* hi, __bf16* lo, int64_t off, float a, f
 
 // image [B,C,H,W] fp32 -> patch rows [B*np, C*P*P] as a (hi, lo) pair
 __global__ __launch_bounds__(256) void k_patches_split(const float* __restrict__ img, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int B, int C,
-                                                       int H, int W, int P) {
+                                                       int H, int W, int P, int f16) {
     const int gw = W / P, gh = H / P, K = C * P * P;
     const int64_t n4 = (int64_t)B * gh * gw * K / 4;
     for (int64_t e4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e4 < n4; e4 += (int64_t)gridDim.x * blockDim.x) {
@@ -42,7 +56,7 @@ __global__ __launch_bounds__(256) void k_patches_split(const float* __restrict__
         const int px = (int)(prow % gw), py = (int)((prow / gw) % gh), b = (int)(prow / ((int64_t)gw * gh));
         const int j = col % P, i = (col / P) % P, c = col / (P * P);
         const float4 v = *reinterpret_cast<const float4*>(img + (((int64_t)b * C + c) * H + py * P + i) * W + px * P + j);
-        st_split4(hi, lo, e, v.x, v.y, v.z, v.w);
+        st_split4(hi, lo, e, v.x, v.y, v.z, v.w, f16);
     }
 }
 
@@ -56,7 +70,7 @@ template <int MODE, int NV>
 __global__ __launch_bounds__(256) void k_resid_ln_split(const float* __restrict__ x_prev, const float* __restrict__ Y, const float* __restrict__ cls,
                                                         const float* __restrict__ pos, float* __restrict__ x_new, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, __bf16* __restrict__ h_hi,
-                                                        __bf16* __restrict__ h_lo, int64_t M, int D, int T) {
+                                                        __bf16* __restrict__ h_lo, int64_t M, int D, int T, int f16) {
     const int lane = threadIdx.x & 63;
     bool act[NV];
     int cc[NV];
@@ -103,7 +117,7 @@ __global__ __launch_bounds__(256) void k_resid_ln_split(const float* __restrict_
         for (int j = 0; j < NV; ++j)
             if (act[j])
                 st_split4(h_hi, h_lo, row * D + cc[j], v[j].x * rs * g[j].x + bb[j].x, v[j].y * rs * g[j].y + bb[j].y, v[j].z * rs * g[j].z + bb[j].z,
-                          v[j].w * rs * g[j].w + bb[j].w);
+                          v[j].w * rs * g[j].w + bb[j].w, f16);
     }
 }
 template <int MODE, typename... A>
@@ -204,7 +218,7 @@ __device__ inline bool t_wave_retile8(float* sO, const f32x4 (&acc)[HD / 16], fl
 constexpr int kTW = 8;  // waves per workgroup
 template <int HD, int NKT>
 __global__ __launch_bounds__(kTW * 64) void k_attn_fwd_float(const float* __restrict__ qkv, int B, int T, int H, int D, float scale,
-                                                             __bf16* __restrict__ O_hi, __bf16* __restrict__ O_lo) {
+                                                             __bf16* __restrict__ O_hi, __bf16* __restrict__ O_lo, int f16) {
     constexpr int IMG = NKT * 16 * HD * 2, CH = HD / 8, KK = HD / 32, ND = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sKh = smem;            // row images of K (hi, lo)
@@ -315,12 +329,20 @@ __global__ __launch_bounds__(kTW * 64) void k_attn_fwd_float(const float* __rest
             const bool act = t_wave_retile8<HD>(sO, o, 1.0f, lane, half, ov, orow, oc);
             const int qq = qt * 16 + 8 * half + orow;
             if (act && qq < T) {
-                bf16x8 hv, lv;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { hv[j] = (__bf16)ov[j]; lv[j] = (__bf16)(ov[j] - (float)hv[j]); }
                 const int64_t off = ((int64_t)b * T + qq) * D + h * HD + 8 * oc;
-                *reinterpret_cast<bf16x8*>(O_hi + off) = hv;
-                *reinterpret_cast<bf16x8*>(O_lo + off) = lv;
+                if (f16) {   // (uniform) the output pair in fp16 for the fp16 proj GEMM; the one-pass form keeps the hi part only
+                    f16x8 hv, lv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { hv[j] = (_Float16)ov[j]; lv[j] = (_Float16)(ov[j] - (float)hv[j]); }
+                    *reinterpret_cast<f16x8*>(O_hi + off) = hv;
+                    if (O_lo) *reinterpret_cast<f16x8*>(O_lo + off) = lv;
+                } else {
+                    bf16x8 hv, lv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { hv[j] = (__bf16)ov[j]; lv[j] = (__bf16)(ov[j] - (float)hv[j]); }
+                    *reinterpret_cast<bf16x8*>(O_hi + off) = hv;
+                    *reinterpret_cast<bf16x8*>(O_lo + off) = lv;
+                }
             }
         }
     }
@@ -336,21 +358,21 @@ static int rows_grid_t(int64_t rows) {
 }
 
 template <int HD, int NKT>
-static void launch_attn_float(const float* qkv, int B, int T, int H, int D, void* O_hi, void* O_lo, hipStream_t st) {
+static void launch_attn_float(const float* qkv, int B, int T, int H, int D, void* O_hi, void* O_lo, hipStream_t st, int f16) {
     const size_t lds = (size_t)4 * NKT * 16 * HD * 2 + (size_t)kTW * 8 * (HD + 4) * sizeof(float);
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd_float<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     k_attn_fwd_float<HD, NKT><<<B * H, kTW * 64, lds, st>>>(qkv, B, T, H, D, 1.0f / sqrtf((float)HD), reinterpret_cast<__bf16*>(O_hi),
-                                                            reinterpret_cast<__bf16*>(O_lo));
+                                                            reinterpret_cast<__bf16*>(O_lo), f16);
 }
 
-int launch_attn_fwd_float(const float* qkv, int B, int T, int H, int D, void* O_hi, void* O_lo, hipStream_t st) {
+int launch_attn_fwd_float(const float* qkv, int B, int T, int H, int D, void* O_hi, void* O_lo, hipStream_t st, int f16 = 0) {
     const int hd = D / H;
     if (D % H != 0 || (hd != 64 && hd != 32) || T > 224) { set_error("teacher attention: head_dim %d / T %d unsupported", hd, T); return 1; }
-    if (hd == 64 && T > 32) launch_attn_float<64, 14>(qkv, B, T, H, D, O_hi, O_lo, st);
-    else if (hd == 64) launch_attn_float<64, 2>(qkv, B, T, H, D, O_hi, O_lo, st);
-    else if (T > 32) launch_attn_float<32, 14>(qkv, B, T, H, D, O_hi, O_lo, st);
-    else launch_attn_float<32, 2>(qkv, B, T, H, D, O_hi, O_lo, st);
+    if (hd == 64 && T > 32) launch_attn_float<64, 14>(qkv, B, T, H, D, O_hi, O_lo, st, f16);
+    else if (hd == 64) launch_attn_float<64, 2>(qkv, B, T, H, D, O_hi, O_lo, st, f16);
+    else if (T > 32) launch_attn_float<32, 14>(qkv, B, T, H, D, O_hi, O_lo, st, f16);
+    else launch_attn_float<32, 2>(qkv, B, T, H, D, O_hi, O_lo, st, f16);
     return 0;
 }
 
@@ -396,11 +418,15 @@ int64_t qatvit_teacher_workspace_bytes(const qatvit_cfg* cfg) {
     return tplan(*cfg).total;
 }
 
-// params: fp32 tensors in the student's order (include/qatvit.h); w_hi / w_lo: the bf16 (hi, lo) pairs of the 2-D weights in the
-// weight_fq order (patch_embed.proj, per block qkv, proj, fc1, fc2; the head stays fp32).
-int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* const* w_hi, void* const* w_lo, const float* images, float* logits,
-                           void* workspace, void* stream) {
-    QV_CHECK_ARG(cfg && params && w_hi && w_lo && images && logits && workspace, "qatvit_teacher_forward: null argument");
+// params: fp32 tensors in the student's order (include/qatvit.h).
+// passes == 3: w_hi / w_lo = the bf16 (hi, lo) pairs of the 2-D weights in the weight_fq order (patch_embed.proj, per block qkv, proj, fc1, fc2; the head
+//   stays fp32); activations as bf16 pairs; three MFMA passes per GEMM (a_hi w_hi + a_lo w_hi + a_hi w_lo): logits within 1e-5 of fp64.
+// passes == 2 / 1: w_hi = the weights as fp16 (11 significant bits), w_lo unused; activations as an fp16 (hi, lo) pair (two passes, v_mfma_f32_16x16x32_f16)
+//   or as fp16 alone (one pass).  Measured against fp64 (tools/teacher_precision.py): profiles/round3_teacher_precision.txt.
+static int teacher_forward_impl(const qatvit_cfg* cfg, void* const* params, void* const* w_hi, void* const* w_lo, int passes, const float* images,
+                                float* logits, void* workspace, void* stream, const char* who) {
+    QV_CHECK_ARG(cfg && params && w_hi && images && logits && workspace && (passes != 3 || w_lo), "%s: null argument", who);
+    QV_CHECK_ARG(passes >= 1 && passes <= 3, "%s: passes %d (1, 2 or 3)", who, passes);
     if (tcheck(*cfg)) return 1;
     const qatvit_cfg& c = *cfg;
     const TPlan p = tplan(c);
@@ -409,50 +435,60 @@ int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* con
     const int np = (c.img_size / c.patch_size) * (c.img_size / c.patch_size), T = np + 1, D = c.embed_dim, Hd = c.mlp_hidden;
     const int Kpe = c.in_chans * c.patch_size * c.patch_size;
     const int64_t M = (int64_t)c.batch * T;
+    const int f16 = passes < 3;
+    QV_CHECK_ARG(!f16 || (D % 384 == 0 && Hd % 384 == 0 && Kpe % 32 == 0), "%s: the fp16 forms need embed_dim and mlp_hidden multiples of 384", who);
     auto F = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
     auto V = [&](int64_t off) { return reinterpret_cast<void*>(ws + off); };
     auto H16 = [&](int64_t off) { return reinterpret_cast<__bf16*>(ws + off); };
+    auto LO = [&](int64_t off) { return passes == 1 ? (__bf16*)nullptr : H16(off); };   // the one-pass form has no lo planes
     auto prm = [&](int i) { return reinterpret_cast<const float*>(params[i]); };
     auto bprm = [&](int blk, int k) { return prm(4 + 12 * blk + k); };
-    // QATVIT_TEACHER_PASSES=2 drops the activation_hi x weight_lo pass (weights as single bf16: ~1e-3 relative on the logits instead of
-    // 2e-5; a third less GEMM time).  Default 3: the teacher matches an fp64 evaluation to 2e-5.
-    static const int passes = getenv("QATVIT_TEACHER_PASSES") ? atoi(getenv("QATVIT_TEACHER_PASSES")) : 3;
-    auto wlo = [&](int wi) -> const void* { return passes == 2 ? nullptr : w_lo[wi]; };
-    auto gemm = [&](const void* Ah, const void* Al, int wi, const float* bias, float* C, int Mrows, int N, int K) {
-        return launch_gemm_nt(Ah, Al, w_hi[wi], C, Mrows, N, K, K, K, N, nullptr, nullptr, nullptr, bias, nullptr, 1, st, wlo(wi));
+    auto gemm = [&](const void* Ah, const void* Al, int wi, const float* bias, float* C, int Mrows, int N, int K, const NTPost* post = nullptr) {
+        if (f16) return launch_gemm_nt(Ah, passes == 1 ? nullptr : Al, w_hi[wi], C, Mrows, N, K, K, K, N, nullptr, nullptr, nullptr, bias, nullptr, 1, st, nullptr, post, true);
+        return launch_gemm_nt(Ah, Al, w_hi[wi], C, Mrows, N, K, K, K, N, nullptr, nullptr, nullptr, bias, nullptr, 1, st, w_lo[wi], post);
     };
-    k_patches_split<<<flat_grid_t((int64_t)c.batch * np * Kpe / 4), 256, 0, st>>>(images, H16(p.p_hi), H16(p.p_lo), c.batch, c.in_chans, c.img_size,
-                                                                               c.img_size, c.patch_size);
+    k_patches_split<<<flat_grid_t((int64_t)c.batch * np * Kpe / 4), 256, 0, st>>>(images, H16(p.p_hi), LO(p.p_lo), c.batch, c.in_chans, c.img_size,
+                                                                               c.img_size, c.patch_size, f16);
     if (gemm(V(p.p_hi), V(p.p_lo), 0, prm(1), F(p.Y0), c.batch * np, D, Kpe)) return 1;
     float* x = F(p.xA);
     float* x2 = F(p.xB);
     launch_resid_ln_split<0>(rows_grid_t(M), st, D, (const float*)nullptr, F(p.Y0), prm(2), prm(3), x, bprm(0, 0), bprm(0, 1), c.ln_eps, H16(p.h_hi),
-                                                        H16(p.h_lo), M, D, T);
+                                                        LO(p.h_lo), M, D, T, f16);
     for (int i = 0; i < c.depth; ++i) {
         const int w0 = 1 + 4 * i;
         if (gemm(V(p.h_hi), V(p.h_lo), w0 + 0, bprm(i, 3), F(p.qkv), (int)M, 3 * D, D)) return 1;
-        if (launch_attn_fwd_float(F(p.qkv), c.batch, T, c.num_heads, D, V(p.O_hi), V(p.O_lo), st)) return 1;
+        if (launch_attn_fwd_float(F(p.qkv), c.batch, T, c.num_heads, D, V(p.O_hi), passes == 1 ? nullptr : V(p.O_lo), st, f16)) return 1;
         if (gemm(V(p.O_hi), V(p.O_lo), w0 + 1, bprm(i, 5), F(p.Y), (int)M, D, D)) return 1;
         launch_resid_ln_split<1>(rows_grid_t(M), st, D, (const float*)x, (const float*)F(p.Y), (const float*)nullptr, (const float*)nullptr, x2, bprm(i, 6), bprm(i, 7), c.ln_eps, H16(p.h_hi),
-                                                            H16(p.h_lo), M, D, T);
+                                                            LO(p.h_lo), M, D, T, f16);
         {   // fc1 with GELU + hi/lo split in the GEMM epilogue (the fp32 [M, Hd] tensor never exists)
-            NTPost post{nullptr, nullptr, 0, 0, nullptr, V(p.G_hi), V(p.G_lo)};
-            if (launch_gemm_nt(V(p.h_hi), V(p.h_lo), w_hi[w0 + 2], nullptr, (int)M, Hd, D, D, D, Hd, nullptr, nullptr, nullptr, bprm(i, 9), nullptr, 1, st,
-                               wlo(w0 + 2), &post))
-                return 1;
+            NTPost post{nullptr, nullptr, 0, 0, nullptr, V(p.G_hi), passes == 1 ? nullptr : V(p.G_lo)};
+            post.out_f16 = f16;
+            if (gemm(V(p.h_hi), V(p.h_lo), w0 + 2, bprm(i, 9), nullptr, (int)M, Hd, D, &post)) return 1;
         }
         if (gemm(V(p.G_hi), V(p.G_lo), w0 + 3, bprm(i, 11), F(p.Y), (int)M, D, Hd)) return 1;
         const bool last = (i + 1 == c.depth);
         // the next block's norm1 (for the last block the pair is unused: the head normalises the cls rows itself)
         const float* g = last ? prm(4 + 12 * c.depth) : bprm(i + 1, 0);
         const float* bt = last ? prm(4 + 12 * c.depth + 1) : bprm(i + 1, 1);
-        launch_resid_ln_split<1>(rows_grid_t(M), st, D, (const float*)x2, (const float*)F(p.Y), (const float*)nullptr, (const float*)nullptr, x, g, bt, c.ln_eps, H16(p.h_hi), H16(p.h_lo), M, D, T);
+        launch_resid_ln_split<1>(rows_grid_t(M), st, D, (const float*)x2, (const float*)F(p.Y), (const float*)nullptr, (const float*)nullptr, x, g, bt, c.ln_eps, H16(p.h_hi), LO(p.h_lo), M, D, T, f16);
     }
     const int base = 4 + 12 * c.depth;
     k_teacher_head<<<c.batch, 256, (D + 8) * sizeof(float), st>>>(x, prm(base), prm(base + 1), c.ln_eps, prm(base + 2), prm(base + 3), logits, D, T,
                                                                   c.num_classes);
-    QV_CHECK_LAUNCH("qatvit_teacher_forward");
+    QV_CHECK_LAUNCH(who);
     return 0;
+}
+
+int qatvit_teacher_forward(const qatvit_cfg* cfg, void* const* params, void* const* w_hi, void* const* w_lo, const float* images, float* logits,
+                           void* workspace, void* stream) {
+    return teacher_forward_impl(cfg, params, w_hi, w_lo, 3, images, logits, workspace, stream, "qatvit_teacher_forward");
+}
+
+int qatvit_teacher_forward_f16(const qatvit_cfg* cfg, void* const* params, void* const* w16, int32_t passes, const float* images, float* logits,
+                               void* workspace, void* stream) {
+    QV_CHECK_ARG(passes == 1 || passes == 2, "qatvit_teacher_forward_f16: passes %d (1 or 2)", passes);
+    return teacher_forward_impl(cfg, params, w16, nullptr, passes, images, logits, workspace, stream, "qatvit_teacher_forward_f16");
 }
 
 }  // extern "C"

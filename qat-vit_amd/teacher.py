@@ -2,17 +2,28 @@
 
 The reference calls ``teacher(images)`` under ``torch.no_grad()`` with every parameter frozen
 (/root/reference/src/training/qat_trainer.py:257-260,337-338).  ``VisionTransformer.forward`` routes exactly that
-situation (CUDA input, grad mode off, eval) here; the weights' (hi, lo) bf16 pairs are built once and rebuilt only
+situation (CUDA input, grad mode off, eval) here; the weights' MFMA operands are built once and rebuilt only
 if a weight tensor is replaced or modified in place.
+
+Three arithmetic forms of the same forward (``QATVIT_TEACHER_PASSES``, read when an engine is built; measured against the
+fp64 tree by tools/teacher_precision.py -> profiles/round3_teacher_precision.txt):
+  3  bf16 (hi, lo) pairs of activations AND weights, three MFMA passes per GEMM (``qatvit_teacher_forward``);
+  2  fp16 (hi, lo) pair of the activations x the weights rounded to fp16 (11 significant bits), two passes
+     (``qatvit_teacher_forward_f16``) - the default: the cheapest form inside the 1e-3 bar on logits and on the KD gradient;
+  1  fp16 activations x fp16 weights, one pass (``qatvit_teacher_forward_f16``).
 """
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 
 import torch
 
 from . import native
+
+
+DEFAULT_PASSES = 2
 
 
 class TeacherEngine:
@@ -38,6 +49,11 @@ class TeacherEngine:
             averaging_const=0.01, ln_eps=float(blocks[0].norm1.eps),
         )
         self.weights = [pe.weight] + [w for b in blocks for w in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight)]
+        self.passes = int(os.environ.get("QATVIT_TEACHER_PASSES", str(DEFAULT_PASSES)))
+        if self.passes not in (1, 2, 3):
+            raise RuntimeError(f"QATVIT_TEACHER_PASSES={self.passes}: 1, 2 or 3")
+        if self.passes < 3 and (model.embed_dim % 384 or blocks[0].mlp.fc1.weight.shape[0] % 384):
+            self.passes = 3   # the fp16 forms run on the tall 208 x 384 tile only
         self._split_weights()
         nbytes = self.lib.qatvit_teacher_workspace_bytes(ctypes.byref(self.cfg))
         if nbytes <= 0:
@@ -51,6 +67,11 @@ class TeacherEngine:
         self.w_hi, self.w_lo = [], []
         for w in self.weights:
             w2 = w.detach().reshape(w.shape[0], -1)
+            if self.passes < 3:
+                if float(w2.abs().max()) >= 65504.0:
+                    raise RuntimeError("teacher weight outside fp16's range: run with QATVIT_TEACHER_PASSES=3")
+                self.w_hi.append(w2.to(torch.float16).contiguous())
+                continue
             hi = w2.to(torch.bfloat16)
             self.w_hi.append(hi.contiguous())
             self.w_lo.append((w2 - hi.float()).to(torch.bfloat16).contiguous())
@@ -66,8 +87,13 @@ class TeacherEngine:
             self._split_weights()  # a checkpoint was loaded into the teacher after the first call
         images = images.contiguous()
         logits = torch.empty(c.batch, c.num_classes, dtype=torch.float32, device=self.device)
-        native.check(self.lib.qatvit_teacher_forward(ctypes.byref(c), self._ptr_params, self._ptr_hi, self._ptr_lo, images.data_ptr(),
-                                                     logits.data_ptr(), self.workspace.data_ptr(), native.stream_ptr()), "qatvit_teacher_forward")
+        if self.passes == 3:
+            native.check(self.lib.qatvit_teacher_forward(ctypes.byref(c), self._ptr_params, self._ptr_hi, self._ptr_lo, images.data_ptr(),
+                                                         logits.data_ptr(), self.workspace.data_ptr(), native.stream_ptr()), "qatvit_teacher_forward")
+        else:
+            native.check(self.lib.qatvit_teacher_forward_f16(ctypes.byref(c), self._ptr_params, self._ptr_hi, self.passes, images.data_ptr(),
+                                                             logits.data_ptr(), self.workspace.data_ptr(), native.stream_ptr()),
+                         "qatvit_teacher_forward_f16")
         return logits
 
 

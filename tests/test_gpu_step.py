@@ -334,10 +334,21 @@ def test_engine_data_parallel_path_single_rank(native_lib):
         dist.destroy_process_group()
 
 
+# the three arithmetic forms of the teacher forward (qat_vit_amd/teacher.py) and the relative L2 asserted against the fp64 tree:
+#   3: bf16 pairs x bf16 pairs, 2^-16 per product, 12 blocks deep: observed ~1e-5
+#   2: fp16 pair x weights rounded to fp16 (the default): observed 4.2e-4 .. 6.3e-4 over six seeds, worst single image 8.2e-4
+#   1: fp16 x fp16: observed 6.1e-4 .. 8.4e-4 over six seeds - inside 1e-3 as a batch, single images up to 1.3e-3 (opt-in for that reason)
+# (profiles/round3_teacher_precision.txt)
+TEACHER_TOL = {3: (2e-4, 5e-4), 2: (1e-3, 1e-3), 1: (1e-3, 2e-3)}
+
+
+@pytest.mark.parametrize("passes", [3, 2, 1])
 @pytest.mark.parametrize("arch,B", [("vit_base_patch16_224_teacher", 4), ("vit_small_patch16_224_student", 3)])
-def test_native_teacher_forward_vs_fp64(native_lib, arch, B):
-    """Frozen-teacher forward (no fake-quant => no discontinuities): native 3-pass split-bf16 path vs the same tree in fp64
-    torch on the GPU.  2^-16 per product, fp32 accumulate, 12 blocks deep: 2e-4 relative L2 asserted (observed ~1e-5)."""
+def test_native_teacher_forward_vs_fp64(native_lib, monkeypatch, arch, B, passes):
+    """Frozen-teacher forward (no fake-quant => no discontinuities): each arithmetic form of the native path vs the same tree in fp64
+    torch on the GPU."""
+    monkeypatch.setenv("QATVIT_TEACHER_PASSES", str(passes))
+    tol = TEACHER_TOL[passes][0]
     torch.manual_seed(0)
     m = qat_vit_amd.create_model(arch, pretrained=False, num_classes=10).cuda().eval()
     with torch.no_grad():
@@ -350,24 +361,38 @@ def test_native_teacher_forward_vs_fp64(native_lib, arch, B):
         out = m(x)                                    # native (eval + no_grad + CUDA)
     from qat_vit_amd.teacher import _ENGINES as T_ENGINES
 
-    assert m in T_ENGINES
+    assert m in T_ENGINES and T_ENGINES[m].passes == passes
     m64 = copy.deepcopy(m).double()
     with torch.no_grad():
         ref = m64.head(m64.forward_features(x.double())[:, 0])
-    assert rel_l2(out.cpu(), ref.cpu()) < 2e-4
+    assert rel_l2(out.cpu(), ref.cpu()) < tol
     # a weight update invalidates the cached (hi, lo) pairs
     with torch.no_grad():
         m.blocks[0].mlp.fc1.weight.mul_(1.5)
         out2 = m(x)
         m64.blocks[0].mlp.fc1.weight.mul_(1.5)
         ref2 = m64.head(m64.forward_features(x.double())[:, 0])
-    assert rel_l2(out2.cpu(), ref2.cpu()) < 2e-4
+    assert rel_l2(out2.cpu(), ref2.cpu()) < tol
 
 
-def test_native_teacher_forward_at_b256_vs_fp64(native_lib):
+def test_teacher_default_form_is_the_two_pass_fp16_one(native_lib, monkeypatch):
+    monkeypatch.delenv("QATVIT_TEACHER_PASSES", raising=False)
+    from qat_vit_amd.teacher import DEFAULT_PASSES, TeacherEngine
+
+    m = qat_vit_amd.create_teacher("vit", num_classes=10).cuda().eval()
+    assert DEFAULT_PASSES == 2 and TeacherEngine(m, 2).passes == 2
+    monkeypatch.setenv("QATVIT_TEACHER_PASSES", "4")
+    with pytest.raises(RuntimeError, match="QATVIT_TEACHER_PASSES"):
+        TeacherEngine(m, 2)
+
+
+@pytest.mark.parametrize("passes", [3, 2, 1])
+def test_native_teacher_forward_at_b256_vs_fp64(native_lib, monkeypatch, passes):
     """The teacher at the batch it is benchmarked at (config C3: qat_trainer.py:337-338 runs it on the training batch, 256 per GPU): the native forward at
     B = 256 against the fp64 tree on sampled images (no batch statistics anywhere in a ViT, so image i's logits do not depend on the other images) -
     first / middle / last image and the row-tile boundaries of the 208-row GEMM tiles."""
+    monkeypatch.setenv("QATVIT_TEACHER_PASSES", str(passes))
+    tol, tol_img = TEACHER_TOL[passes]
     torch.manual_seed(1)
     m = qat_vit_amd.create_teacher("vit", num_classes=10).cuda().eval()
     with torch.no_grad():
@@ -386,6 +411,6 @@ def test_native_teacher_forward_at_b256_vs_fp64(native_lib):
     m64 = copy.deepcopy(m).double()
     with torch.no_grad():
         ref = m64.head(m64.forward_features(x[idx].double())[:, 0])
-    assert rel_l2(out[idx].cpu(), ref.cpu()) < 2e-4
+    assert rel_l2(out[idx].cpu(), ref.cpu()) < tol
     for k, i in enumerate(idx):   # per image too: one wrong row tile must not hide in the average
-        assert rel_l2(out[i].cpu(), ref[k].cpu()) < 5e-4, i
+        assert rel_l2(out[i].cpu(), ref[k].cpu()) < tol_img, i
