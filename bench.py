@@ -8,7 +8,7 @@ batch 256, qnnpack qconfig (per-tensor fake-quant), no teacher; synthetic 224x22
 A "step" = student forward + label-smoothed CE + backward (+ bucketed RCCL gradient all-reduce
 overlapped with backward and the rank-0 fake-quant-state broadcast when N>1); optimizer/clip are
 outside the metric.  `--backend x86 --teacher` gives config C3/C4
-(per-channel weights, [0,127] activations, KD against a frozen ViT-B teacher: native 3-pass split-bf16 forward).
+(per-channel weights, [0,127] activations, KD against a frozen ViT-B teacher: native forward, fp16 activation pair x fp16 weights on MFMA by default - qat-vit_amd/teacher.py).
 
 Started directly with ``--gpus N`` (N > 1, no WORLD_SIZE in the environment) it launches its own N workers - the reference starts
 its workers itself too (scripts/train_final.sh:13, torchrun --standalone) - BEFORE any GPU call; the parent never touches the GPU,
@@ -296,9 +296,9 @@ def main():
              4: "k_gemm_nt split-A dgrad + LayerNorm backward fused into the epilogue (fc1 / qkv dgrad, mode 8)",
              5: "k_gemm_nt split-A fc2 dgrad + GELU backward fused into the epilogue (mode 9: codes + mask bits; mode 5: uint16 codes)",
              2: "k_gemm_nt grid A on int8 MFMA, plain epilogue (patch embedding; qkv when it runs once)",
-             7: "k_gemm_nt grid A on int8 MFMA, statistics-only pass (mode 3: qkv and fc1 first passes)",
-             8: "k_gemm_nt grid A on int8 MFMA, fc1 storing pass (mode 4: gelu(fq(.)) as uint8 codes + STE mask bits + two 256-entry tables)",
-             9: "k_gemm_nt grid A on int8 MFMA, qkv code pass (mode 7: uint8 codes + STE mask bits in the attention layout)",
+             7: "k_i8_strip<3> A-stationary int8 strip kernel, statistics-only pass (qkv and fc1 first passes; csrc/i8strip.hip)",
+             8: "k_i8_strip<4> A-stationary int8 strip kernel, fc1 code pass (gelu(fq(.)) as uint8 codes + STE mask bits + two 256-entry tables)",
+             9: "k_i8_strip<7> A-stationary int8 strip kernel, qkv code pass (uint8 codes + STE mask bits in the attention layout)",
              3: "k_gemm_tn<1,..> + k_tn_reduce: weight gradients with grid X (qkv / fc1 / patch-embed; split dY: 2 bf16 passes issued)",
              6: "k_gemm_tn<2,..> + k_tn_reduce: weight gradients with split X (proj; fc2 with X as codes expanded in the kernel; 3 bf16 passes issued)"}
     SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_plain", 7: "nt_int8_stats_pass",
@@ -409,6 +409,9 @@ def main():
                 d3 = timed_steps(t_only, k, 2, 1, dev)
                 e["teacher_forward_ms"] = round(1e3 * d3 / k, 3)
                 e["student_step_ms"] = round(1e3 * (d2 - d3) / k, 3)
+                from qat_vit_amd.teacher import DEFAULT_PASSES
+                e["teacher_form"] = {3: "bf16 pairs x bf16 pairs, 3 MFMA passes", 2: "fp16 activation pair x fp16 weights, 2 MFMA passes",
+                                     1: "fp16 x fp16, 1 MFMA pass"}[int(os.environ.get("QATVIT_TEACHER_PASSES", DEFAULT_PASSES))]
             extras[tag] = e
             del st2, _m, _x, _y, t_only
             eng2.workspace = None

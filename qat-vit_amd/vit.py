@@ -7,7 +7,8 @@ The reference obtains this tree from ``timm.create_model("vit_small_patch16_224"
 type (torch/ao/quantization/quantize.py:765), timm's parameter names (so ``model.``-prefixed
 checkpoints load, model_registry.py:247-260), deep-copy-ability, and ``.parameters()``.
 This file provides exactly that tree; on an MI355X the arithmetic of a QAT-prepared tree
-is executed by libqatvit.so (see qat_forward.py), not by these modules' ``forward``.
+is executed by libqatvit.so (engine.py: ``student_forward``; the frozen teacher: teacher.py), not by
+these modules' ``forward``.
 """
 from __future__ import annotations
 
