@@ -24,7 +24,27 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int kAW = 8;  // waves per attention workgroup (two per SIMD)
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+// The attention kernels are VALU-bound (ISA count per 16 x 32 tile pair of the backward sweep: 290 VALU instructions against 64 MFMAs), so
+// the float -> bf16 (hi, lo) splits go two elements per instruction: v_cvt_pk_bf16_f32 on a PAIR (a per-element cast costs one v_cvt_pk
+// plus a shift to pack), the hi parts back to fp32 by shift / mask, the residuals by one v_pk_add_f32.  Same roundings, same bits.
+__device__ inline uint32_t pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ inline void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 h = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    const f32x2 r = v - h;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+}
 
 struct AQP { float s, inv, zp; float fqmin, fqmax; };
 __device__ inline float qint(float x, const AQP& q) { return fminf(fmaxf(rintf(x * q.inv) + q.zp, q.fqmin), q.fqmax) - q.zp; }
@@ -105,13 +125,13 @@ __device__ inline void store_mask_row(uint8_t* dst_row, uint32_t mk, int ch, boo
 }
 // 8 codes -> the bf16 fragment of integers q - zp (what quant8 produces from the pre-FQ values)
 __device__ inline bf16x8 decode8(const uint2& codes, float off /* qmin - zp */) {
-    bf16x8 f;
+    uint32_t w[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f[j] = (__bf16)((float)((codes.x >> (8 * j)) & 0xffu) + off);
-        f[4 + j] = (__bf16)((float)((codes.y >> (8 * j)) & 0xffu) + off);
+    for (int j = 0; j < 2; ++j) {
+        w[j] = pk_bf16((float)((codes.x >> (16 * j)) & 0xffu) + off, (float)((codes.x >> (16 * j + 8)) & 0xffu) + off);
+        w[2 + j] = pk_bf16((float)((codes.y >> (16 * j)) & 0xffu) + off, (float)((codes.y >> (16 * j + 8)) & 0xffu) + off);
     }
-    return f;
+    return __builtin_bit_cast(bf16x8, (u32x4){w[0], w[1], w[2], w[3]});
 }
 
 // ---- LDS images of a [tokens][HD] bf16 tile
@@ -148,19 +168,18 @@ __device__ inline bf16x8 load_q8(const float* p, const AQP& q) {
 }
 __device__ inline void load_split8(const float* p, bf16x8& hi, bf16x8& lo) {
     const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        hi[j] = (__bf16)v[j];
-        lo[j] = (__bf16)(v[j] - (float)hi[j]);
-    }
+    uint32_t H[4], L[4];
+    split_pair(a.x, a.y, H[0], L[0]); split_pair(a.z, a.w, H[1], L[1]);
+    split_pair(b.x, b.y, H[2], L[2]); split_pair(b.z, b.w, H[3], L[3]);
+    hi = __builtin_bit_cast(bf16x8, (u32x4){H[0], H[1], H[2], H[3]});
+    lo = __builtin_bit_cast(bf16x8, (u32x4){L[0], L[1], L[2], L[3]});
 }
 __device__ inline void split_acc2(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        hi[j] = (__bf16)a[j]; lo[j] = (__bf16)(a[j] - (float)hi[j]);
-        hi[j + 4] = (__bf16)b[j]; lo[j + 4] = (__bf16)(b[j] - (float)hi[j + 4]);
-    }
+    uint32_t H[4], L[4];
+    split_pair(a[0], a[1], H[0], L[0]); split_pair(a[2], a[3], H[1], L[1]);
+    split_pair(b[0], b[1], H[2], L[2]); split_pair(b[2], b[3], H[3], L[3]);
+    hi = __builtin_bit_cast(bf16x8, (u32x4){H[0], H[1], H[2], H[3]});
+    lo = __builtin_bit_cast(bf16x8, (u32x4){L[0], L[1], L[2], L[3]});
 }
 
 // The forward keeps its float MFMA operands (softmax probabilities, and the output handed to attn.proj) as fp16 (hi, lo) pairs:
@@ -248,11 +267,11 @@ __device__ inline bool wave_retile8(float* sO, const f32x4 (&acc)[HD / 16], floa
     return active;
 }
 __device__ inline void store_split8(__bf16* hi, __bf16* lo, int64_t off, const float (&v)[8]) {
-    bf16x8 h, l;
+    uint32_t H[4], L[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
-    *reinterpret_cast<bf16x8*>(hi + off) = h;
-    *reinterpret_cast<bf16x8*>(lo + off) = l;
+    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], H[j], L[j]);
+    *reinterpret_cast<uint4*>(hi + off) = make_uint4(H[0], H[1], H[2], H[3]);
+    *reinterpret_cast<uint4*>(lo + off) = make_uint4(L[0], L[1], L[2], L[3]);
 }
 
 struct AttnArgs {
@@ -378,15 +397,12 @@ __device__ inline void stage_split_tr(char* img_hi, char* img_lo, const float* b
     for (int it = 0; it < ITERS; ++it) {
         const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
         if (i < TOTAL) {
-            const float v[8] = {a[it].x, a[it].y, a[it].z, a[it].w, b[it].x, b[it].y, b[it].z, b[it].w};
-            bf16x8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                hi[j] = (__bf16)(tok < T ? v[j] : 0.f);
-                lo[j] = (__bf16)(tok < T ? v[j] - (float)hi[j] : 0.f);
-            }
-            *reinterpret_cast<bf16x8*>(img_hi + tr_off<HD>(tok, ch)) = hi;
-            *reinterpret_cast<bf16x8*>(img_lo + tr_off<HD>(tok, ch)) = lo;
+            uint32_t H[4], L[4];
+            split_pair(a[it].x, a[it].y, H[0], L[0]); split_pair(a[it].z, a[it].w, H[1], L[1]);
+            split_pair(b[it].x, b[it].y, H[2], L[2]); split_pair(b[it].z, b[it].w, H[3], L[3]);
+            const bool real = tok < T;   // padded token rows are zero in both images
+            *reinterpret_cast<uint4*>(img_hi + tr_off<HD>(tok, ch)) = real ? make_uint4(H[0], H[1], H[2], H[3]) : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(img_lo + tr_off<HD>(tok, ch)) = real ? make_uint4(L[0], L[1], L[2], L[3]) : make_uint4(0u, 0u, 0u, 0u);
         }
     }
 }
@@ -421,7 +437,8 @@ __global__ __launch_bounds__(kAW * 64, 4) void k_attn_fwd(const AttnArgs p) {   
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.o16_scale) *p.o16_scale = q.s * (1.0f / kOScale);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    const float c = q.s * q.s * p.softmax_scale;
+    const float c2 = q.s * q.s * p.softmax_scale * kLog2e;
+    const int jfull = T >> 4;   // key tiles below this one hold real keys only
     const int nqt = (T + 15) / 16;
     for (int qt = wave; qt < nqt; qt += kAW) {
         const int qrow = min(qt * 16 + r, T - 1);
@@ -456,16 +473,19 @@ __global__ __launch_bounds__(kAW * 64, 4) void k_attn_fwd(const AttnArgs p) {   
                 s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[j], 0, 0, 0);
             }
         }
-        // softmax over keys: key = 16j + 4g + e, this lane's query = r
+        // softmax over keys: key = 16j + 4g + e, this lane's query = r.  In the log2 domain (t = s c log2 e, one multiply per element and a bare
+        // v_exp_f32); only the key tiles that hold padded keys (j >= T / 16, wave-uniform) pay for a mask.
         float m = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < NKT; ++j)
+        for (int j = 0; j < NKT; ++j) {
+            s[j] = s[j] * c2;
+            if (j >= jfull) {
+                asm volatile("");   // (keeps the branch: if-converted, every tile would pay the compares and selects again)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool valid = 16 * j + 4 * g + e < T;
-                s[j][e] = valid ? s[j][e] * c : -INFINITY;
-                m = fmaxf(m, s[j][e]);
+                for (int e = 0; e < 4; ++e) s[j][e] = 16 * j + 4 * g + e < T ? s[j][e] : -INFINITY;
             }
+            m = fmaxf(fmaxf(m, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));
+        }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float l = 0.f;
@@ -473,13 +493,13 @@ __global__ __launch_bounds__(kAW * 64, 4) void k_attn_fwd(const AttnArgs p) {   
         for (int j = 0; j < NKT; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s[j][e] = fast_exp(s[j][e] - m);
+                s[j][e] = __builtin_amdgcn_exp2f(s[j][e] - m);
                 l += s[j][e];
             }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float invl = kPScale / l;      // probabilities enter the MFMA scaled by 2^14 (fp16 range); taken out again below
-        if (p.lse && g == 0 && qt * 16 + r < T) p.lse[(int64_t)blockIdx.x * TP + qt * 16 + r] = m + logf(l);
+        if (p.lse && g == 0 && qt * 16 + r < T) p.lse[(int64_t)blockIdx.x * TP + qt * 16 + r] = m * kLn2 + logf(l);
         f32x4 o[HD / 16];
 #pragma unroll
         for (int jd = 0; jd < HD / 16; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -539,7 +559,8 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    const float c = q.s * q.s * p.softmax_scale;
+    const float c = q.s * q.s * p.softmax_scale, c2 = c * kLog2e;
+    const int jfull = T >> 4;   // key tiles below this one hold real keys only
     const int nqt = (T + 15) / 16;
     for (int qt = wave; qt < nqt; qt += kAW) {
         const int qrow = min(qt * 16 + r, T - 1);
@@ -562,7 +583,9 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
         dpart += __shfl_xor(dpart, 16, 64);
         dpart += __shfl_xor(dpart, 32, 64);
         const float delta = dpart;
-        const float lse = p.lse[(int64_t)blockIdx.x * TP + qrow];
+        // P = exp2(s c log2e - lse log2e) as one fma + v_exp_f32; dS = P (dP s - delta) = s P (dP - delta / s), the factor s goes into the
+        // scale of the finished dQ tile
+        const float nlse = -p.lse[(int64_t)blockIdx.x * TP + qrow] * kLog2e, dlt = delta * q.inv;
         if (g == 0 && qvalid) p.delta[(int64_t)blockIdx.x * TP + qt * 16 + r] = delta;
         f32x4 dq[HD / 16];
 #pragma unroll
@@ -583,10 +606,11 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dl[kk], dp, 0, 0, 0);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool valid = 16 * j + 4 * g + e < T;
-                    const float pr = valid ? fast_exp(s[e] * c - lse) : 0.f;
-                    ds2[u][e] = pr * (dp[e] * q.s - delta);
+                for (int e = 0; e < 4; ++e) ds2[u][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c2, nlse)) * (dp[e] - dlt);
+                if (j >= jfull) {   // (wave-uniform) padded keys: their K rows are zero, but exp(0 - lse) may overflow, and inf * 0 = NaN
+                    asm volatile("");
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ds2[u][e] = 16 * j + 4 * g + e < T ? ds2[u][e] : 0.f;
                 }
             }
             bf16x8 sh, sl;
@@ -627,7 +651,7 @@ __global__ __launch_bounds__(kAW * 64) void k_attn_bwd_dq(const AttnArgs p) {
         for (int half = 0; half < 2; ++half) {
             float gv[8];
             int orow, oc;
-            const bool act = wave_retile8<HD>(sO, dq, q.s * p.softmax_scale, lane, half, gv, orow, oc);
+            const bool act = wave_retile8<HD>(sO, dq, c, lane, half, gv, orow, oc);
             const int qq = qt * 16 + 8 * half + orow;
             if (act && qq < T) {
                 const int64_t off = ((int64_t)b * T + qq) * ld + h * HD + 8 * oc;
@@ -672,8 +696,10 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     static_assert(NKT * 16 <= NWV * 64, "one softmax constant per thread");
     // (requested first, written to LDS after the first image: a load -> ds_write right here would be a round trip of its own)
     const int ci = min((int)threadIdx.x, NKT * 16 - 1);
-    const float lse_i = p.lse[(int64_t)blockIdx.x * (NKT * 16) + min(ci, p.T - 1)];
-    const float dlt_i = p.delta[(int64_t)blockIdx.x * (NKT * 16) + min(ci, p.T - 1)];
+    // kept as -lse log2e (P = exp2(fma(s, c log2e, .)): one fma + v_exp_f32) and delta / s (dS = s P (dP - delta / s): s goes into dK's final scale);
+    // padded query rows get -inf, i.e. P = 0 exactly: their Q / dO rows are zero, but exp(0 - lse) may overflow, and inf * 0 = NaN
+    const float lse_i = ci < p.T ? -p.lse[(int64_t)blockIdx.x * (NKT * 16) + ci] * kLog2e : -INFINITY;
+    const float dlt_i = p.delta[(int64_t)blockIdx.x * (NKT * 16) + min(ci, p.T - 1)] * p.qp[1];
     const int64_t sl = (int64_t)T * HD;
     const uint8_t* const cbase = p.codes ? p.codes + (int64_t)blockIdx.x * 3 * sl : nullptr;
     const uint8_t* const mbase = p.codes ? p.cmask + (int64_t)blockIdx.x * 3 * (sl / 8) : nullptr;
@@ -685,7 +711,7 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float c = q.s * q.s * p.softmax_scale;
+    const float c = q.s * q.s * p.softmax_scale, c2 = c * kLog2e;
     const int nkt = (T + 15) / 16;
     int jt[U];
     bool has[U];
@@ -754,7 +780,6 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
         // this pair's query-row fragments (A operands of S and dP), and per-row softmax constants
         bf16x8 qa[2][KK], da[2][KK], db[2][KK];
         float lse_r[2][4], dlt_r[2][4];
-        bool qval[2][4];
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int qt = 2 * qs + v;
@@ -769,7 +794,6 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int qq = 16 * qt + 4 * g + e;
-                qval[v][e] = qq < T;
                 lse_r[v][e] = sLse[qq];
                 dlt_r[v][e] = sDlt[qq];
             }
@@ -794,12 +818,13 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[v][kk], vf[u][kk], dp, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db[v][kk], vf[u][kk], dp, 0, 0, 0);
                 }
-                // S orientation: this lane's key = 16*jt[u] + r, query = 16*(2qs+v) + 4g + e
+                // S orientation: this lane's key = 16*jt[u] + r, query = 16*(2qs+v) + 4g + e.  No masks: a padded query has P = 0 (see sLse), a
+                // padded key is a column of its own (this lane's) that is never stored
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pr = (qval[v][e] && kvalid[u]) ? fast_exp(sacc[e] * c - lse_r[v][e]) : 0.f;
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[e], c2, lse_r[v][e]));
                     p2[v][e] = pr;
-                    ds2[v][e] = pr * (dp[e] * q.s - dlt_r[v][e]);
+                    ds2[v][e] = pr * (dp[e] - dlt_r[v][e]);
                 }
             }
             bf16x8 ph, pl, sh, sl;
@@ -816,7 +841,7 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
         }
     }
     // accumulators: row = feature 16id + 4g + e, col = key 16j + r  -> 8-B (4 x bf16) stores along d
-    const float a = q.s * p.softmax_scale;
+    const float a = c;   // s * softmax_scale, times the s factored out of dS
     // the STE mask needs the pre-FQ k / v values: all of them are requested before any is used (one memory round trip for the
     // epilogue instead of one per fragment; the sweep's operand registers are dead here)
     float4 xk[U][ND], xv[U][ND], ckc[ND], cvc[ND];
@@ -870,16 +895,13 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
                                  ik[2] ? dk[u][id][2] * a * ck.z : 0.f, ik[3] ? dk[u][id][3] * a * ck.w : 0.f};
             const float vv[4] = {iv[0] ? dv[u][id][0] * cv.x : 0.f, iv[1] ? dv[u][id][1] * cv.y : 0.f,
                                  iv[2] ? dv[u][id][2] * cv.z : 0.f, iv[3] ? dv[u][id][3] * cv.w : 0.f};
-            bf16x4 kh, kl, vh, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                kh[e] = (__bf16)vk[e]; kl[e] = (__bf16)(vk[e] - (float)kh[e]);
-                vh[e] = (__bf16)vv[e]; vl[e] = (__bf16)(vv[e] - (float)vh[e]);
-            }
-            *reinterpret_cast<bf16x4*>(p.dqkv_hi + offk) = kh;
-            *reinterpret_cast<bf16x4*>(p.dqkv_lo + offk) = kl;
-            *reinterpret_cast<bf16x4*>(p.dqkv_hi + offv) = vh;
-            *reinterpret_cast<bf16x4*>(p.dqkv_lo + offv) = vl;
+            uint2 kh, kl, vh, vl;
+            split_pair(vk[0], vk[1], kh.x, kl.x); split_pair(vk[2], vk[3], kh.y, kl.y);
+            split_pair(vv[0], vv[1], vh.x, vl.x); split_pair(vv[2], vv[3], vh.y, vl.y);
+            *reinterpret_cast<uint2*>(p.dqkv_hi + offk) = kh;
+            *reinterpret_cast<uint2*>(p.dqkv_lo + offk) = kl;
+            *reinterpret_cast<uint2*>(p.dqkv_hi + offv) = vh;
+            *reinterpret_cast<uint2*>(p.dqkv_lo + offv) = vl;
         }
     }
 }
