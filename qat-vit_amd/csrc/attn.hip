@@ -28,7 +28,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef QV_ABL
+#define QV_ABL 0   // timing-only ablations of k_attn_bwd_fused (development builds: -DQV_ABL=bits)
+#endif
 constexpr int kAW = 8;  // waves per attention workgroup (two per SIMD)
+// workgroup barrier that waits for this wave's LDS traffic only (__syncthreads also drains vmcnt: every global store's round trip)
+__device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
 // The attention kernels are VALU-bound (ISA count per 16 x 32 tile pair of the backward sweep: 290 VALU instructions against 64 MFMAs), so
@@ -906,6 +911,374 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
     }
 }
 
+// ============================================================================ backward, fused: dK, dV AND dQ in one sweep
+// The two-kernel backward computes S, dP, P and dS twice (once with the query on the lanes for dK / dV, once with the key on the lanes for dQ)
+// and stages every head twice.  Here the dK / dV sweep hands its dS tiles to dQ through LDS: each wave writes the (hi, lo) split of the dS
+// it holds - this lane's key, four consecutive queries per register group - as 8-byte runs into a [key][32 queries] bf16 image, and after a
+// barrier the eight waves each own one 16 (features) x 16 (queries) tile of dQ^T = K^T . dS^T for that query pair (transposed reads of the K
+// image and of the dS image: ds_read_b64_tr_b16, the same k-slot map on both sides), finish it over all keys and store it at once.  delta
+// (row sums of dO . O) is formed while dO is staged.  head_dim 64, eight waves, saved codes; everything else takes the two-kernel path.
+// LDS: images of Q, K (integers), dO hi / lo (4 x 28 KiB) + dS hi / lo (2 x 17.5 KiB) + the per-row softmax constants = 149 KiB, one workgroup per CU.
+// transposed fragment of the dS image ([key][32 queries] bf16, rows kSRow bytes apart: 80, not 64 - sixteen 64-byte rows would put rows r and
+// r + 4 in the same banks, a 4-way conflict on every read and write; at 80 the sixteen 32-byte pieces of one access cover every bank twice)
+constexpr int kSRow = 80;
+__device__ inline bf16x8 tr_frag_ds(const char* img, int tokA, int tokB, int col0, int lane) {
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (tokA + 4 * g + q) * kSRow + col0 * 2 + pp * 8));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (tokB + 4 * g + q) * kSRow + col0 * 2 + pp * 8));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <int NKT>
+__global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
+    constexpr int HD = 64, NWV = 8;
+    constexpr int U = (NKT + NWV - 1) / NWV;   // key tiles per wave
+    constexpr int IMG = NKT * 16 * HD * 2, SIMG = NKT * 16 * kSRow;
+    constexpr int KK = HD / 32, ND = HD / 16;
+    static_assert(2 * ND == NWV, "one dQ^T tile (16 features x 16 queries of a query pair) per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQt = smem;               // [token][d] images for transposed reads: Q and K integers, dO hi / lo
+    char* sDh = smem + IMG;
+    char* sDl = smem + 2 * IMG;
+    char* sKt = smem + 3 * IMG;
+    char* sSh = smem + 4 * IMG;     // [key][32 queries] image of the current query pair's dS, hi / lo
+    char* sSl = sSh + SIMG;
+    float* sLse = reinterpret_cast<float*>(sSl + SIMG);
+    float* sDlt = sLse + NKT * 16;
+    uint2* sM = reinterpret_cast<uint2*>(sDlt + NKT * 16);   // STE mask bits of this head's q | k | v slices: [3][T] rows of HD / 8 = 8 bytes
+#if (QV_ABL & 16)
+    if ((blockIdx.x & 1) && blockIdx.x < 256) { for (int i = 0; i < (QV_ABL >> 8); ++i) __builtin_amdgcn_s_sleep(127); }
+#endif
+    const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int T = p.T, D = p.D, ld = 3 * D;
+    static_assert(NKT * 16 <= NWV * 64, "one softmax constant per thread");
+    const int ci = min((int)threadIdx.x, NKT * 16 - 1);
+    const float lse_i = ci < T ? -p.lse[(int64_t)blockIdx.x * (NKT * 16) + ci] * kLog2e : -INFINITY;   // (see k_attn_bwd_dkv)
+    const int64_t sl = (int64_t)T * HD;
+    const uint8_t* const cbase = p.codes + (int64_t)blockIdx.x * 3 * sl;
+    const uint8_t* const mbase = p.cmask + (int64_t)blockIdx.x * 3 * (sl / 8);
+    const float coff = q.fqmin - q.zp;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nkt = (T + 15) / 16;
+#if (QV_ABL & 32)
+    const unsigned long long t00 = __builtin_amdgcn_s_memtime();
+    int nst = 0;
+    auto stamp = [&]() {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if ((blockIdx.x == 5 || blockIdx.x == 700) && lane == 0 && (wave == 0 || wave == 5) && nst < 13)
+            p.delta[(int64_t)blockIdx.x * (NKT * 16) + 198 + (wave ? 13 : 0) + nst] = (float)(unsigned)(t - t00);
+        ++nst;
+    };
+#define QV_STAMP() stamp()
+#else
+#define QV_STAMP()
+#endif
+    int jt[U];
+    bool has[U], kvalid[U];
+    // the owned V row fragments from the saved codes, requested first (the K fragments are re-read from the K image every sweep step: 16 registers)
+    uint2 vc[U][KK];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        jt[u] = wave + u * NWV;
+        has[u] = jt[u] < nkt;
+        const int krow = min(16 * jt[u] + r, T - 1);
+        kvalid[u] = has[u] && 16 * jt[u] + r < T;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            vc[u][kk] = *reinterpret_cast<const uint2*>(cbase + 2 * sl + krow * HD + 32 * kk + 8 * g);
+        }
+    }
+    // Staging: EVERY global load of the workgroup is requested before anything is converted (Q and K codes, dO, O hi / lo: 20 registers per
+    // 16-byte chunk, four chunks per thread) - with one workgroup per CU each dependent round trip is exposed in full.
+    constexpr int CH = HD / 8, TOTAL = NKT * 16 * CH, ITERS = (TOTAL + NWV * 64 - 1) / (NWV * 64);
+    uint2 cq[ITERS], ck[ITERS];
+    float4 da4[ITERS], db4[ITERS];
+    uint4 oh[ITERS], ol[ITERS];
+    {
+        const float* const dOb = p.dO + (int64_t)b * T * D + h * HD;
+        const __bf16* const Ohb = p.O_hi + (int64_t)b * T * D + h * HD;
+        const __bf16* const Olb = p.O_lo + (int64_t)b * T * D + h * HD;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = threadIdx.x + it * NWV * 64, tok = min(i / CH, T - 1), ch = i % CH;   // (branch-free: a padded token reads the last real one)
+            cq[it] = *reinterpret_cast<const uint2*>(cbase + tok * HD + ch * 8);
+            ck[it] = *reinterpret_cast<const uint2*>(cbase + sl + tok * HD + ch * 8);
+            const int64_t off = (int64_t)tok * D + ch * 8;
+            da4[it] = reinterpret_cast<const float4*>(dOb + off)[0];
+            db4[it] = reinterpret_cast<const float4*>(dOb + off)[1];
+            oh[it] = *reinterpret_cast<const uint4*>(Ohb + off);
+            ol[it] = *reinterpret_cast<const uint4*>(Olb + off);
+        }
+    }
+    QV_STAMP();   // 0: loads requested
+    // the head's three mask slices are one contiguous run of 3 T rows: two 8-byte loads per thread here instead of 23 single-byte loads per
+    // thread for the epilogues (each a full 64-lane address instruction)
+    uint2 mrow[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) mrow[k] = reinterpret_cast<const uint2*>(mbase)[min((int)threadIdx.x + k * NWV * 64, 3 * T - 1)];
+    if (threadIdx.x < NKT * 16) sLse[threadIdx.x] = lse_i;
+    for (int i = threadIdx.x; i < 2 * SIMG / 16; i += NWV * 64) reinterpret_cast<uint4*>(sSh)[i] = make_uint4(0u, 0u, 0u, 0u);   // key tiles nobody owns stay zero
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        pin4(da4[it]); pin4(db4[it]);
+        asm volatile("" ::"v"(oh[it].x), "v"(oh[it].y), "v"(oh[it].z), "v"(oh[it].w), "v"(ol[it].x), "v"(ol[it].y), "v"(ol[it].z), "v"(ol[it].w));
+        asm volatile("" ::"v"(cq[it].x), "v"(cq[it].y), "v"(ck[it].x), "v"(ck[it].y));
+    }
+    QV_STAMP();   // 1: loads arrived
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if ((int)threadIdx.x + k * NWV * 64 < 3 * T) sM[threadIdx.x + k * NWV * 64] = mrow[k];
+    float* const gdelta = p.delta ? p.delta + (int64_t)blockIdx.x * (NKT * 16) : nullptr;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = threadIdx.x + it * NWV * 64, tok = i / CH, ch = i % CH;
+        const bool real = tok < T;   // padded token rows are zero in every image
+        const float v[8] = {da4[it].x, da4[it].y, da4[it].z, da4[it].w, db4[it].x, db4[it].y, db4[it].z, db4[it].w};
+        const uint32_t wh[4] = {oh[it].x, oh[it].y, oh[it].z, oh[it].w}, wl[4] = {ol[it].x, ol[it].y, ol[it].z, ol[it].w};
+        float d = 0.f;   // delta = sum_d dO . O over the row: 8 features here, the row's 8 chunks on consecutive lanes
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d += v[2 * j] * (__builtin_bit_cast(float, wh[j] << 16) + __builtin_bit_cast(float, wl[j] << 16));
+            d += v[2 * j + 1] * (__builtin_bit_cast(float, wh[j] & 0xffff0000u) + __builtin_bit_cast(float, wl[j] & 0xffff0000u));
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (i < TOTAL) {
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(sQt + tr_off<HD>(tok, ch)) = real ? __builtin_bit_cast(uint4, decode8(cq[it], coff)) : z;
+            *reinterpret_cast<uint4*>(sKt + tr_off<HD>(tok, ch)) = real ? __builtin_bit_cast(uint4, decode8(ck[it], coff)) : z;
+            uint32_t H[4], L[4];
+            split_pair(v[0], v[1], H[0], L[0]); split_pair(v[2], v[3], H[1], L[1]);
+            split_pair(v[4], v[5], H[2], L[2]); split_pair(v[6], v[7], H[3], L[3]);
+            *reinterpret_cast<uint4*>(sDh + tr_off<HD>(tok, ch)) = real ? make_uint4(H[0], H[1], H[2], H[3]) : z;
+            *reinterpret_cast<uint4*>(sDl + tr_off<HD>(tok, ch)) = real ? make_uint4(L[0], L[1], L[2], L[3]) : z;
+            if (ch == 0) {
+                sDlt[tok] = d * q.inv;
+                if (real && gdelta) gdelta[tok] = d;
+            }
+        }
+    }
+    bf16x8 vf[U][KK];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) vf[u][kk] = decode8(vc[u][kk], coff);
+    // this wave's dQ^T tile of every query pair: features 16 jd .. + 15, queries 16 (2 qs + vq) .. + 15
+    const int jd = wave & (ND - 1), vq = wave / ND;
+    float4 ckq = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (p.col_scale) ckq = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 16 * jd + 4 * g);
+    QV_STAMP();   // 2: images written
+    __syncthreads();
+    QV_STAMP();   // 3: barrier
+    const float c = q.s * q.s * p.softmax_scale, c2 = c * kLog2e;
+    f32x4 dk[U][ND], dv[U][ND];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int id = 0; id < ND; ++id) dk[u][id] = dv[u][id] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int qs = 0; qs < ((QV_ABL & 8) ? (p.T < 0 ? 1 : 0) : NKT / 2); ++qs) {
+        const int qme = 16 * (2 * qs + vq) + r;
+        const uint32_t mqb = reinterpret_cast<const uint8_t*>(sM)[min(qme, T - 1) * 8 + 2 * jd + (g >> 1)];
+        // phase 1: S and dP of every owned key tile (the query-row fragments are dead afterwards: 48 registers)
+        f32x4 sacc[U][2], dpv[U][2];
+        {
+            bf16x8 qa[2][KK], da[2][KK], db[2][KK];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    qa[v][kk] = *reinterpret_cast<const bf16x8*>(sQt + tr_off<HD>(16 * (2 * qs + v) + r, 4 * kk + g));
+                    da[v][kk] = *reinterpret_cast<const bf16x8*>(sDh + tr_off<HD>(16 * (2 * qs + v) + r, 4 * kk + g));
+                    db[v][kk] = *reinterpret_cast<const bf16x8*>(sDl + tr_off<HD>(16 * (2 * qs + v) + r, 4 * kk + g));
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!has[u]) continue;   // wave-uniform
+                bf16x8 kf[KK];           // (rows >= T of the image are zero)
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(sKt + tr_off<HD>(16 * jt[u] + r, 4 * kk + g));
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    sacc[u][v] = dpv[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) {
+                        sacc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[v][kk], kf[kk], sacc[u][v], 0, 0, 0);
+                        dpv[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[v][kk], vf[u][kk], dpv[u][v], 0, 0, 0);
+                        dpv[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db[v][kk], vf[u][kk], dpv[u][v], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: the transposed fragments (their LDS latency runs under the exp / split arithmetic), P and dS, dV / dK
+        bf16x8 dth[ND], dtl[ND], qtf[ND];
+#pragma unroll
+        for (int id = 0; id < ND; ++id) {
+            dth[id] = tr_frag2<HD>(sDh, 32 * qs, 32 * qs + 16, 16 * id, lane);
+            dtl[id] = tr_frag2<HD>(sDl, 32 * qs, 32 * qs + 16, 16 * id, lane);
+            qtf[id] = tr_frag2<HD>(sQt, 32 * qs, 32 * qs + 16, 16 * id, lane);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bf16x8 ph, pl, sh, sl2;
+            if (has[u]) {
+                f32x4 p2[2], ds2[2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    // S orientation: this lane's key = 16 jt + r, query = 16 (2qs + v) + 4g + e: the four softmax constants are one 16-byte read
+                    const float4 nl = *reinterpret_cast<const float4*>(sLse + 16 * (2 * qs + v) + 4 * g);
+                    const float4 dl = *reinterpret_cast<const float4*>(sDlt + 16 * (2 * qs + v) + 4 * g);
+                    const float nlv[4] = {nl.x, nl.y, nl.z, nl.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][v][e], c2, nlv[e]));
+                        p2[v][e] = pr;
+                        ds2[v][e] = pr * (dpv[u][v][e] - dlv[e]);
+                    }
+                }
+                if (16 * jt[u] + 15 >= T) {   // (wave-uniform) the tile with padded keys: their dS goes into the image as zero - their P is e^-lse, which
+                    asm volatile("");         // may overflow, and dQ^T multiplies it with the zero rows of the K image (inf * 0 = NaN)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ds2[v][e] = kvalid[u] ? ds2[v][e] : 0.f;
+                }
+                split_acc2(p2[0], p2[1], ph, pl);
+                split_acc2(ds2[0], ds2[1], sh, sl2);
+            }
+            // the dS image is free again once every wave has finished the previous pair's dQ^T tile
+#if !(QV_ABL & 2)
+            if (u == 0) lds_only_barrier();
+#endif
+            if (has[u]) {
+                // this lane: key 16 jt + r, queries 4g .. 4g+3 of tile v in elements 4v .. 4v+3 -> 8-byte runs of the [key][32 queries] image
+                const uint4 wh = __builtin_bit_cast(uint4, sh), wl = __builtin_bit_cast(uint4, sl2);
+#if (QV_ABL & 4)
+                if (p.T < 0)
+#endif
+                {
+                char* const row_h = sSh + (16 * jt[u] + r) * kSRow + 8 * g;
+                char* const row_l = sSl + (16 * jt[u] + r) * kSRow + 8 * g;
+                *reinterpret_cast<uint2*>(row_h) = make_uint2(wh.x, wh.y);
+                *reinterpret_cast<uint2*>(row_h + 32) = make_uint2(wh.z, wh.w);
+                *reinterpret_cast<uint2*>(row_l) = make_uint2(wl.x, wl.y);
+                *reinterpret_cast<uint2*>(row_l + 32) = make_uint2(wl.z, wl.w);
+                }
+#pragma unroll
+                for (int id = 0; id < ND; ++id) {
+                    dv[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth[id], ph, dv[u][id], 0, 0, 0);
+                    dv[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth[id], pl, dv[u][id], 0, 0, 0);
+                    dv[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtl[id], ph, dv[u][id], 0, 0, 0);
+                    dk[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[id], sh, dk[u][id], 0, 0, 0);
+                    dk[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[id], sl2, dk[u][id], 0, 0, 0);
+                }
+            }
+        }
+#if !(QV_ABL & 2)
+        lds_only_barrier();   // every owned key tile's dS of this query pair is in the image
+#endif
+        if (qs == 3) QV_STAMP();   // 5: second barrier of sweep step 3
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};   // (two chains: the hi and the lo products)
+#pragma unroll
+        for (int ks = 0; ks < ((QV_ABL & 1) ? 0 : NKT / 2); ++ks) {
+            const bf16x8 kt = tr_frag2<HD>(sKt, 32 * ks, 32 * ks + 16, 16 * jd, lane);   // A: row = feature, k-slots = keys
+            const bf16x8 bh = tr_frag_ds(sSh, 32 * ks, 32 * ks + 16, 16 * vq, lane);     // B: col = query, the same k-slots
+            const bf16x8 bl = tr_frag_ds(sSl, 32 * ks, 32 * ks + 16, 16 * vq, lane);
+            dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, bh, dq, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, bl, dq1, 0, 0, 0);
+        }
+        dq += dq1;
+        if (qs == 0 || qs == 3) QV_STAMP();   // 4, 6: dQ tile done (sweep steps 0, 3)
+        if (qme < T) {   // rows: features 16 jd + 4g + e, column: query qme -> 8-byte (4 x bf16) stores along d
+            const uint32_t mb = mqb >> (4 * (g & 1));
+            const float gq[4] = {(mb & 1u) ? dq[0] * c * ckq.x : 0.f, (mb & 2u) ? dq[1] * c * ckq.y : 0.f, (mb & 4u) ? dq[2] * c * ckq.z : 0.f,
+                                 (mb & 8u) ? dq[3] * c * ckq.w : 0.f};
+            uint2 gh, gl;
+            split_pair(gq[0], gq[1], gh.x, gl.x); split_pair(gq[2], gq[3], gh.y, gl.y);
+            const int64_t offq = ((int64_t)b * T + qme) * ld + h * HD + 16 * jd + 4 * g;
+            *reinterpret_cast<uint2*>(p.dqkv_hi + offq) = gh;
+            *reinterpret_cast<uint2*>(p.dqkv_lo + offq) = gl;
+        }
+    }
+    QV_STAMP();   // 7: sweep done
+    // dK / dV: accumulators hold row = feature 16id + 4g + e, col = key 16j + r -> 8-B (4 x bf16) stores along d  (as k_attn_bwd_dkv)
+    float4 ckc[ND], cvc[ND];
+#pragma unroll
+    for (int id = 0; id < ND; ++id) {
+        ckc[id] = cvc[id] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.col_scale) {
+            ckc[id] = *reinterpret_cast<const float4*>(p.col_scale + D + h * HD + 16 * id + 4 * g);
+            cvc[id] = *reinterpret_cast<const float4*>(p.col_scale + 2 * D + h * HD + 16 * id + 4 * g);
+        }
+    }
+#if (QV_ABL & 32)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    QV_STAMP();   // 8: epilogue loads arrived (and the sweep's stores were acknowledged)
+#endif
+    // Through a wave-private LDS tile ([key][64 features] bf16, rows 144 B apart: 16-byte aligned, 2-way conflicts at most) so that the global
+    // stores are 16 bytes per lane in whole 128-byte row segments - straight from the accumulator layout they would be 8-byte pieces, 32 bytes
+    // per row and instruction: twice the store instructions, half-used lines.  The images are dead: one barrier, then each wave has its own 9 KiB.
+    uint2 mkr[U], mvr[U];   // the mask rows of this lane's keys (before the barrier: the epilogue tiles overwrite the front of the LDS only, but
+#pragma unroll              // keep the read next to the other image reads)
+    for (int u = 0; u < U; ++u) {
+        const int krow = min(16 * jt[u] + r, T - 1);
+        mkr[u] = sM[T + krow];
+        mvr[u] = sM[2 * T + krow];
+    }
+    lds_only_barrier();
+    constexpr int kERow = 144;
+    char* const sE = smem + wave * (4 * 16 * kERow);   // [k hi | k lo | v hi | v lo][16 keys][144 B]
+    const int erow = lane >> 3, ech = lane & 7;       // read-back: 8 lanes per key row, two passes of 8 rows
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!has[u]) continue;   // wave-uniform
+#pragma unroll
+        for (int id = 0; id < ND; ++id) {
+            const float4 ck = ckc[id], cv = cvc[id];
+            const uint32_t bk = (id < 2 ? mkr[u].x : mkr[u].y) >> (16 * (id & 1) + 4 * g), bv = (id < 2 ? mvr[u].x : mvr[u].y) >> (16 * (id & 1) + 4 * g);
+            const float vk[4] = {(bk & 1u) ? dk[u][id][0] * c * ck.x : 0.f, (bk & 2u) ? dk[u][id][1] * c * ck.y : 0.f,
+                                 (bk & 4u) ? dk[u][id][2] * c * ck.z : 0.f, (bk & 8u) ? dk[u][id][3] * c * ck.w : 0.f};
+            const float vv[4] = {(bv & 1u) ? dv[u][id][0] * cv.x : 0.f, (bv & 2u) ? dv[u][id][1] * cv.y : 0.f,
+                                 (bv & 4u) ? dv[u][id][2] * cv.z : 0.f, (bv & 8u) ? dv[u][id][3] * cv.w : 0.f};
+            uint2 kh, kl, vh, vl;
+            split_pair(vk[0], vk[1], kh.x, kl.x); split_pair(vk[2], vk[3], kh.y, kl.y);
+            split_pair(vv[0], vv[1], vh.x, vl.x); split_pair(vv[2], vv[3], vh.y, vl.y);
+            char* const e = sE + r * kERow + (16 * id + 4 * g) * 2;
+            *reinterpret_cast<uint2*>(e) = kh;
+            *reinterpret_cast<uint2*>(e + 16 * kERow) = kl;
+            *reinterpret_cast<uint2*>(e + 32 * kERow) = vh;
+            *reinterpret_cast<uint2*>(e + 48 * kERow) = vl;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-private: LDS is in order per wave, no barrier)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int key = 16 * jt[u] + 8 * half + erow;
+            const char* const e = sE + (8 * half + erow) * kERow + ech * 16;
+            const uint4 kh = *reinterpret_cast<const uint4*>(e), kl = *reinterpret_cast<const uint4*>(e + 16 * kERow);
+            const uint4 vh = *reinterpret_cast<const uint4*>(e + 32 * kERow), vl = *reinterpret_cast<const uint4*>(e + 48 * kERow);
+            if (key < T) {
+                const int64_t offk = ((int64_t)b * T + key) * ld + D + h * HD + 8 * ech;
+                *reinterpret_cast<uint4*>(p.dqkv_hi + offk) = kh;
+                *reinterpret_cast<uint4*>(p.dqkv_lo + offk) = kl;
+                *reinterpret_cast<uint4*>(p.dqkv_hi + offk + D) = vh;
+                *reinterpret_cast<uint4*>(p.dqkv_lo + offk + D) = vl;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is read before the next key tile overwrites it
+    }
+#if (QV_ABL & 32)
+    QV_STAMP();   // 9: stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    QV_STAMP();   // 10: stores acknowledged
+#endif
+}
+
 // ============================================================================ launchers
 static int check_shape(int T, int D, int H, int* nkt) {
     const int hd = D / H;
@@ -969,6 +1342,18 @@ int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B
                reinterpret_cast<__bf16*>(const_cast<void*>(O_lo)), const_cast<float*>(lse), delta, dO, reinterpret_cast<__bf16*>(dqkv_hi),
                reinterpret_cast<__bf16*>(dqkv_lo), col_scale, nullptr, nullptr, nullptr,
                reinterpret_cast<uint8_t*>(const_cast<void*>(codes)), reinterpret_cast<uint8_t*>(const_cast<void*>(cmask))};
+    // one fused kernel (dK, dV and dQ from one sweep) where its shape holds: head_dim 64, 33..224 tokens, saved codes; QATVIT_ATTN_BWD_FUSED=0: the
+    // two-kernel form (k_attn_bwd_dq + k_attn_bwd_dkv) everything else takes
+    static const bool fused_on = !(getenv("QATVIT_ATTN_BWD_FUSED") && atoi(getenv("QATVIT_ATTN_BWD_FUSED")) == 0);
+    int nkt;
+    if (check_shape(T, D, H, &nkt)) return 1;
+    if (fused_on && codes && D / H == 64 && nkt == 14) {
+        constexpr int kLds = 4 * 14 * 16 * 64 * 2 + 2 * 14 * 16 * kSRow + 2 * 14 * 16 * 4 + 3 * 14 * 16 * 8;   // 157,696 B
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_fused<14>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+        (void)once;
+        k_attn_bwd_fused<14><<<B * H, 8 * 64, kLds, st>>>(a);
+        return 0;
+    }
     if (dispatch(1, a, st)) return 1;
     return dispatch(2, a, st);
 }

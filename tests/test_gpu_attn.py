@@ -60,6 +60,51 @@ def test_attention_fwd_bwd(native_lib, B, T, H, D, with_colscale):
     assert (dqkv[0, :7] == 0).all()
 
 
+@pytest.mark.parametrize("B,T,H,D", [(3, 197, 6, 384), (2, 197, 12, 768), (2, 50, 6, 384), (1, 224, 6, 384), (2, 33, 6, 384), (1, 208, 1, 64)])
+@pytest.mark.parametrize("with_colscale", [False, True])
+def test_attention_fused_backward_vs_fp64(native_lib, B, T, H, D, with_colscale):
+    """The backward from the saved codes at head_dim 64 / 33..224 tokens runs as ONE kernel (k_attn_bwd_fused: dQ from the dK / dV sweep's dS through
+    LDS): against the fp64 reference, incl. token counts that leave waves without a key tile (50), that fill every tile (224, 208) and the
+    per-channel scale; delta is written as before."""
+    torch.manual_seed(B * T + D + 3)
+    dev = "cuda"
+    qkv = torch.randn(B * T, 3 * D, device=dev) * 1.5
+    qkv[0, :7] = 40.0
+    qkv[T - 1, D + 3:D + 9] = -40.0
+    scale, zp, qmin, qmax = 8.0 / 255, 120, 0, 255
+    qp = torch.tensor([scale, 1.0, float(zp), 1.0], device=dev)
+    qp[1] = torch.ones(1, device=dev)[0] / qp[0]
+    TP = native_lib.qatvit_attn_padded_tokens(T)
+    Oh = torch.zeros(B * T, D, device=dev, dtype=torch.bfloat16); Ol = torch.zeros_like(Oh)
+    O16h = torch.zeros(B * T, D, device=dev, dtype=torch.float16); O16l = torch.zeros_like(O16h)
+    osc = torch.zeros(1, device=dev)
+    lse = torch.zeros(B * H, TP, device=dev)
+    delta = torch.full((B * H, TP), float("nan"), device=dev)
+    codes = torch.zeros(B * T, 3 * D, dtype=torch.uint8, device=dev)
+    cmask = torch.zeros(B * T, 3 * D // 8, dtype=torch.uint8, device=dev)
+    dO = torch.randn(B * T, D, device=dev)
+    gh = torch.full((B * T, 3 * D), float("nan"), device=dev, dtype=torch.bfloat16)
+    gl = torch.full_like(gh, float("nan"))
+    cs = (torch.rand(3 * D, device=dev) + 0.5) if with_colscale else None
+    st = torch.cuda.current_stream().cuda_stream
+    assert native_lib.qatvit_attn_forward_f16(qkv.data_ptr(), qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
+                                              O16h.data_ptr(), O16l.data_ptr(), osc.data_ptr(), codes.data_ptr(), cmask.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+    assert native_lib.qatvit_attn_backward(None, qp.data_ptr(), qmin, qmax, B, T, H, D, Oh.data_ptr(), Ol.data_ptr(), lse.data_ptr(),
+                                           delta.data_ptr(), dO.data_ptr(), gh.data_ptr(), gl.data_ptr(), None if cs is None else cs.data_ptr(),
+                                           codes.data_ptr(), cmask.data_ptr(), st) == 0, native_lib.qatvit_last_error()
+    ro, rg = _ref(qkv, qp[0], zp, qmin, qmax, B, T, H, D, dO)
+    if cs is not None:
+        rg = rg * cs.double()[None, :]
+    dqkv = gh.float() + gl.float()
+    assert not torch.isnan(dqkv).any()
+    assert rel_l2(dqkv[:, :D].cpu(), rg[:, :D].cpu()) < 3e-5           # dQ
+    assert rel_l2(dqkv[:, D:2 * D].cpu(), rg[:, D:2 * D].cpu()) < 3e-5  # dK
+    assert rel_l2(dqkv[:, 2 * D:].cpu(), rg[:, 2 * D:].cpu()) < 3e-5    # dV
+    assert (dqkv[0, :7] == 0).all() and (dqkv[T - 1, D + 3:D + 9] == 0).all()
+    want = (dO.double() * ro).view(B, T, H, D // H).sum(-1).permute(0, 2, 1).reshape(B * H, T)     # delta = rowsum(dO . O) per head
+    assert rel_l2(delta[:, :T].cpu(), want.cpu()) < 3e-5
+
+
 def test_attention_rejects_unsupported(native_lib):
     x = torch.zeros(8, device="cuda")
     assert native_lib.qatvit_attn_forward(x.data_ptr(), x.data_ptr(), 0, 255, 1, 300, 1, 64, x.data_ptr(), x.data_ptr(), x.data_ptr(), None) != 0
@@ -97,7 +142,9 @@ def test_attention_forward_f16_pair(native_lib, B, T, H, D):
 @pytest.mark.parametrize("B,T,H,D,qmin,qmax,zp", [(3, 197, 6, 384, 0, 255, 120), (2, 197, 12, 768, 0, 127, 60), (1, 17, 4, 128, 0, 255, 131)])
 def test_attention_backward_from_saved_codes(native_lib, B, T, H, D, qmin, qmax, zp):
     """The forward saves the quantised qkv (uint8 codes + STE mask bits); the backward from them equals the backward that re-quantises the
-    pre-FQ tensor, bit for bit, and never touches that tensor (NULL is passed)."""
+    pre-FQ tensor, bit for bit, and never touches that tensor (NULL is passed).  Where the fused backward kernel takes the code form (head_dim 64,
+    33..224 tokens: k_attn_bwd_fused, dQ from the dK / dV sweep's dS through LDS) dV is still the same bits; dK and dQ - the same products, with
+    delta = rowsum(dO . O) summed in another order - agree to fp32 rounding."""
     torch.manual_seed(B * T + D + 7)
     dev = "cuda"
     qkv = torch.randn(B * T, 3 * D, device=dev) * 1.5
@@ -141,5 +188,13 @@ def test_attention_backward_from_saved_codes(native_lib, B, T, H, D, qmin, qmax,
                                                lse.data_ptr(), delta.data_ptr(), dO.data_ptr(), gh.data_ptr(), gl.data_ptr(), None,
                                                codes.data_ptr() if use_codes else None, cmask.data_ptr() if use_codes else None, st) == 0, native_lib.qatvit_last_error()
         outs.append((gh.clone(), gl.clone()))
-    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    fused = D // H == 64 and 32 < T <= 224
+    c0 = 2 * D if fused else 0   # dV columns (all columns in the two-kernel form): bit-identical
+    assert torch.equal(outs[0][0][:, c0:].view(torch.int16), outs[1][0][:, c0:].view(torch.int16))
+    assert torch.equal(outs[0][1][:, c0:].view(torch.int16), outs[1][1][:, c0:].view(torch.int16))
+    if fused:
+        for lo, hi in ((0, D), (D, 2 * D)):
+            g0, g1 = (o[0][:, lo:hi].float() + o[1][:, lo:hi].float() for o in outs)
+            assert rel_l2(g1.cpu(), g0.cpu()) < 2e-6
+            assert torch.equal(g0 == 0, g1 == 0)       # the STE mask zeros are the same elements
     assert not torch.isnan(outs[1][0].float()).any() and (outs[1][0][0, :9] == 0).all()
