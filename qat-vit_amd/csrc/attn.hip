@@ -28,9 +28,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef QV_ABL
-#define QV_ABL 0   // timing-only ablations of k_attn_bwd_fused (development builds: -DQV_ABL=bits)
-#endif
 constexpr int kAW = 8;  // waves per attention workgroup (two per SIMD)
 // workgroup barrier that waits for this wave's LDS traffic only (__syncthreads also drains vmcnt: every global store's round trip)
 __device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -948,9 +945,6 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
     float* sLse = reinterpret_cast<float*>(sSl + SIMG);
     float* sDlt = sLse + NKT * 16;
     uint2* sM = reinterpret_cast<uint2*>(sDlt + NKT * 16);   // STE mask bits of this head's q | k | v slices: [3][T] rows of HD / 8 = 8 bytes
-#if (QV_ABL & 16)
-    if ((blockIdx.x & 1) && blockIdx.x < 256) { for (int i = 0; i < (QV_ABL >> 8); ++i) __builtin_amdgcn_s_sleep(127); }
-#endif
     const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, D = p.D, ld = 3 * D;
@@ -964,19 +958,6 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nkt = (T + 15) / 16;
-#if (QV_ABL & 32)
-    const unsigned long long t00 = __builtin_amdgcn_s_memtime();
-    int nst = 0;
-    auto stamp = [&]() {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if ((blockIdx.x == 5 || blockIdx.x == 700) && lane == 0 && (wave == 0 || wave == 5) && nst < 13)
-            p.delta[(int64_t)blockIdx.x * (NKT * 16) + 198 + (wave ? 13 : 0) + nst] = (float)(unsigned)(t - t00);
-        ++nst;
-    };
-#define QV_STAMP() stamp()
-#else
-#define QV_STAMP()
-#endif
     int jt[U];
     bool has[U], kvalid[U];
     // the owned V row fragments from the saved codes, requested first (the K fragments are re-read from the K image every sweep step: 16 registers)
@@ -1014,7 +995,6 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
             ol[it] = *reinterpret_cast<const uint4*>(Olb + off);
         }
     }
-    QV_STAMP();   // 0: loads requested
     // the head's three mask slices are one contiguous run of 3 T rows: two 8-byte loads per thread here instead of 23 single-byte loads per
     // thread for the epilogues (each a full 64-lane address instruction)
     uint2 mrow[2];
@@ -1028,7 +1008,6 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
         asm volatile("" ::"v"(oh[it].x), "v"(oh[it].y), "v"(oh[it].z), "v"(oh[it].w), "v"(ol[it].x), "v"(ol[it].y), "v"(ol[it].z), "v"(ol[it].w));
         asm volatile("" ::"v"(cq[it].x), "v"(cq[it].y), "v"(ck[it].x), "v"(ck[it].y));
     }
-    QV_STAMP();   // 1: loads arrived
 #pragma unroll
     for (int k = 0; k < 2; ++k)
         if ((int)threadIdx.x + k * NWV * 64 < 3 * T) sM[threadIdx.x + k * NWV * 64] = mrow[k];
@@ -1072,9 +1051,7 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
     const int jd = wave & (ND - 1), vq = wave / ND;
     float4 ckq = make_float4(1.f, 1.f, 1.f, 1.f);
     if (p.col_scale) ckq = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 16 * jd + 4 * g);
-    QV_STAMP();   // 2: images written
     __syncthreads();
-    QV_STAMP();   // 3: barrier
     const float c = q.s * q.s * p.softmax_scale, c2 = c * kLog2e;
     f32x4 dk[U][ND], dv[U][ND];
 #pragma unroll
@@ -1082,7 +1059,7 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
 #pragma unroll
         for (int id = 0; id < ND; ++id) dk[u][id] = dv[u][id] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int qs = 0; qs < ((QV_ABL & 8) ? (p.T < 0 ? 1 : 0) : NKT / 2); ++qs) {
+    for (int qs = 0; qs < NKT / 2; ++qs) {
         const int qme = 16 * (2 * qs + vq) + r;
         const uint32_t mqb = reinterpret_cast<const uint8_t*>(sM)[min(qme, T - 1) * 8 + 2 * jd + (g >> 1)];
         // phase 1: S and dP of every owned key tile (the query-row fragments are dead afterwards: 48 registers)
@@ -1153,23 +1130,16 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
                 split_acc2(ds2[0], ds2[1], sh, sl2);
             }
             // the dS image is free again once every wave has finished the previous pair's dQ^T tile
-#if !(QV_ABL & 2)
             if (u == 0) lds_only_barrier();
-#endif
             if (has[u]) {
                 // this lane: key 16 jt + r, queries 4g .. 4g+3 of tile v in elements 4v .. 4v+3 -> 8-byte runs of the [key][32 queries] image
                 const uint4 wh = __builtin_bit_cast(uint4, sh), wl = __builtin_bit_cast(uint4, sl2);
-#if (QV_ABL & 4)
-                if (p.T < 0)
-#endif
-                {
                 char* const row_h = sSh + (16 * jt[u] + r) * kSRow + 8 * g;
                 char* const row_l = sSl + (16 * jt[u] + r) * kSRow + 8 * g;
                 *reinterpret_cast<uint2*>(row_h) = make_uint2(wh.x, wh.y);
                 *reinterpret_cast<uint2*>(row_h + 32) = make_uint2(wh.z, wh.w);
                 *reinterpret_cast<uint2*>(row_l) = make_uint2(wl.x, wl.y);
                 *reinterpret_cast<uint2*>(row_l + 32) = make_uint2(wl.z, wl.w);
-                }
 #pragma unroll
                 for (int id = 0; id < ND; ++id) {
                     dv[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth[id], ph, dv[u][id], 0, 0, 0);
@@ -1180,13 +1150,10 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
                 }
             }
         }
-#if !(QV_ABL & 2)
         lds_only_barrier();   // every owned key tile's dS of this query pair is in the image
-#endif
-        if (qs == 3) QV_STAMP();   // 5: second barrier of sweep step 3
         f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};   // (two chains: the hi and the lo products)
 #pragma unroll
-        for (int ks = 0; ks < ((QV_ABL & 1) ? 0 : NKT / 2); ++ks) {
+        for (int ks = 0; ks < NKT / 2; ++ks) {
             const bf16x8 kt = tr_frag2<HD>(sKt, 32 * ks, 32 * ks + 16, 16 * jd, lane);   // A: row = feature, k-slots = keys
             const bf16x8 bh = tr_frag_ds(sSh, 32 * ks, 32 * ks + 16, 16 * vq, lane);     // B: col = query, the same k-slots
             const bf16x8 bl = tr_frag_ds(sSl, 32 * ks, 32 * ks + 16, 16 * vq, lane);
@@ -1194,7 +1161,6 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
             dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, bl, dq1, 0, 0, 0);
         }
         dq += dq1;
-        if (qs == 0 || qs == 3) QV_STAMP();   // 4, 6: dQ tile done (sweep steps 0, 3)
         if (qme < T) {   // rows: features 16 jd + 4g + e, column: query qme -> 8-byte (4 x bf16) stores along d
             const uint32_t mb = mqb >> (4 * (g & 1));
             const float gq[4] = {(mb & 1u) ? dq[0] * c * ckq.x : 0.f, (mb & 2u) ? dq[1] * c * ckq.y : 0.f, (mb & 4u) ? dq[2] * c * ckq.z : 0.f,
@@ -1206,7 +1172,6 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
             *reinterpret_cast<uint2*>(p.dqkv_lo + offq) = gl;
         }
     }
-    QV_STAMP();   // 7: sweep done
     // dK / dV: accumulators hold row = feature 16id + 4g + e, col = key 16j + r -> 8-B (4 x bf16) stores along d  (as k_attn_bwd_dkv)
     float4 ckc[ND], cvc[ND];
 #pragma unroll
@@ -1217,10 +1182,6 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
             cvc[id] = *reinterpret_cast<const float4*>(p.col_scale + 2 * D + h * HD + 16 * id + 4 * g);
         }
     }
-#if (QV_ABL & 32)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    QV_STAMP();   // 8: epilogue loads arrived (and the sweep's stores were acknowledged)
-#endif
     // Through a wave-private LDS tile ([key][64 features] bf16, rows 144 B apart: 16-byte aligned, 2-way conflicts at most) so that the global
     // stores are 16 bytes per lane in whole 128-byte row segments - straight from the accumulator layout they would be 8-byte pieces, 32 bytes
     // per row and instruction: twice the store instructions, half-used lines.  The images are dead: one barrier, then each wave has its own 9 KiB.
@@ -1272,11 +1233,6 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is read before the next key tile overwrites it
     }
-#if (QV_ABL & 32)
-    QV_STAMP();   // 9: stores issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    QV_STAMP();   // 10: stores acknowledged
-#endif
 }
 
 // ============================================================================ launchers
