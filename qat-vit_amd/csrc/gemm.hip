@@ -163,6 +163,16 @@ __device__ const ZerosTab kZeros{};
 // ---- shared epilogue of the NT kernels.  WM x WN waves, wave (wm, wn) holds a (16*TM) x (16*TNT) sub-tile in acc[][].
 // PM: the epilogue variant compiled into this instantiation (one per kernel: a monolithic epilogue with every mode selected at run time
 // needs 100 more registers than the accumulators leave and spills them)
+#ifdef QV_NT_EXPERIMENTS   // development builds only (-DQV_NT_EXPERIMENTS=<epilogue mode>): s_memtime stamps of that mode's phases, workgroups 0 and 100, every
+__device__ unsigned long long g_nt_stamps[2 * 8 * 16];   // wave; read back with qatvit_debug_nt_stamps (tools/stamp_nt.py).  The shipped library has none.
+#define QV_NT_STAMP(PM_, k_)                                                                                                    \
+    do {                                                                                                                        \
+        if ((PM_) == QV_NT_EXPERIMENTS && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0)                    \
+            g_nt_stamps[((blockIdx.x ? 1 : 0) * 8 + (threadIdx.x >> 6)) * 16 + (k_)] = __builtin_amdgcn_s_memtime();            \
+    } while (0)
+#else
+#define QV_NT_STAMP(PM_, k_)
+#endif
 template <int WM, int WN, int TM, int TNT, int SLAB = 64, int PM = 0, int RING = 0, bool I8 = false>   // SLAB: rows staged through LDS at a time; RING: LDS bytes
 __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4, f32x4> (&acc)[TM][TNT], char* smem, int m0, int n0, int tid, int lane, int wave, int wm, int wn,
                                    int r, int g) {
@@ -309,6 +319,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     } else
 #pragma unroll
     for (int h = 0; h < (BM + SLAB - 1) / SLAB; ++h) {
+        QV_NT_STAMP(PM, 4 + 2 * h);   // slab h: staging starts
         if (h) lds_barrier();   // every wave is done reading the staged slab (its global stores may still be in flight)
         int code_ahead = 0;   // DMA instructions of this wave younger than the ones slab h waits for
         if constexpr (CODE_DB) {
@@ -349,6 +360,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
             else wait_vmcnt<6>();
         } else if constexpr (CODE_LDS) wait_vmcnt<0>();
         lds_barrier();
+        QV_NT_STAMP(PM, 5 + 2 * h);   // slab h staged (and its codes arrived)
         constexpr int C4 = BN / 4;              // float4 per staged row
         const int rows_h = BM - SLAB * h < SLAB ? BM - SLAB * h : SLAB;
         if constexpr (PM == 8) {
@@ -827,11 +839,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void k_gemm_nt(
         for (int j = 0; j < TNT; ++j) acc[i][j] = acc_t{};
 
     const int nk = p.K / BK;
+    QV_NT_STAMP(PM, 0);   // entry
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < nk) issue(s);
 
     for (int kt = 0; kt < nk; ++kt) {
+        if (kt == 1) QV_NT_STAMP(PM, 1);        // first k-step done
+        if (kt == nk / 2) QV_NT_STAMP(PM, 2);   // half of the k-loop
         // tile kt has landed once at most the (NSTAGE-2) younger tiles' DMAs are still outstanding
         if (NSTAGE >= 3 && kt + NSTAGE - 2 < nk) {
             if (NDX && wave < NDX) wait_vmcnt<(NSTAGE - 2) * (NDF + 1)>();
@@ -912,6 +927,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void k_gemm_nt(
         }
     }
     __syncthreads();  // all fragment reads done: the ring is free for the epilogue
+    QV_NT_STAMP(PM, 3);   // k-loop done
     // the staging slab (+ LUT, + the codes of mode 5) must fit inside the ring; mode 5 prefers 48 rows with two code buffers to 64 with one
     constexpr int RING_ = NSTAGE * STAGE;
     constexpr bool PM5_48 = PM == 5 && RING_ >= 48 * (BN + 4) * 4 + 1024 + 2 * 48 * BN * 2 && RING_ < 64 * (BN + 4) * 4 + 1024 + 2 * 64 * BN * 2;
@@ -922,6 +938,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void k_gemm_nt(
     constexpr int EPI_LDS = (PM == 8 || PM == 9) ? 160 * 1024 : NSTAGE * STAGE;
     static_assert(EPI_LDS >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
     nt_epilogue<WM, WN, TM, TNT, SLAB, PM, EPI_LDS, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
+    QV_NT_STAMP(PM, 12);   // stores issued
+#ifdef QV_NT_EXPERIMENTS
+    if (PM == QV_NT_EXPERIMENTS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QV_NT_STAMP(PM, 13); }
+#endif
 }
 
 // register-destination loads beside LDS-DMA: inline asm (hipcc waits vmcnt(0) for every ordinary load result while a DMA is in flight), counted by hand
@@ -1765,3 +1785,9 @@ int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, con
 }
 
 }  // namespace qv
+
+#ifdef QV_NT_EXPERIMENTS
+extern "C" __attribute__((visibility("default"))) int qatvit_debug_nt_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(qv::g_nt_stamps), sizeof(unsigned long long) * 2 * 8 * 16) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""s_memtime stamps of the mode-8 (dgrad + fused LayerNorm backward) or mode-9 (fc2 dgrad + GELU') NT kernel inside the real C2 step at batch 256.
+Needs a development build of the library (-DQV_NT_EXPERIMENTS=8 or 9: tools/ab_lib.sh describes how such a build is linked); the shipped library has
+no stamps.  usage: python3 tools/stamp_nt.py   (prints, for workgroups 0 and 100, ticks since entry per phase for every wave)"""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-rates", "--no-extras", "--no-kernel-legs"]
+import runpy  # noqa: E402
+
+try:
+    runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
+except SystemExit:
+    pass
+torch.cuda.synchronize()
+from qat_vit_amd import native  # noqa: E402
+
+L = native.lib()
+if not hasattr(L, "qatvit_debug_nt_stamps"):
+    sys.exit("this libqatvit.so was built without -DQV_NT_EXPERIMENTS")
+buf = (ctypes.c_ulonglong * (2 * 8 * 16))()
+assert L.qatvit_debug_nt_stamps(buf) == 0
+names = ["entry", "k-step 1", "k half", "k-loop done", "slab0 stage", "slab0 staged", "slab1 stage", "slab1 staged", "slab2 stage", "slab2 staged", "slab3 stage", "slab3 staged",
+         "stores issued", "stores acked"]
+for b in range(2):
+    for w in range(8):
+        t = [buf[(b * 8 + w) * 16 + k] for k in range(14)]
+        print(f"block {(0, 100)[b]} wave {w}: " + "  ".join(f"{n}={t[k] - t[0]}" for k, n in enumerate(names) if t[k] and k))
