@@ -24,8 +24,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kAW = 8;  // waves per attention workgroup (two per SIMD)
@@ -33,20 +31,7 @@ constexpr int kAW = 8;  // waves per attention workgroup (two per SIMD)
 __device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
-// The attention kernels are VALU-bound (ISA count per 16 x 32 tile pair of the backward sweep: 290 VALU instructions against 64 MFMAs), so
-// the float -> bf16 (hi, lo) splits go two elements per instruction: v_cvt_pk_bf16_f32 on a PAIR (a per-element cast costs one v_cvt_pk
-// plus a shift to pack), the hi parts back to fp32 by shift / mask, the residuals by one v_pk_add_f32.  Same roundings, same bits.
-__device__ inline uint32_t pk_bf16(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ inline void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const f32x2 v = {a, b};
-    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-    const f32x2 h = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
-    const f32x2 r = v - h;
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
-}
+// (pk_bf16 / split_pair: qv_common.h)
 
 struct AQP { float s, inv, zp; float fqmin, fqmax; };
 __device__ inline float qint(float x, const AQP& q) { return fminf(fmaxf(rintf(x * q.inv) + q.zp, q.fqmin), q.fqmax) - q.zp; }

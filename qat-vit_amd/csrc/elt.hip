@@ -35,11 +35,11 @@ __device__ inline float fqi(float x, const QP& q, float fqmin, float fqmax) {
 
 // float operand of a later GEMM -> (hi, lo) bf16 pair, 4 elements
 __device__ inline void store_split4(__bf16* hi, __bf16* lo, int64_t off, float a, float b, float c, float d) {
-    bf16x4 h, l;
-    h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
-    l[0] = (__bf16)(a - (float)h[0]); l[1] = (__bf16)(b - (float)h[1]); l[2] = (__bf16)(c - (float)h[2]); l[3] = (__bf16)(d - (float)h[3]);
-    *reinterpret_cast<bf16x4*>(hi + off) = h;
-    *reinterpret_cast<bf16x4*>(lo + off) = l;
+    uint2 h, l;
+    split_pair(a, b, h.x, l.x);
+    split_pair(c, d, h.y, l.y);
+    *reinterpret_cast<uint2*>(hi + off) = h;
+    *reinterpret_cast<uint2*>(lo + off) = l;
 }
 
 static inline int rows_grid(int64_t rows) {

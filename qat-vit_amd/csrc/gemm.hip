@@ -433,12 +433,11 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         const float4 cs = *reinterpret_cast<const float4*>(sCs + c);
                         const float f0 = (mk[j][0] >> lane) & 1 ? o.x * cs.x : 0.f, f1 = (mk[j][1] >> lane) & 1 ? o.y * cs.y : 0.f,
                                     f2 = (mk[j][2] >> lane) & 1 ? o.z * cs.z : 0.f, f3 = (mk[j][3] >> lane) & 1 ? o.w * cs.w : 0.f;
-                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                        bf16x4 hh, ll;
-                        hh[0] = (__bf16)f0; hh[1] = (__bf16)f1; hh[2] = (__bf16)f2; hh[3] = (__bf16)f3;
-                        ll[0] = (__bf16)(f0 - (float)hh[0]); ll[1] = (__bf16)(f1 - (float)hh[1]); ll[2] = (__bf16)(f2 - (float)hh[2]); ll[3] = (__bf16)(f3 - (float)hh[3]);
-                        *reinterpret_cast<bf16x4*>(p.out_hi + row * BN + c) = hh;
-                        *reinterpret_cast<bf16x4*>(p.out_lo + row * BN + c) = ll;
+                        uint2 hh, ll;
+                        split_pair(f0, f1, hh.x, ll.x);
+                        split_pair(f2, f3, hh.y, ll.y);
+                        *reinterpret_cast<uint2*>(p.out_hi + row * BN + c) = hh;
+                        *reinterpret_cast<uint2*>(p.out_lo + row * BN + c) = ll;
                     }
                 }
             }
@@ -568,19 +567,19 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         if constexpr (CS_LDS) cs = *reinterpret_cast<const float4*>(sCs + (int)((base + u * NT_) % C4) * 4);
                         else if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + (int)((base + u * NT_) % C4) * 4);
                         const float cv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, sv[4] = {cs.x, cs.y, cs.z, cs.w};
-                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                        bf16x4 oh, ol;
+                        float o[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const uint32_t cde = (e & 1) ? ((e & 2) ? c2[u].y : c2[u].x) >> 16 : ((e & 2) ? c2[u].y : c2[u].x);
                             const bool in_range = PM == 9 ? ((c2[u].y >> e) & 1u) != 0 : (cde & 0x8000u) != 0;
-                            const float o = in_range ? cv[e] * dg[u][e] * sv[e] : 0.f;
-                            oh[e] = (__bf16)o;
-                            ol[e] = (__bf16)(o - (float)oh[e]);
+                            o[e] = in_range ? cv[e] * dg[u][e] * sv[e] : 0.f;
                         }
+                        uint2 oh, ol;
+                        split_pair(o[0], o[1], oh.x, ol.x);
+                        split_pair(o[2], o[3], oh.y, ol.y);
                         if (ok[u]) {
-                            *reinterpret_cast<bf16x4*>(p.out_hi + off[u]) = oh;
-                            *reinterpret_cast<bf16x4*>(p.out_lo + off[u]) = ol;
+                            *reinterpret_cast<uint2*>(p.out_hi + off[u]) = oh;
+                            *reinterpret_cast<uint2*>(p.out_lo + off[u]) = ol;
                         }
                     }
                 }

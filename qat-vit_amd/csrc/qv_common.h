@@ -82,6 +82,23 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // expf expands to ~20 instructions; v_exp_f32 is accurate to ~1 ulp, far inside the 3e-5 kernel tolerance.
 __device__ inline float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
+// float -> bf16 (hi, lo) splits two elements per instruction: v_cvt_pk_bf16_f32 on a PAIR (a per-element (__bf16) cast costs one v_cvt_pk plus a
+// shift to pack), the hi parts back to fp32 by shift / mask, the residuals by one v_pk_add_f32.  Same roundings, same bits as the per-element form.
+// (The attention sweeps issued 290 VALU instructions per 64 MFMAs before this; the GEMM epilogues that write pairs use it too.)
+typedef float qv_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 qv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pk_bf16(float a, float b) {
+    const qv_f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, qv_bf16x2));
+}
+__device__ inline void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const qv_f32x2 v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, qv_bf16x2));
+    const qv_f32x2 h = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    const qv_f32x2 r = v - h;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, qv_bf16x2));
+}
+
 // exact-erf GELU (nn.GELU() default) and its derivative
 __device__ inline float gelu_fwd(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 // GELU for the frozen teacher's fused fc1 epilogue (no quantisation grid there, so no table): erfc by Abramowitz-Stegun 7.1.26
