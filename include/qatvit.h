@@ -124,8 +124,8 @@ int qatvit_gemm_nt_i8_minmax(const void* A8, const void* B8, const int32_t* wsum
  * 16 x 64 weight fragments as 1 KiB of contiguous memory straight into registers.  N % 48 == 0, K % 64 == 0. */
 int qatvit_w8_fragment_order(const void* B8, void* B8f, int32_t N, int32_t K, void* stream);
 
-/* The K = 384 two-pass forward GEMMs of a block (attn.qkv, mlp.fc1: nnqat.Linear.forward, torch/ao/nn/qat/modules/linear.py:49-50, + the
- * activation_post_process hook, torch/ao/quantization/quantize.py:150-152) on int8 MFMA, A-stationary: one workgroup keeps a 208-row strip of A8
+/* The K = 384 / 768 two-pass forward GEMMs of a block (attn.qkv, mlp.fc1 of ViT-S / ViT-B: nnqat.Linear.forward, torch/ao/nn/qat/modules/linear.py:49-50, + the
+ * activation_post_process hook, torch/ao/quantization/quantize.py:150-152) on int8 MFMA, A-stationary: one workgroup keeps a 208- (K = 768: 112-) row strip of A8
  * in LDS for all column tiles, each wave reads its weight fragments from B8f (qatvit_w8_fragment_order) into registers, the k-loop has no barrier.
  * v[m,n] = (sum_k A8*B8 + (center - zero_point) * wsum[n]) * (*s1) * (*s2) * col_scale[n] + bias[n]  - the value qatvit_gemm_nt_i8 stores, bit for bit.
  *   mode 3: min / max of v into stats (as qatvit_gemm_nt_i8_minmax); nothing is stored.
@@ -134,8 +134,8 @@ int qatvit_w8_fragment_order(const void* B8, void* B8f, int32_t N, int32_t K, vo
  *           mask (qmin <= q <= qmax), one bit per element in the same order.
  *   mode 4: out8 = the same code row-major [M,N], out8_mask [M,N/8]; lut_out / lutq_out [256] = packed fp16 / bf16 (hi | lo << 16) pairs of
  *           2^k * gelu(grid value) / gelu(grid value), *out16_scale = 2^-k (the tables qatvit_gemm_nt_codes / qatvit_gemm_tn_codes expand the codes through).
- * N % 1152 == 0 or N % 1536 == 0; K is 384 (not passed); lda % 16 == 0; M < 2^22. */
-int qatvit_i8_strip(int32_t mode, const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N,
+ * K = 384: N % 1152 == 0 or N % 1536 == 0; K = 768: N = 2304 or 3072; lda % 16 == 0; M < 2^22. */
+int qatvit_i8_strip(int32_t mode, const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N, int32_t K,
                     int32_t lda, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, const float* out_qp,
                     int32_t qmin, int32_t qmax, void* out8, void* out8_mask, int32_t code_T, uint32_t* lut_out, uint32_t* lutq_out,
                     float* out16_scale, void* stream);

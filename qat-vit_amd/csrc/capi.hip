@@ -116,7 +116,7 @@ int qatvit_w8_fragment_order(const void* B8, void* B8f, int32_t N, int32_t K, vo
     return 0;
 }
 
-int qatvit_i8_strip(int32_t mode, const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N,
+int qatvit_i8_strip(int32_t mode, const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int32_t center, int32_t M, int32_t N, int32_t K,
                     int32_t lda, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, const float* out_qp,
                     int32_t qmin, int32_t qmax, void* out8, void* out8_mask, int32_t code_T, uint32_t* lut_out, uint32_t* lutq_out,
                     float* out16_scale, void* stream) {
@@ -126,9 +126,10 @@ int qatvit_i8_strip(int32_t mode, const void* A8, const void* B8f, const int32_t
     post.mode = mode;
     post.qp = out_qp; post.qmin = qmin; post.qmax = qmax; post.out8 = out8; post.out8_mask = out8_mask; post.code_T = code_T; post.code_hd = 64;
     post.lut_out = lut_out; post.lutq_out = lutq_out; post.out16_scale = out16_scale;
-    if (!launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, 384, lda, N, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream, &post, true)) {
-        set_error("qatvit_i8_strip: unsupported arguments (mode %d M=%d N=%d lda=%d: need N %% 1152 == 0 or N %% 1536 == 0, lda %% 16 == 0, M < 2^22, "
-                  "the mode's output pointers, qmax - qmin < 256; mode 7: (N / 3) %% 384 == 0, 0 < code_T < 1024)", mode, M, N, lda);
+    if (!launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, K, lda, N, s1, s2, col_scale, bias, stats, 1, (hipStream_t)stream, &post, true)) {
+        set_error("qatvit_i8_strip: unsupported arguments (mode %d M=%d N=%d K=%d lda=%d: need K = 384 with N %% 1152 == 0 or N %% 1536 == 0, or K = 768 with "
+                  "N = 2304 or 3072; lda %% 16 == 0, M < 2^22, the mode's output pointers, qmax - qmin < 256; mode 7: (N / 3) %% 384 == 0, 0 < code_T < 1024)",
+                  mode, M, N, K, lda);
         return 1;
     }
     QV_CHECK_LAUNCH("qatvit_i8_strip");

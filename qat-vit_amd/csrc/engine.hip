@@ -72,7 +72,7 @@ struct Plan {
     int64_t wq, wqT;                // per weight: offsets table below
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
     int64_t w8_off[64 * 4 + 8], wsum_off[64 * 4 + 8], wsum_base, wsum_bytes, imgq8, h1q8, h2q8;   // int8 operands of the forward grid x grid GEMMs
-    int64_t w8f_off[64 * 4 + 8];   // the int8 weight once more in fragment order (qkv, fc1 with K == 384: the strip kernel's B operand), -1 otherwise
+    int64_t w8f_off[64 * 4 + 8];   // the int8 weight once more in fragment order (qkv, fc1 with K == 384 / 768: the strip kernel's B operand), -1 otherwise
     int64_t w16_off[64 * 4 + 8], O16_hi, O16_lo, G16_hi, G16_lo, scal16;   // fp16 operands of the forward float x grid GEMMs (proj, fc2): shared by all blocks
     int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo, tn_scratch;
     int64_t total, stats_words;
@@ -136,7 +136,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
         p->w8_off[wi] = take((int64_t)N * K);
         const int kind = (wi == 0 || wi == d.n_w - 1) ? -1 : (wi - 1) % WB_COUNT;
         p->w16_off[wi] = (kind == WB_PROJ || kind == WB_FC2) ? take((int64_t)N * K * 2) : -1;
-        p->w8f_off[wi] = ((kind == WB_QKV || kind == WB_FC1) && K == 384 && N % 48 == 0) ? take((int64_t)N * K) : -1;
+        p->w8f_off[wi] = ((kind == WB_QKV || kind == WB_FC1) && (K == 384 || K == 768) && N % 48 == 0) ? take((int64_t)N * K) : -1;
     }
     // the float A operands of the two forward GEMMs with a float operand, as fp16 (hi, lo) pairs: written and consumed inside one block's
     // forward, so ONE set serves every block (the bf16 pairs next to them stay per block: the weight-gradient GEMMs read them in the backward)

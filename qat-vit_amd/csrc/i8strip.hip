@@ -81,11 +81,15 @@ __device__ inline void strip_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\
 #endif
 
 // R255: the output quantizer has 256 levels (qmax - qmin == 255): v_cvt_pk_u8_f32's own saturation is the clamp
-template <int MODE, int NTL, int NWV = 8, bool R255 = false>   // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384; NWV waves, each 208 rows x WC = 384 / NWV columns
+// NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384; NWV waves, each 16 TM rows x WC = 384 / NWV columns; K = 64 KT.
+// (TM, KT) = (13, 6): 208-row strips of K = 384 (ViT-S: 243 strips at batch 256, one round); (7, 12): 112-row strips of K = 768 (ViT-B: 226 strips at
+// batch 128, all 6 / 8 column tiles in one workgroup) - the strip has to fit LDS next to the constants and the staging patches.
+template <int MODE, int NTL, int NWV = 8, bool R255 = false, int TM_ = 13, int KT_ = 6>
 __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArgs p) {
-    constexpr int TM = 13, TNT = 24 / NWV, WC = 16 * TNT, BM = 208, BN = 384, KT = 6, PF = 3, NT_ = NWV * 64;
+    constexpr int TM = TM_, TNT = 24 / NWV, WC = 16 * TNT, BM = 16 * TM, BN = 384, KT = KT_, PF = 3, NT_ = NWV * 64;
+    static_assert(TM <= 2 * NWV, "the strip's 1-KiB DMA pieces are dealt in two rounds");
     static_assert(NWV == 8 || NWV == 12, "8 waves x 48 columns or 12 waves x 32 columns");
-    constexpr int IMGA = BM * 64, LA = KT * IMGA;        // 79,872 B
+    constexpr int IMGA = BM * 64, LA = KT * IMGA;        // 79,872 B (13, 6) / 86,016 B (7, 12)
     constexpr int NC = NTL * BN;                         // columns of this workgroup
     constexpr int CH = 4;                                // row fragments per staging chunk: 64 rows x 48 columns of codes + 64 x 8 B of mask bits per wave
     constexpr int WSTG = 16 * CH * WC + 16 * CH * 16;    // per wave: [64][WC B] codes + [64][16 B] mask nibbles
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
 #endif
     QV_STAMP();   // entry
 
-    // ---- A strip: 6 k-tiles x 13 pieces of 1 KiB, dealt to the 8 waves; the swizzle goes on the SOURCE address (the DMA destination is lane-linear)
+    // ---- A strip: KT k-tiles x TM pieces of 1 KiB, dealt to the waves; the swizzle goes on the SOURCE address (the DMA destination is lane-linear)
     {
         const int64_t abytes = (int64_t)p.M * p.lda;   // wave-uniform raw-buffer descriptor: lanes past the end read zero
         const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.A), 0, abytes > 0xffffffffll ? 0xffffffffu : (uint32_t)abytes, 0x00020000);
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
     }
     // this wave's weight fragments: group (nbase / 48 + 8 nt + wave), k-step kt, fragment j: 1 KiB each, lane * 16 B inside.  Buffer loads with the
     // fragment's offset in an SGPR (one VGPR of address for all 18 fragments of a column tile: as 64-bit global addresses they were 36 registers)
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4*>(p.Bf), 0, (uint32_t)((int64_t)p.N * 384), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4*>(p.Bf), 0, (uint32_t)((int64_t)p.N * (KT * 64)), 0x00020000);
     // (w8f order: 16-column fragment f = column / 16 lives at ((f / 3) * KT + kt) * 3 + f % 3, in units of 1 KiB)
     const int f0 = nbase / 16 + wave * TNT;              // (uniform) this wave's first fragment of column tile 0
     auto load_b = [&](int nt, int kt, i32x4 (&b)[TNT]) {
@@ -377,19 +381,20 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
     }
 }
 
-template <int MODE, int NTL, int NWV, bool R255>
+template <int MODE, int NTL, int NWV, bool R255, int TM, int KT>
 static void strip_launch_r(const I8StripArgs& a, hipStream_t st) {
-    constexpr int kLds = 6 * 208 * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : NWV * (64 * (384 / NWV) + 64 * 16));
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, NWV, R255>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+    constexpr int kLds = KT * 16 * TM * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : NWV * (64 * (384 / NWV) + 64 * 16));
+    static_assert(kLds <= 160 * 1024, "strip + constants + staging patches exceed the LDS");
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, NWV, R255, TM, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
     (void)once;
-    k_i8_strip<MODE, NTL, NWV, R255><<<dim3(cdiv(a.M, 208), a.N / (NTL * 384)), NWV * 64, kLds, st>>>(a);
+    k_i8_strip<MODE, NTL, NWV, R255, TM, KT><<<dim3(cdiv(a.M, 16 * TM), a.N / (NTL * 384)), NWV * 64, kLds, st>>>(a);
 }
-template <int MODE, int NTL, int NWV>
+template <int MODE, int NTL, int NWV, int TM, int KT>
 static void strip_launch_w(const I8StripArgs& a, hipStream_t st) {
-    if (MODE != 3 && a.qmax - a.qmin == 255) strip_launch_r<MODE, NTL, NWV, true>(a, st);
-    else strip_launch_r<MODE, NTL, NWV, false>(a, st);
+    if (MODE != 3 && a.qmax - a.qmin == 255) strip_launch_r<MODE, NTL, NWV, true, TM, KT>(a, st);
+    else strip_launch_r<MODE, NTL, NWV, false, TM, KT>(a, st);
 }
-template <int MODE, int NTL>
+template <int MODE, int NTL, int TM = 13, int KT = 6>
 static void strip_launch(const I8StripArgs& a0, hipStream_t st) {
     I8StripArgs a = a0;
 #ifdef QV_STRIP_EXPERIMENTS
@@ -399,8 +404,8 @@ static void strip_launch(const I8StripArgs& a0, hipStream_t st) {
     // statistics pass: 8 waves x 48 columns (two per SIMD); code passes: 12 waves x 32 columns (three per SIMD, 104 accumulator registers) - their
     // quantise phase is VALU-issue-bound per wave, and a third wave per SIMD fills it: qkv 45.5 -> 42.9 us, fc1 54.4 -> 50.4 us (the statistics
     // pass does not gain: 27.4 -> 28.0)
-    if constexpr (MODE == 3) strip_launch_w<MODE, NTL, 8>(a, st);
-    else strip_launch_w<MODE, NTL, 12>(a, st);
+    if constexpr (MODE == 3) strip_launch_w<MODE, NTL, 8, TM, KT>(a, st);
+    else strip_launch_w<MODE, NTL, 12, TM, KT>(a, st);
 }
 
 // true when the strip kernel covers the request (the caller then launched it); false -> the general tall kernel
@@ -408,16 +413,19 @@ bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
                      const NTPost* post, bool force) {
     static const int on = getenv("QATVIT_I8_STRIP") ? atoi(getenv("QATVIT_I8_STRIP")) : 1;   // 0: the general tall kernel (A/B arm of the bit-identity test)
-    if ((!on && !force) || !B8f || !post || K != 384 || lda % 16 != 0 || !s1 || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24)) return false;
-    const int ntl = N % (4 * 384) == 0 ? 4 : N % (3 * 384) == 0 ? 3 : 0;
+    if ((!on && !force) || !B8f || !post || (K != 384 && K != 768) || lda % 16 != 0 || !s1 || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24)) return false;
+    // K = 384: 3 or 4 column tiles per workgroup (qkv 1152 / fc1 1536 of ViT-S); K = 768: all 6 or 8 of them (qkv 2304 / fc1 3072 of ViT-B)
+    const int ntl = K == 384 ? (N % (4 * 384) == 0 ? 4 : N % (3 * 384) == 0 ? 3 : 0) : (N == 6 * 384 ? 6 : N == 8 * 384 ? 8 : 0);
     if (!ntl) return false;
+    const bool wide = K == 768;
     I8StripArgs a{};
     a.A = reinterpret_cast<const int8_t*>(A8); a.Bf = reinterpret_cast<const i32x4*>(B8f); a.M = M; a.N = N; a.lda = lda;
     a.s1 = s1; a.s2 = s2; a.col_scale = col_scale; a.bias = bias; a.wsum = wsum; a.aqp = a_qp; a.center = center;
     if (post->mode == 3) {
         if (!stats) return false;
         a.stats = stats; a.stat_slots = stat_slots < 1 ? 1 : stat_slots;
-        if (ntl == 4) strip_launch<3, 4>(a, st); else strip_launch<3, 3>(a, st);
+        if (wide) { if (ntl == 8) strip_launch<3, 8, 7, 12>(a, st); else strip_launch<3, 6, 7, 12>(a, st); }
+        else if (ntl == 4) strip_launch<3, 4>(a, st); else strip_launch<3, 3>(a, st);
         return true;
     }
     a.qp = post->qp; a.qmin = post->qmin; a.qmax = post->qmax;
@@ -427,14 +435,16 @@ bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const
         const int D = N / 3;
         if (post->code_hd != 64 || D % 384 != 0 || post->code_T < 1 || post->code_T >= 1024) return false;
         a.code_T = post->code_T; a.D = D;
-        if (ntl == 4) strip_launch<7, 4>(a, st); else strip_launch<7, 3>(a, st);
+        if (wide) { if (ntl == 8) strip_launch<7, 8, 7, 12>(a, st); else strip_launch<7, 6, 7, 12>(a, st); }
+        else if (ntl == 4) strip_launch<7, 4>(a, st); else strip_launch<7, 3>(a, st);
         return true;
     }
     if (post->mode == 4) {
         // the codes-only form of the storing pass: grid indices + mask bits + the two tables, no 2- or 4-byte plane
         if (post->out_hi || post->out_lo || post->code || post->out16_hi || post->out16_lo || !post->lut_out || !post->lutq_out || ldc % 128 != 0) return false;
         a.ldc = ldc; a.lut_out = post->lut_out; a.lutq_out = post->lutq_out; a.out16_scale = post->out16_scale;
-        if (ntl == 4) strip_launch<4, 4>(a, st); else strip_launch<4, 3>(a, st);
+        if (wide) { if (ntl == 8) strip_launch<4, 8, 7, 12>(a, st); else strip_launch<4, 6, 7, 12>(a, st); }
+        else if (ntl == 4) strip_launch<4, 4>(a, st); else strip_launch<4, 3>(a, st);
         return true;
     }
     return false;

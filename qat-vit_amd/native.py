@@ -33,7 +33,7 @@ SIGNATURES = {
     "qatvit_gemm_nt_f16": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_nt_i8_minmax": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_w8_fragment_order": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
-    "qatvit_i8_strip": (c_int, [c_int32] + [c_void_p] * 4 + [c_int32] * 4 + [c_void_p] * 6 + [c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 4),
+    "qatvit_i8_strip": (c_int, [c_int32] + [c_void_p] * 4 + [c_int32] * 5 + [c_void_p] * 6 + [c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 4),
     "qatvit_gemm_nt_codes": (c_int, [c_void_p] * 4 + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_nt_i8": (c_int, [c_void_p] * 4 + [c_int32, c_void_p] + [c_int32] * 6 + [c_void_p] * 6),
     "qatvit_gemm_tn_scratch_bytes": (c_int64, []),

@@ -273,13 +273,15 @@ def _unpack_bits(mask_bytes, n):
 
 @pytest.mark.parametrize("per_channel", [0, 1])
 @pytest.mark.parametrize("qrange", [(0, 255), (0, 127)])
-@pytest.mark.parametrize("B,T,N", [(8, 197, 1152), (8, 197, 1536), (256, 197, 1536), (256, 197, 1152), (1, 209, 2304), (1, 40, 3072), (3, 65, 1152)])
-def test_i8_strip_kernel_equals_general_kernel(native_lib, B, T, N, per_channel, qrange):
-    """The A-stationary strip kernel of the two-pass K = 384 GEMMs (qkv, fc1: csrc/i8strip.hip) against qatvit_gemm_nt_i8 (general 208 x 384 tile, fp32
+@pytest.mark.parametrize("B,T,N,K", [(8, 197, 1152, 384), (8, 197, 1536, 384), (256, 197, 1536, 384), (256, 197, 1152, 384), (1, 209, 2304, 384), (1, 40, 3072, 384),
+                                     (3, 65, 1152, 384), (128, 197, 2304, 768), (128, 197, 3072, 768), (4, 197, 2304, 768), (1, 113, 3072, 768)])
+def test_i8_strip_kernel_equals_general_kernel(native_lib, B, T, N, K, per_channel, qrange):
+    """The A-stationary strip kernel of the two-pass K = 384 / 768 GEMMs (qkv, fc1 of ViT-S / ViT-B: csrc/i8strip.hip; 208-row strips x 3 or 4 column tiles per
+    workgroup, resp. 112-row strips x all 6 or 8) against qatvit_gemm_nt_i8 (general 208 x 384 tile, fp32
     output): the statistics pass returns the min / max of that tensor bit for bit; the code passes return, for every element, the code and the STE mask bit
     that fake-quantising that fp32 value with the given qparams yields - in the row-major layout (fc1, mode 4) and in the attention layout (qkv, mode 7).
     Integer rounding must be bit-exact: torch.equal throughout.  Ragged last strips (M % 208 != 0), one / several column-tile groups, both activation ranges."""
-    K, M = 384, B * T
+    M = B * T
     torch.manual_seed(M + N + per_channel + qrange[1])
     dev = "cuda"
     zp, center = 131, 128
@@ -308,7 +310,7 @@ def test_i8_strip_kernel_equals_general_kernel(native_lib, B, T, N, per_channel,
                                                bias.data_ptr(), st_gen.data_ptr(), _st()) == 0, native_lib.qatvit_last_error()
 
     def strip(mode, stats=None, qp=None, out8=None, mask=None, code_T=0, lut=None, lutq=None, sc=None):
-        assert native_lib.qatvit_i8_strip(mode, A8.data_ptr(), B8f.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), center, M, N, K, s1.data_ptr(), s2p, csp,
+        assert native_lib.qatvit_i8_strip(mode, A8.data_ptr(), B8f.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), center, M, N, K, K, s1.data_ptr(), s2p, csp,
                                           bias.data_ptr(), _ptr(stats), _ptr(qp), qrange[0], qrange[1], _ptr(out8), _ptr(mask), code_T, _ptr(lut), _ptr(lutq),
                                           _ptr(sc), _st()) == 0, native_lib.qatvit_last_error()
 

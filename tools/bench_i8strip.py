@@ -42,7 +42,7 @@ for N in (1152, 1536):
     code_mode = 7 if N == 1152 else 4
 
     def run(mode):
-        native.check(L.qatvit_i8_strip(mode, A8.data_ptr(), B8f.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), 128, M, N, K, s1.data_ptr(), s2.data_ptr(), None,
+        native.check(L.qatvit_i8_strip(mode, A8.data_ptr(), B8f.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), 128, M, N, K, K, s1.data_ptr(), s2.data_ptr(), None,
                                        bias.data_ptr(), stats.data_ptr() if mode == 3 else None, qp.data_ptr(), 0, 255, out8.data_ptr(), mask.data_ptr(), T,
                                        lut.data_ptr(), lutq.data_ptr(), sc.data_ptr(), st), "strip")
 

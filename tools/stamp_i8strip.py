@@ -37,7 +37,7 @@ names = {3: ["entry", "own DMA", "strip ready"] + [f"t{t} k-loop" for t in range
 for mode in (3, 7):
     for _ in range(5):   # warm
         dbg.zero_()
-        native.check(L.qatvit_i8_strip(mode, A8.data_ptr(), B8f.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), 128, M, N, K, s1.data_ptr(), s2.data_ptr(), None,
+        native.check(L.qatvit_i8_strip(mode, A8.data_ptr(), B8f.data_ptr(), wsum.data_ptr(), aqp.data_ptr(), 128, M, N, K, K, s1.data_ptr(), s2.data_ptr(), None,
                                        bias.data_ptr(), stats.data_ptr() if mode == 3 else None, qp.data_ptr(), 0, 255, out8.data_ptr(), mask.data_ptr(), T,
                                        None, None, None, st), "strip")
         torch.cuda.synchronize()
