@@ -1245,7 +1245,7 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 
 // fc2 forward from codes: A8 [M, lda] uint8 grid indices, lut[256] packed fp16 (hi | lo << 16) pairs, B16 [N, ldb] the weight integers as fp16
 int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st) {
+                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st, const NTPost* post) {
     if (M < 1 || N % 384 != 0 || K % 64 != 0 || lda % 16 != 0 || ldb % 8 != 0 || ldc % 4 != 0 || !A8 || !lut || !B16 || !C) {
         set_error("gemm_nt_codes: unsupported arguments M=%d N=%d K=%d lda=%d ldb=%d ldc=%d (need N%%384==0, K%%64==0, lda%%16==0)", M, N, K, lda, ldb, ldc);
         return 1;
@@ -1256,6 +1256,15 @@ int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, f
     a.s1 = s1; a.s2 = s2; a.col_scale = col_scale; a.bias = bias; a.stats = stats; a.stat_slots = stat_slots < 1 ? 1 : stat_slots;
     a.a_lut = lut;
     constexpr int kLds = 3 * (2 * 208 + 384) * 64 + 1024;   // 151 KiB
+    if (post) {   // inference: the residual update C[orow] = resid + fq(acc) in the epilogue (mode 6), frozen qparams
+        if (post->mode != 6 || !post->qp || !post->resid) { set_error("gemm_nt_codes: only the residual epilogue (mode 6: qp, resid) is available"); return 1; }
+        a.post_mode = a.pm = 6;
+        a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.resid = post->resid; a.embed_np = post->embed_np;
+        static bool once6 = (allow_lds(k_gemm_nt_ac<3, 6, kLds>, (size_t)kLds), true);
+        (void)once6;
+        k_gemm_nt_ac<3, 6, kLds><<<cdiv(M, 208) * (N / 384), 512, kLds, st>>>(a);
+        return 0;
+    }
     static bool once = (allow_lds(k_gemm_nt_ac<3, 0, kLds>, (size_t)kLds), true);
     (void)once;
     k_gemm_nt_ac<3, 0, kLds><<<cdiv(M, 208) * (N / 384), 512, kLds, st>>>(a);

@@ -45,7 +45,7 @@ int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 constexpr int kMaxIW = 64 * 4 + 8;
 struct IPlan {
-    int64_t qp, stats, wsum[kMaxIW], w16[kMaxIW], head_bf16;
+    int64_t qp, stats, wsum[kMaxIW], w16[kMaxIW], w8f[kMaxIW], head_bf16, qkvm, G8, Gm, glut;   // w8f: qkv weights in MFMA fragment order (the strip kernel's B operand); qkvm: its mask-bit output (unused here)
     int64_t xA, xB, h8, imgq8, codes, O16_hi, O16_lo, G16_hi, G16_lo, scal16, meanF, rstdF, hq, logits_pre, total;
 };
 int iplan(const qatvit_cfg& c, IPlan* p) {
@@ -60,12 +60,15 @@ int iplan(const qatvit_cfg& c, IPlan* p) {
         p->wsum[wi] = take((int64_t)N * 4);
         const int kind = (wi == 0 || wi == d.n_w - 1) ? -1 : (wi - 1) % 4;
         p->w16[wi] = (kind == 1 || kind == 3) ? take((int64_t)N * K * 2) : -1;
+        p->w8f[wi] = ((kind == 0 || kind == 2) && (K == 384 || K == 768) && N % 48 == 0) ? take((int64_t)N * K) : -1;
     }
     p->head_bf16 = take((int64_t)d.C * d.D * 2);
     p->xA = take(d.M * d.D * 4); p->xB = take(d.M * d.D * 4);
     p->h8 = take(d.M * d.D);
     p->imgq8 = take((int64_t)d.B * d.np * d.Kpe);
     p->codes = take(d.M * 3 * d.D);
+    p->qkvm = take(d.M * 3 * d.D / 8);
+    p->G8 = take(d.M * d.Hd); p->Gm = take(d.M * d.Hd / 8); p->glut = take(2 * 256 * 4);   // fc1 as codes + mask bits + the two 256-entry tables
     p->O16_hi = take(d.M * d.D * 2); p->O16_lo = take(d.M * d.D * 2);
     p->G16_hi = take(d.M * d.Hd * 2); p->G16_lo = take(d.M * d.Hd * 2);
     p->scal16 = take(8);
@@ -149,6 +152,7 @@ int qatvit_infer_prepare(const qatvit_cfg* cfg, const void* const* w8, const flo
         k_infer_wprep<<<N, 256, 0, st>>>(reinterpret_cast<const int8_t*>(w8[wi]), K, reinterpret_cast<int32_t*>(ws + p.wsum[wi]),
                                          p.w16[wi] >= 0 ? reinterpret_cast<_Float16*>(ws + p.w16[wi]) : nullptr,
                                          wi == d.n_w - 1 ? reinterpret_cast<__bf16*>(ws + p.head_bf16) : nullptr);
+        if (p.w8f[wi] >= 0 && launch_w8_fragment_order(w8[wi], ws + p.w8f[wi], N, K, st)) return 1;
     }
     QV_CHECK_LAUNCH("qatvit_infer_prepare");
     return 0;
@@ -200,9 +204,14 @@ int qatvit_infer_forward(const qatvit_cfg* cfg, void* const* params, const void*
         {
             NTPost post{};
             post.mode = 7; post.qp = qp(aidx(i, 1)); post.qmin = qa; post.qmax = qb; post.out8 = codes; post.code_T = d.T; post.code_hd = hd;
-            scal(widx(i, 0), &s2, &cs);
-            if (launch_gemm_nt_i8(h8, w8[widx(i, 0)], wsum(widx(i, 0)), qp(aidx(i, 0)), center, nullptr, M, 3 * d.D, d.D, d.D, d.D, 3 * d.D, qp(aidx(i, 0)), s2, cs,
-                                  bprm(i, 3), nullptr, 1, st, &post))
+            // (with the weight in fragment order and a place for the mask bits nobody reads here, the launcher takes the A-stationary strip kernel:
+            //  the same codes bit for bit - head_dim 64, K = 384 / 768; the general tile otherwise)
+            const int wq = widx(i, 0);
+            const void* b8f = (p.w8f[wq] >= 0 && hd == 64) ? ws + p.w8f[wq] : nullptr;
+            if (b8f) post.out8_mask = ws + p.qkvm;
+            scal(wq, &s2, &cs);
+            if (launch_gemm_nt_i8(h8, w8[wq], wsum(wq), qp(aidx(i, 0)), center, nullptr, M, 3 * d.D, d.D, d.D, d.D, 3 * d.D, qp(aidx(i, 0)), s2, cs,
+                                  bprm(i, 3), nullptr, 1, st, &post, b8f))
                 return 1;
         }
         // attention from the code plane -> fp16 pair; proj adds fq(.) into the residual stream
@@ -219,20 +228,28 @@ int qatvit_infer_forward(const qatvit_cfg* cfg, void* const* params, const void*
         // norm2 -> fc1 (one pass: quantise + GELU table + fp16 pair) -> fc2 adds fq(.) into the residual stream
         if (launch_ln_quant8(xB, bprm(i, 6), bprm(i, 7), c.ln_eps, qp(aidx(i, 3)), qa, qb, center, h8, nullptr, nullptr, d.M, 1, d.D, st)) return 1;
         {
+            // fc1 -> gelu(fq(.)) as one byte per element + a 256-entry table of fp16 pairs (strip kernel), fc2 expands them on its way into LDS and adds
+            // fq(.) into the residual stream: the training forward's kernels with frozen qparams.  Shapes the strip kernel does not take: fc1 on
+            // the general tile writing the fp16 pair, fc2 from the planes.
+            const int w1 = widx(i, 2), w2 = widx(i, 3);
+            const bool strip = p.w8f[w1] >= 0 && d.Hd % 128 == 0;
             NTPost post{};
-            post.mode = 4; post.qp = qp(aidx(i, 4)); post.qmin = qa; post.qmax = qb;
-            post.out16_hi = ws + p.G16_hi; post.out16_lo = ws + p.G16_lo; post.out16_scale = scal16 + 1;
-            scal(widx(i, 2), &s2, &cs);
-            if (launch_gemm_nt_i8(h8, w8[widx(i, 2)], wsum(widx(i, 2)), qp(aidx(i, 3)), center, nullptr, M, d.Hd, d.D, d.D, d.D, d.Hd, qp(aidx(i, 3)), s2, cs,
-                                  bprm(i, 9), nullptr, 1, st, &post))
+            post.mode = 4; post.qp = qp(aidx(i, 4)); post.qmin = qa; post.qmax = qb; post.out16_scale = scal16 + 1;
+            uint32_t* const glut = reinterpret_cast<uint32_t*>(ws + p.glut);
+            if (strip) { post.out8 = ws + p.G8; post.out8_mask = ws + p.Gm; post.lut_out = glut; post.lutq_out = glut + 256; }
+            else { post.out16_hi = ws + p.G16_hi; post.out16_lo = ws + p.G16_lo; }
+            scal(w1, &s2, &cs);
+            if (launch_gemm_nt_i8(h8, w8[w1], wsum(w1), qp(aidx(i, 3)), center, nullptr, M, d.Hd, d.D, d.D, d.D, d.Hd, qp(aidx(i, 3)), s2, cs,
+                                  bprm(i, 9), nullptr, 1, st, &post, strip ? ws + p.w8f[w1] : nullptr))
                 return 1;
-        }
-        {
-            NTPost post{};
-            post.mode = 6; post.qp = qp(aidx(i, 5)); post.qmin = qa; post.qmax = qb; post.resid = xB;
-            scal(widx(i, 3), &s2, &cs);
-            if (launch_gemm_nt(ws + p.G16_hi, ws + p.G16_lo, ws + p.w16[widx(i, 3)], xA, M, d.D, d.Hd, d.Hd, d.Hd, d.D, scal16 + 1, s2, cs, bprm(i, 11), nullptr, 1, st,
-                               nullptr, &post, true))
+            NTPost post2{};
+            post2.mode = 6; post2.qp = qp(aidx(i, 5)); post2.qmin = qa; post2.qmax = qb; post2.resid = xB;
+            scal(w2, &s2, &cs);
+            if (strip) {
+                if (launch_gemm_nt_codes(ws + p.G8, glut, ws + p.w16[w2], xA, M, d.D, d.Hd, d.Hd, d.Hd, d.D, scal16 + 1, s2, cs, bprm(i, 11), nullptr, 1, st, &post2))
+                    return 1;
+            } else if (launch_gemm_nt(ws + p.G16_hi, ws + p.G16_lo, ws + p.w16[w2], xA, M, d.D, d.Hd, d.Hd, d.Hd, d.D, scal16 + 1, s2, cs, bprm(i, 11), nullptr, 1, st,
+                                      nullptr, &post2, true))
                 return 1;
         }
     }

@@ -103,7 +103,7 @@ __host__ __device__ inline int64_t w8f_offset(int n, int k, int K) {
 int launch_w8_fragment_order(const void* B8, void* B8f, int N, int K, hipStream_t st);   // N % 48 == 0, K % 64 == 0
 // A operand = uint8 grid indices [M, lda] expanded through lut[256] (packed fp16 hi | lo << 16 pairs) inside the kernel; B16 = weight integers as fp16
 int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
-                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st);
+                         const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st, const NTPost* post = nullptr);
 // scratch that lets every wgrad shape take the two-phase (non-atomic, bit-reproducible) reduction: 256 workgroups x the largest tile
 constexpr int64_t kTnScratchBytes = 256ll * 128 * 384 * 4;
 int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
