@@ -295,14 +295,15 @@ int qatvit_teacher_forward_f16(const qatvit_cfg* cfg, void* const* params, void*
  * Integer inference forward of the trained student from its exported integers.
  * Replaces: the last-epoch  convert(base.eval()) ... evaluate_quantized_cpu(...)  of qat_trainer.py:376-388 (an eager int8 model for the CPU
  * backends only).  int8 MFMA for every grid x grid product; qparams are frozen, so each GEMM epilogue quantises at once: no pre-fake-quant fp32
- * tensor exists, qkv leaves its GEMM as uint8 codes, fc1 as the fp16 pair of gelu(fq(.)), proj / fc2 add fq(.) into the fp32 residual stream
+ * tensor exists, qkv leaves its GEMM as uint8 codes, fc1 as one byte per element + a 256-entry table of the fp16 pairs of gelu(fq(.)) (the fp16 pair
+ * itself where the strip kernel does not apply), proj / fc2 add fq(.) into the fp32 residual stream
  * (which the reference keeps in fp32 as well).  Logits are bit-identical to qatvit_student_forward with the observers switched off.
  *  cfg: as for the student step.  Shapes: embed_dim and mlp_hidden multiples of 384, head_dim 64 or 32.
  *  w8: n_weight_fq device pointers, int8 [N, K] row-major weight integers (q - zero_point; symmetric: zero_point 0), weight_fq order
  *      (patch_embed.proj as [D, C*P*P], per block qkv / proj / fc1 / fc2, head);  w_scale: same order, fp32 [1] or [N] (cfg->w_per_channel)
  *  act_scale / act_zero_point: device arrays [n_act_fq] in act_fq order (the frozen activation quantizers)
  *  params: the student's parameter table (fp32; the six 2-D weight slots are not read: may be NULL)
- * prepare() derives what the forward needs beside the integers (reciprocal scales, weight row sums, fp16 copies) into the head of the workspace -
+ * prepare() derives what the forward needs beside the integers (reciprocal scales, weight row sums, fp16 and fragment-order copies) into the head of the workspace -
  * once per set of weights; the same workspace then serves every batch size <= the one it was sized for. */
 int64_t qatvit_infer_workspace_bytes(const qatvit_cfg* cfg);
 int qatvit_infer_prepare(const qatvit_cfg* cfg, const void* const* w8, const float* act_scale, const int32_t* act_zero_point, void* workspace,
