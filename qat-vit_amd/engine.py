@@ -229,7 +229,7 @@ class StudentEngine:
         self._rehome_fq_state()
         self.capacity = 0
         self.workspace: Optional[torch.Tensor] = None
-        self.frozen = False                      # set by a captured hipGraph: the workspace address must not change under it
+        self._pins = 0                           # live captured hipGraphs: the workspace address must not change under them
         self._reserve(batch)
         # ---- flat gradient buffer, laid out in backward-stage order so that finished buckets are contiguous
         self.layout = FlatGradLayout([p.numel() for p in ps], self.cfg.depth)
@@ -248,6 +248,16 @@ class StudentEngine:
         if c is None:
             c = self._cfgs[batch] = native.Cfg(batch=batch, **self._cfg_kw)
         return c
+
+    @property
+    def frozen(self) -> bool:
+        return self._pins > 0
+
+    def pin(self) -> None:
+        self._pins += 1
+
+    def unpin(self) -> None:
+        self._pins = max(0, self._pins - 1)
 
     def _reserve(self, batch: int) -> None:
         """Make the workspace large enough for `batch` images.  Offsets inside it depend on the batch of the call, the

@@ -42,22 +42,24 @@ class GraphedStudentStep:
         for p in model.parameters():
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        eng.frozen = True                          # no re-allocation during capture ...
+        eng.pin()                                  # no re-allocation during capture ...
         try:
             with torch.cuda.graph(self.graph):
                 self.out, self.loss, self.parts = self._eager()
         except BaseException:
-            eng.frozen = False                     # ... a failed capture leaves the engine as it was
+            eng.unpin()                            # ... a failed capture leaves the engine as it was
             self.graph = None
+            self.engine = None
             raise
         self._grads = [p.grad for p in model.parameters()]   # from here on the pin lasts as long as this object (close() / __del__ release it)
 
     def close(self) -> None:
-        """Drops the graph and un-pins the engine's workspace (it may grow again for a larger batch)."""
+        """Drops the graph and releases THIS object's pin on the engine's workspace (idempotent).  The pin is a count on the engine: a
+        second live GraphedStudentStep of the same engine keeps the workspace where it is."""
         self.graph = None
-        if getattr(self, "engine", None) is not None:
-            self.engine.frozen = False
-            self.engine = None
+        eng, self.engine = getattr(self, "engine", None), None
+        if eng is not None:
+            eng.unpin()
 
     def __del__(self):
         try:

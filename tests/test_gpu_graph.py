@@ -59,3 +59,25 @@ def test_graphed_step_matches_eager(native_lib):
         assert b(torch.cat([xs[0], xs[1]])).shape == (8, 10)
     with pytest.raises(RuntimeError, match="closed"):
         step(xs[0], ys[0])
+
+
+def test_second_capture_keeps_the_workspace_pinned(native_lib):
+    """The pin is a count on the engine: re-capturing (`step = GraphedStudentStep(...)` builds the new object first, the old object's
+    __del__ runs afterwards) must not un-pin the workspace the live graph replays into."""
+    torch.manual_seed(0)
+    stu = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True, **TINY)
+    m = prepare(copy.deepcopy(stu).cuda(), "qnnpack")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 3, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 10, (4,), generator=g).cuda()
+    step = GraphedStudentStep(m, x, y, warmup=1)
+    eng = step.engine
+    step = GraphedStudentStep(m, x, y, warmup=1)      # the first object dies here, after the second one pinned the engine
+    assert eng.frozen and eng._pins == 1
+    with pytest.raises(RuntimeError, match="exceeds the workspace"):
+        m(torch.cat([x, x]))
+    step(x, y)                                        # the live graph still replays
+    step.close(); step.close()                        # idempotent
+    assert not eng.frozen
+    with torch.no_grad():
+        assert m(torch.cat([x, x])).shape == (8, 10)
