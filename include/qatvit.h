@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define QATVIT_ABI_VERSION 3
+#define QATVIT_ABI_VERSION 4
 
 int qatvit_abi_version(void);
 const char* qatvit_last_error(void);
@@ -176,6 +176,17 @@ int qatvit_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
                    const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias,
                    const float* row_div, float* scratch, int64_t scratch_bytes, void* stream);
 
+/* The one-plane forms of the two backward GEMMs (see QATVIT_BWD_DY16 below): the gradient operand is ONE fp16 plane = gradient * 2^e, *s2 = 2^-e.
+ * nt: C[M,N] = A16[M,K] . B16[N,K]^T * (*s1) * (*s2), B16 = the transposed weight integers as fp16; N % 384 == 0, K % 32 == 0.  (dgrad of nnqat.Linear)
+ * tn: C[N,Kw] += sum_m P16[m,N] * Q[m,Kw] * (*s1) * (*s2) / row_div[n] under the weight STE mask, dbias += sum_m P16 * (*s2) / row_div; Q = fp16 integers
+ *     (Q_lo NULL), an fp16 (hi, lo) pair, or - Qc / lutQ16 set, Q_hi / Q_lo NULL - uint8 codes + a table of fp16 (hi | lo << 16) pairs.  Shapes as qatvit_gemm_tn. */
+int qatvit_gemm_nt_dy16(const void* A16, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, const float* s1,
+                        const float* s2, void* stream);
+int qatvit_gemm_tn_dy16(const void* P16, const void* Q_hi, const void* Q_lo, const void* Qc, const uint32_t* lutQ16, float* C, int32_t M, int32_t N, int32_t Kw,
+                        int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* s2, const float* W, const float* w_scale, const int32_t* w_zp,
+                        int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes,
+                        void* stream);
+
 /* Attention core between attn.qkv and attn.proj (timm Attention; no fake-quant inside).
  *  qkv: PRE-fake-quant fp32 [B*T, 3*D]; qp: {scale, 1/scale, zero_point, enabled} of the qkv activation FQ
  *  (quantize-on-load).  O = O_hi + O_lo, bf16 [B*T, D] each; lse fp32 [B*H, qatvit_attn_padded_tokens(T)].
@@ -255,6 +266,22 @@ int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qa
  * copy of the gradient) before running the stages.  images may be NULL when stage_from > 0, logits when stage_to <= depth, dlogits when
  * stage_from > 0.  Replaces, per stage, the corresponding slice of `ddp_model(images)` / `loss.backward()` (qat_trainer.py:341,359). */
 #define QATVIT_STAGE_INJECT 1
+/* The one-plane backward (ABI 4).  The float operand of every backward GEMM of a block - the masked residual gradient entering mlp.fc2 and attn.proj, the
+ * gradients of the fc1 and qkv outputs - is written as ONE fp16 plane value * 2^e and consumed in one v_mfma_f32_16x16x32_f16 pass, instead of a bf16
+ * (hi, lo) pair (4 B per element, two passes).  e is chosen per tensor before the tensor exists, from the maximum that tensor had in the previous backward
+ * rescaled by max |dlogits| now / then; producers record this backward's maxima and raise an overflow flag (workspace word "dy16" + 2) when one did not
+ * fit below 65504.  Protocol (qat-vit_amd/engine.py): the first backward on a workspace runs with QATVIT_BWD_CALIBRATE (the pair form, recording maxima);
+ * later steps run the forward with QATVIT_FWD_X16 (the quantised LayerNorm outputs, X operand of the qkv / fc1 weight gradients, as fp16 integers) and the
+ * backward with QATVIT_BWD_DY16; a raised flag -> qatvit_student_dy16_to_pair + the same backward again with QATVIT_BWD_CALIBRATE into zeroed gradients:
+ * the step is then bit-identical to a pair-form step.  Error of the one-plane form against the pair form: 2^-12 per element, relative L2 1-2e-4 per stage
+ * (tests/test_gpu_stage_parity.py runs every stage table in both forms).  qatvit_student_backward (no flags) is always the pair form.
+ * Replaces: the same `loss.backward()` (qat_trainer.py:359). */
+#define QATVIT_FWD_X16 2        /* forward: h1q / h2q as fp16 integers (needs qatvit_student_dy16_supported) */
+#define QATVIT_BWD_DY16 2       /* backward: the one-plane form (the forward ran with QATVIT_FWD_X16, the workspace is calibrated) */
+#define QATVIT_BWD_CALIBRATE 4  /* backward: the pair form, recording the maxima the next one-plane backward scales by (the forward ran WITHOUT QATVIT_FWD_X16) */
+int32_t qatvit_student_dy16_supported(const qatvit_cfg* cfg);
+/* h1q / h2q of every block from fp16 integers back to bf16 integers, in place (fallback after an overflow: the pair form reads bf16) */
+int qatvit_student_dy16_to_pair(const qatvit_cfg* cfg, void* workspace, void* stream);
 int qatvit_student_forward_stages(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
                                   const float* images, float* logits, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags,
                                   void* stream);

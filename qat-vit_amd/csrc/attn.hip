@@ -284,6 +284,9 @@ struct AttnArgs {
     // kernels read 1.125 bytes per element instead of re-quantising the 4-byte pre-FQ tensor (3 x 232 MB per layer at batch 256).
     uint8_t* codes;
     uint8_t* cmask;
+    // the one-plane backward (k_attn_bwd_fused<NKT, true>): dqkv_hi is ONE fp16 plane of value * (*o16_mul), max |value| goes to o16_amax (dy16.hip)
+    const float* o16_mul;
+    uint32_t* o16_amax;
 };
 
 // stage one [T][HD] slice (q, k or v of head h) into an LDS image; `which`: 0 q, 1 k, 2 v
@@ -913,9 +916,11 @@ __device__ inline bf16x8 tr_frag_ds(const char* img, int tokA, int tokB, int col
     const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
-template <int NKT>
+template <int NKT, bool O16 = false>
 __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
     constexpr int HD = 64, NWV = 8;
+    float mul16 = 1.f, am16 = 0.f;
+    if constexpr (O16) mul16 = *p.o16_mul;
     constexpr int U = (NKT + NWV - 1) / NWV;   // key tiles per wave
     constexpr int IMG = NKT * 16 * HD * 2, SIMG = NKT * 16 * kSRow;
     constexpr int KK = HD / 32, ND = HD / 16;
@@ -1150,11 +1155,16 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
             const uint32_t mb = mqb >> (4 * (g & 1));
             const float gq[4] = {(mb & 1u) ? dq[0] * c * ckq.x : 0.f, (mb & 2u) ? dq[1] * c * ckq.y : 0.f, (mb & 4u) ? dq[2] * c * ckq.z : 0.f,
                                  (mb & 8u) ? dq[3] * c * ckq.w : 0.f};
-            uint2 gh, gl;
-            split_pair(gq[0], gq[1], gh.x, gl.x); split_pair(gq[2], gq[3], gh.y, gl.y);
             const int64_t offq = ((int64_t)b * T + qme) * ld + h * HD + 16 * jd + 4 * g;
-            *reinterpret_cast<uint2*>(p.dqkv_hi + offq) = gh;
-            *reinterpret_cast<uint2*>(p.dqkv_lo + offq) = gl;
+            if constexpr (O16) {
+                am16 = fmaxf(fmaxf(am16, fmaxf(fabsf(gq[0]), fabsf(gq[1]))), fmaxf(fabsf(gq[2]), fabsf(gq[3])));
+                *reinterpret_cast<uint2*>(p.dqkv_hi + offq) = make_uint2(pk_f16(gq[0] * mul16, gq[1] * mul16), pk_f16(gq[2] * mul16, gq[3] * mul16));
+            } else {
+                uint2 gh, gl;
+                split_pair(gq[0], gq[1], gh.x, gl.x); split_pair(gq[2], gq[3], gh.y, gl.y);
+                *reinterpret_cast<uint2*>(p.dqkv_hi + offq) = gh;
+                *reinterpret_cast<uint2*>(p.dqkv_lo + offq) = gl;
+            }
         }
     }
     // dK / dV: accumulators hold row = feature 16id + 4g + e, col = key 16j + r -> 8-B (4 x bf16) stores along d  (as k_attn_bwd_dkv)
@@ -1193,30 +1203,50 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
             const float vv[4] = {(bv & 1u) ? dv[u][id][0] * cv.x : 0.f, (bv & 2u) ? dv[u][id][1] * cv.y : 0.f,
                                  (bv & 4u) ? dv[u][id][2] * cv.z : 0.f, (bv & 8u) ? dv[u][id][3] * cv.w : 0.f};
             uint2 kh, kl, vh, vl;
-            split_pair(vk[0], vk[1], kh.x, kl.x); split_pair(vk[2], vk[3], kh.y, kl.y);
-            split_pair(vv[0], vv[1], vh.x, vl.x); split_pair(vv[2], vv[3], vh.y, vl.y);
             char* const e = sE + r * kERow + (16 * id + 4 * g) * 2;
-            *reinterpret_cast<uint2*>(e) = kh;
-            *reinterpret_cast<uint2*>(e + 16 * kERow) = kl;
-            *reinterpret_cast<uint2*>(e + 32 * kERow) = vh;
-            *reinterpret_cast<uint2*>(e + 48 * kERow) = vl;
+            if constexpr (O16) {   // (padded keys hold zero accumulators: P = 0 and dS = 0 for them)
+                am16 = fmaxf(fmaxf(am16, fmaxf(fmaxf(fabsf(vk[0]), fabsf(vk[1])), fmaxf(fabsf(vk[2]), fabsf(vk[3])))),
+                             fmaxf(fmaxf(fabsf(vv[0]), fabsf(vv[1])), fmaxf(fabsf(vv[2]), fabsf(vv[3]))));
+                kh = make_uint2(pk_f16(vk[0] * mul16, vk[1] * mul16), pk_f16(vk[2] * mul16, vk[3] * mul16));
+                vh = make_uint2(pk_f16(vv[0] * mul16, vv[1] * mul16), pk_f16(vv[2] * mul16, vv[3] * mul16));
+                *reinterpret_cast<uint2*>(e) = kh;
+                *reinterpret_cast<uint2*>(e + 32 * kERow) = vh;
+            } else {
+                split_pair(vk[0], vk[1], kh.x, kl.x); split_pair(vk[2], vk[3], kh.y, kl.y);
+                split_pair(vv[0], vv[1], vh.x, vl.x); split_pair(vv[2], vv[3], vh.y, vl.y);
+                *reinterpret_cast<uint2*>(e) = kh;
+                *reinterpret_cast<uint2*>(e + 16 * kERow) = kl;
+                *reinterpret_cast<uint2*>(e + 32 * kERow) = vh;
+                *reinterpret_cast<uint2*>(e + 48 * kERow) = vl;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-private: LDS is in order per wave, no barrier)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int key = 16 * jt[u] + 8 * half + erow;
             const char* const e = sE + (8 * half + erow) * kERow + ech * 16;
-            const uint4 kh = *reinterpret_cast<const uint4*>(e), kl = *reinterpret_cast<const uint4*>(e + 16 * kERow);
-            const uint4 vh = *reinterpret_cast<const uint4*>(e + 32 * kERow), vl = *reinterpret_cast<const uint4*>(e + 48 * kERow);
-            if (key < T) {
-                const int64_t offk = ((int64_t)b * T + key) * ld + D + h * HD + 8 * ech;
-                *reinterpret_cast<uint4*>(p.dqkv_hi + offk) = kh;
-                *reinterpret_cast<uint4*>(p.dqkv_lo + offk) = kl;
-                *reinterpret_cast<uint4*>(p.dqkv_hi + offk + D) = vh;
-                *reinterpret_cast<uint4*>(p.dqkv_lo + offk + D) = vl;
+            const uint4 kh = *reinterpret_cast<const uint4*>(e), vh = *reinterpret_cast<const uint4*>(e + 32 * kERow);
+            const int64_t offk = ((int64_t)b * T + key) * ld + D + h * HD + 8 * ech;
+            if constexpr (O16) {
+                if (key < T) {
+                    *reinterpret_cast<uint4*>(p.dqkv_hi + offk) = kh;
+                    *reinterpret_cast<uint4*>(p.dqkv_hi + offk + D) = vh;
+                }
+            } else {
+                const uint4 kl = *reinterpret_cast<const uint4*>(e + 16 * kERow), vl = *reinterpret_cast<const uint4*>(e + 48 * kERow);
+                if (key < T) {
+                    *reinterpret_cast<uint4*>(p.dqkv_hi + offk) = kh;
+                    *reinterpret_cast<uint4*>(p.dqkv_lo + offk) = kl;
+                    *reinterpret_cast<uint4*>(p.dqkv_hi + offk + D) = vh;
+                    *reinterpret_cast<uint4*>(p.dqkv_lo + offk + D) = vl;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is read before the next key tile overwrites it
+    }
+    if constexpr (O16) {
+        am16 = wave_max(am16);
+        if (lane == 0) atomicMax(p.o16_amax + (blockIdx.x & (kDyAmaxSlots - 1)) * kDyAmaxStride, __builtin_bit_cast(uint32_t, am16));
     }
 }
 
@@ -1275,26 +1305,35 @@ int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B
     return dispatch(0, a, st);
 }
 
+bool attn_bwd_is_fused(int T, int H, int D, bool codes) {
+    static const bool fused_on = !(getenv("QATVIT_ATTN_BWD_FUSED") && atoi(getenv("QATVIT_ATTN_BWD_FUSED")) == 0);
+    return fused_on && codes && H > 0 && D % H == 0 && D / H == 64 && T > 32 && T <= 224;
+}
+
 int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const void* O_hi, const void* O_lo,
                     const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st,
-                    const void* codes, const void* cmask) {
+                    const void* codes, const void* cmask, const float* o16_mul, uint32_t* o16_amax) {
     if ((codes != nullptr) != (cmask != nullptr)) { set_error("attention backward: codes / cmask go together"); return 1; }
     AttnArgs a{qkv, qp, qmin, qmax, B, T, H, D, 1.0f / sqrtf((float)(D / H)), reinterpret_cast<__bf16*>(const_cast<void*>(O_hi)),
                reinterpret_cast<__bf16*>(const_cast<void*>(O_lo)), const_cast<float*>(lse), delta, dO, reinterpret_cast<__bf16*>(dqkv_hi),
                reinterpret_cast<__bf16*>(dqkv_lo), col_scale, nullptr, nullptr, nullptr,
-               reinterpret_cast<uint8_t*>(const_cast<void*>(codes)), reinterpret_cast<uint8_t*>(const_cast<void*>(cmask))};
+               reinterpret_cast<uint8_t*>(const_cast<void*>(codes)), reinterpret_cast<uint8_t*>(const_cast<void*>(cmask)), o16_mul, o16_amax};
     // one fused kernel (dK, dV and dQ from one sweep) where its shape holds: head_dim 64, 33..224 tokens, saved codes; QATVIT_ATTN_BWD_FUSED=0: the
     // two-kernel form (k_attn_bwd_dq + k_attn_bwd_dkv) everything else takes
-    static const bool fused_on = !(getenv("QATVIT_ATTN_BWD_FUSED") && atoi(getenv("QATVIT_ATTN_BWD_FUSED")) == 0);
     int nkt;
     if (check_shape(T, D, H, &nkt)) return 1;
-    if (fused_on && codes && D / H == 64 && nkt == 14) {
+    if (attn_bwd_is_fused(T, H, D, codes != nullptr)) {
         constexpr int kLds = 4 * 14 * 16 * 64 * 2 + 2 * 14 * 16 * kSRow + 2 * 14 * 16 * 4 + 3 * 14 * 16 * 8;   // 157,696 B
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_fused<14>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_fused<14>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds),
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_fused<14, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
         (void)once;
-        k_attn_bwd_fused<14><<<B * H, 8 * 64, kLds, st>>>(a);
+        if (o16_mul) {
+            if (!o16_amax) { set_error("attention backward: o16_mul needs o16_amax"); return 1; }
+            k_attn_bwd_fused<14, true><<<B * H, 8 * 64, kLds, st>>>(a);
+        } else k_attn_bwd_fused<14><<<B * H, 8 * 64, kLds, st>>>(a);
         return 0;
     }
+    if (o16_mul) { set_error("attention backward: the one-plane output exists in the fused kernel only (head_dim 64, 33..224 tokens, saved codes)"); return 1; }
     if (dispatch(1, a, st)) return 1;
     return dispatch(2, a, st);
 }

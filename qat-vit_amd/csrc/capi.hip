@@ -165,6 +165,29 @@ int qatvit_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     return 0;
 }
 
+int qatvit_gemm_nt_dy16(const void* A16, const void* B16, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, const float* s1,
+                        const float* s2, void* stream) {
+    QV_CHECK_ARG(A16 && B16 && C, "qatvit_gemm_nt_dy16: null pointer argument");
+    if (launch_gemm_nt_dy16(A16, B16, C, M, N, K, lda, ldb, ldc, s1, s2, (hipStream_t)stream)) return 1;
+    QV_CHECK_LAUNCH("qatvit_gemm_nt_dy16");
+    return 0;
+}
+
+int qatvit_gemm_tn_dy16(const void* P16, const void* Q_hi, const void* Q_lo, const void* Qc, const uint32_t* lutQ16, float* C, int32_t M, int32_t N, int32_t Kw,
+                        int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* s2, const float* W, const float* w_scale, const int32_t* w_zp,
+                        int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes,
+                        void* stream) {
+    QV_CHECK_ARG(P16 && C && ((Q_hi && !Qc) || (Qc && lutQ16 && !Q_hi && !Q_lo)), "qatvit_gemm_tn_dy16: Q is either planes (Q_hi, optional Q_lo) or codes + table");
+    QV_CHECK_ARG(!W || (w_scale && w_zp), "qatvit_gemm_tn_dy16: weight mask needs w_scale and w_zp");
+    const int rc = Qc ? launch_gemm_tn_codes_dy16(P16, Qc, lutQ16, C, M, N, Kw, ldp, ldq, ldc, s1, s2, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div,
+                                                  (hipStream_t)stream, scratch, scratch_bytes)
+                      : launch_gemm_tn_dy16(P16, Q_hi, Q_lo, C, M, N, Kw, ldp, ldq, ldc, s1, s2, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div,
+                                            (hipStream_t)stream, scratch, scratch_bytes);
+    if (rc) return 1;
+    QV_CHECK_LAUNCH("qatvit_gemm_tn_dy16");
+    return 0;
+}
+
 int qatvit_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int32_t M, int32_t N, int32_t Kw, int32_t ldp,
                          int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel,
                          int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes, void* stream) {

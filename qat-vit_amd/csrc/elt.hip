@@ -42,6 +42,16 @@ __device__ inline void store_split4(__bf16* hi, __bf16* lo, int64_t off, float a
     *reinterpret_cast<uint2*>(lo + off) = l;
 }
 
+// the one-plane backward: four gradient elements -> one fp16 plane (value * mul), running max |value| in am
+__device__ inline void store_f16x4(__bf16* plane, int64_t off, float a, float b, float c, float d, float mul, float& am) {
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+    *reinterpret_cast<uint2*>(plane + off) = make_uint2(pk_f16(a * mul, b * mul), pk_f16(c * mul, d * mul));
+}
+__device__ inline void amax_publish(uint32_t* amax, float am, int lane) {   // one atomic per wave into the workgroup's sub-slot (dy16.hip)
+    am = wave_max(am);
+    if (lane == 0) atomicMax(amax + (blockIdx.x & (kDyAmaxSlots - 1)) * kDyAmaxStride, __builtin_bit_cast(uint32_t, am));
+}
+
 static inline int rows_grid(int64_t rows) {
     int64_t b = (rows + 3) / 4;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
 __global__ __launch_bounds__(256) void k_ln_apply_quant(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ qp,
                                                         int qmin, int qmax, __bf16* __restrict__ out, int64_t M, int D,
-                                                        int8_t* __restrict__ out8, int center) {
+                                                        int8_t* __restrict__ out8, int center, int out_f16) {
     // out = q - zp as bf16 (the exact operand of the weight-gradient GEMM); out8 (optional) = q - center as int8 (the operand of the
     // int8-MFMA forward GEMM)
     const QP q = load_qp(qp);
@@ -207,7 +217,9 @@ __global__ __launch_bounds__(256) void k_ln_apply_quant(const float* __restrict_
         o[1] = (__bf16)fqi((v.y - mu) * rs * g.y + b.y, q, qmin, qmax);
         o[2] = (__bf16)fqi((v.z - mu) * rs * g.z + b.z, q, qmin, qmax);
         o[3] = (__bf16)fqi((v.w - mu) * rs * g.w + b.w, q, qmin, qmax);
-        *reinterpret_cast<bf16x4*>(out + row * D + c) = o;
+        // out_f16 (uniform): the same integers as fp16 bit patterns - the X operand of the one-plane weight gradient (|q - zp| <= 255: exact either way)
+        if (out_f16) *reinterpret_cast<uint2*>(out + row * D + c) = make_uint2(pk_f16((float)o[0], (float)o[1]), pk_f16((float)o[2], (float)o[3]));
+        else *reinterpret_cast<bf16x4*>(out + row * D + c) = o;
         if (out8) {
             const float sh = q.zp - (float)center;
             char4 o8 = make_char4((signed char)((float)o[0] + sh), (signed char)((float)o[1] + sh), (signed char)((float)o[2] + sh),
@@ -331,11 +343,14 @@ __global__ __launch_bounds__(256) void k_fq_gelu(const float* __restrict__ Y, co
 // GELU_BWD=0: dY = d * mask(Y);  GELU_BWD=1: dY = d * gelu'(fq(Y)) * mask(Y); optionally * col_scale[col]
 // (per-channel weight scale of the consuming layer, folded here because dgrad's reduction runs over that axis).
 // Output: the (hi, lo) bf16 pair both the dgrad and the wgrad GEMM read.
-template <int GELU_BWD>
+template <int GELU_BWD, bool O16 = false>
 __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ d, const float* __restrict__ Y, const float* __restrict__ qp,
                                                   int qmin, int qmax, const float* __restrict__ col_scale, int ncols4,
-                                                  __bf16* __restrict__ dst_hi, __bf16* __restrict__ dst_lo, int64_t n4) {
+                                                  __bf16* __restrict__ dst_hi, __bf16* __restrict__ dst_lo, int64_t n4,
+                                                  const float* __restrict__ o16_mul, uint32_t* __restrict__ o16_amax) {
     const QP q = load_qp(qp);
+    float mul = 1.f, am = 0.f;
+    if constexpr (O16) mul = *o16_mul;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(Y)[i];
         const float4 g = reinterpret_cast<const float4*>(d)[i];
@@ -352,8 +367,10 @@ __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ d, c
             const float f = fqv(in4[e], q, qmin, qmax, in);
             o[e] = in ? (GELU_BWD ? g4[e] * dgelu(f) : g4[e]) * cs[e] : 0.f;
         }
-        store_split4(dst_hi, dst_lo, i * 4, o[0], o[1], o[2], o[3]);
+        if constexpr (O16) store_f16x4(dst_hi, i * 4, o[0], o[1], o[2], o[3], mul, am);
+        else store_split4(dst_hi, dst_lo, i * 4, o[0], o[1], o[2], o[3]);
     }
+    if constexpr (O16) amax_publish(o16_amax, am, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------- LayerNorm backward with the aFQ mask of its output
@@ -364,16 +381,20 @@ __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ d, c
 // time as the (hi, lo) bf16 pair that branch's dgrad / wgrad GEMMs read, multiplied by that output's STE mask (the ballot words
 // k_resid_fq_lnstats wrote in the forward) and the optional per-channel weight scale: what k_mask_bwd<0> would compute from a second
 // read of dx_out and of the fp32 pre-FQ tensor.
-template <int ACC, int NV, int WPB = 8, bool FUSE = false>   // WPB waves per block: column sums meet in LDS, so more waves per block = same atomics, more rows in flight
+template <int ACC, int NV, int WPB = 8, bool FUSE = false, bool O16 = false>   // WPB waves per block: column sums meet in LDS, so more waves per block = same atomics, more rows in flight
 __global__ __launch_bounds__(WPB * 64) void k_ln_bwd_fq(const float* __restrict__ dH, int64_t dH_row_stride_rows, const float* __restrict__ x,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ qp, int qmin, int qmax,
                                                    const float* __restrict__ dx_in, float* __restrict__ dx_out, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, int64_t M, int D, int T, int cls_only,
                                                    const unsigned long long* __restrict__ nmask, const float* __restrict__ ncs,
-                                                   __bf16* __restrict__ nhi, __bf16* __restrict__ nlo) {
+                                                   __bf16* __restrict__ nhi, __bf16* __restrict__ nlo, const float* __restrict__ o16_mul,
+                                                   uint32_t* __restrict__ o16_amax) {
+    static_assert(!O16 || FUSE, "the one-plane output is the fused next-branch gradient");
     const QP q = load_qp(qp);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float mul16 = 1.f, am16 = 0.f;
+    if constexpr (O16) mul16 = *o16_mul;
     unsigned long long mk[NV][4];   // this row's mask words (wave-uniform: scalar loads, requested at the top of the row)
     bool act[NV];
     int cc[NV];
@@ -390,8 +411,10 @@ __global__ __launch_bounds__(WPB * 64) void k_ln_bwd_fq(const float* __restrict_
     auto fuse_store = [&](int64_t row, int j, int c, const float4& o) {
         const unsigned long long m0 = mk[j][0], m1 = mk[j][1], m2 = mk[j][2], m3 = mk[j][3];
         const float4 cs = csn[j];
-        store_split4(nhi, nlo, row * D + c, (m0 >> lane) & 1 ? o.x * cs.x : 0.f, (m1 >> lane) & 1 ? o.y * cs.y : 0.f,
-                     (m2 >> lane) & 1 ? o.z * cs.z : 0.f, (m3 >> lane) & 1 ? o.w * cs.w : 0.f);
+        const float f0 = (m0 >> lane) & 1 ? o.x * cs.x : 0.f, f1 = (m1 >> lane) & 1 ? o.y * cs.y : 0.f, f2 = (m2 >> lane) & 1 ? o.z * cs.z : 0.f,
+                    f3 = (m3 >> lane) & 1 ? o.w * cs.w : 0.f;
+        if constexpr (O16) store_f16x4(nhi, row * D + c, f0, f1, f2, f3, mul16, am16);
+        else store_split4(nhi, nlo, row * D + c, f0, f1, f2, f3);
     };
     constexpr int nv = NV;
     float4 ag[NV], ab[NV];
@@ -467,6 +490,7 @@ __global__ __launch_bounds__(WPB * 64) void k_ln_bwd_fq(const float* __restrict_
             }
         }
     }
+    if constexpr (O16) amax_publish(o16_amax, am16, lane);
     // column sums: the block's waves through LDS, one atomic per column per block
     __shared__ float sg[WPB][256 * NV + 8], sb[WPB][256 * NV + 8];
 #pragma unroll
@@ -628,7 +652,7 @@ __global__ __launch_bounds__(64) void k_embed_bwd(const float* __restrict__ dx0,
 __device__ inline void wquant_body(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
                                    __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K, int bx, int by,
                                    int8_t* __restrict__ w8 = nullptr, int32_t* __restrict__ wsum = nullptr, _Float16* __restrict__ w16 = nullptr,
-                                   int8_t* __restrict__ w8f = nullptr) {
+                                   int8_t* __restrict__ w8f = nullptr, int64_t wT16_gap = 0) {   // wT16_gap: byte distance from wqT to its fp16 twin (0: none)
     // 32x32 tile transpose through LDS
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -655,10 +679,14 @@ __device__ inline void wquant_body(const float* __restrict__ W, const float* __r
         atomicAdd(&wsum[n0 + threadIdx.x], (int)sacc);
     }
     if (wqT) {
+        _Float16* const wT16 = wT16_gap ? reinterpret_cast<_Float16*>(reinterpret_cast<char*>(wqT) + wT16_gap) : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + ty + 8 * i, n = n0 + tx;
-            if (n < N && k < K) wqT[(int64_t)k * N + n] = (__bf16)tile[tx][ty + 8 * i];
+            if (n < N && k < K) {
+                wqT[(int64_t)k * N + n] = (__bf16)tile[tx][ty + 8 * i];
+                if (wT16) wT16[(int64_t)k * N + n] = (_Float16)tile[tx][ty + 8 * i];   // the transposed integers as fp16: the one-plane dgrad's B operand
+            }
         }
     }
 }
@@ -672,7 +700,7 @@ __global__ __launch_bounds__(256) void k_w_quant_all(const WQuantTab t) {
     const int b = blockIdx.x - t.blk0[wi], kt = (t.K[wi] + 31) / 32;
     wquant_body(t.W[wi], t.qp[wi], t.per_channel, t.qmin, t.qmax, reinterpret_cast<__bf16*>(t.wq[wi]), reinterpret_cast<__bf16*>(t.wqT[wi]), t.N[wi],
                 t.K[wi], b % kt, b / kt, reinterpret_cast<int8_t*>(t.w8[wi]), t.wsum[wi], reinterpret_cast<_Float16*>(t.w16[wi]),
-                reinterpret_cast<int8_t*>(t.w8f[wi]));
+                reinterpret_cast<int8_t*>(t.w8f[wi]), t.wT16 ? wT16_gap_bytes(t.N[wi], t.K[wi]) : 0);
 }
 static_assert(sizeof(WQuantTab) <= 4096, "WQuantTab travels as a kernel argument");
 // row-major int8 [N, K] -> fragment order (kernel-level tests / callers that hold a row-major weight)
@@ -712,9 +740,9 @@ int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const
 }
 
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
-                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8, int center) {
+                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8, int center, bool out_f16) {
     k_ln_apply_quant<<<flat_grid(M * (D / 4)), 256, 0, st>>>(x, mean, rstd, gamma, beta, qp, qmin, qmax, reinterpret_cast<__bf16*>(out_bf16), M, D,
-                                                             reinterpret_cast<int8_t*>(out8), center);
+                                                             reinterpret_cast<int8_t*>(out8), center, out_f16 ? 1 : 0);
     return 0;
 }
 
@@ -739,11 +767,16 @@ int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, void* G_
 }
 
 int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, const float* col_scale, int ncols,
-                    void* dst_hi, void* dst_lo, int64_t n, hipStream_t st) {
+                    void* dst_hi, void* dst_lo, int64_t n, hipStream_t st, const float* o16_mul, uint32_t* o16_amax) {
     __bf16* h = reinterpret_cast<__bf16*>(dst_hi);
     __bf16* l = reinterpret_cast<__bf16*>(dst_lo);
-    if (gelu_bwd) k_mask_bwd<1><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, col_scale, ncols / 4, h, l, n / 4);
-    else k_mask_bwd<0><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, col_scale, ncols / 4, h, l, n / 4);
+    if (o16_mul) {   // the one-plane form (dst_hi = the fp16 plane)
+        if (gelu_bwd || !o16_amax) { set_error("mask_bwd: the one-plane form covers the plain mask with o16_amax"); return 1; }
+        k_mask_bwd<0, true><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, col_scale, ncols / 4, h, l, n / 4, o16_mul, o16_amax);
+        return 0;
+    }
+    if (gelu_bwd) k_mask_bwd<1><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, col_scale, ncols / 4, h, l, n / 4, nullptr, nullptr);
+    else k_mask_bwd<0><<<flat_grid(n / 4), 256, 0, st>>>(d, Y, qp, qmin, qmax, col_scale, ncols / 4, h, l, n / 4, nullptr, nullptr);
     return 0;
 }
 
@@ -759,10 +792,14 @@ int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean
     const float* ncs = next ? next->colscale : nullptr;
     __bf16* nh = next ? reinterpret_cast<__bf16*>(next->out_hi) : nullptr;
     __bf16* nl = next ? reinterpret_cast<__bf16*>(next->out_lo) : nullptr;
+    const float* m16 = next ? next->o16_mul : nullptr;
+    uint32_t* a16 = next ? next->o16_amax : nullptr;
+    if (m16 && !a16) { set_error("ln_bwd_fq: o16_mul needs o16_amax"); return 1; }
 #define QV_LNB(ACC_, NV_)                                                                                                                          \
     do {                                                                                                                                           \
-        if (next) k_ln_bwd_fq<ACC_, NV_, 8, true><<<grid, 512, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only, nm, ncs, nh, nl); \
-        else k_ln_bwd_fq<ACC_, NV_, 8, false><<<grid, 512, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only, nm, ncs, nh, nl); \
+        if (next && m16) k_ln_bwd_fq<ACC_, NV_, 8, true, true><<<grid, 512, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only, nm, ncs, nh, nl, m16, a16); \
+        else if (next) k_ln_bwd_fq<ACC_, NV_, 8, true><<<grid, 512, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only, nm, ncs, nh, nl, nullptr, nullptr); \
+        else k_ln_bwd_fq<ACC_, NV_, 8, false><<<grid, 512, 0, st>>>(dH, 0, x, mean, rstd, gamma, beta, qp, qmin, qmax, dx_in, dx_out, dgamma, dbeta, M, D, T, cls_only, nm, ncs, nh, nl, nullptr, nullptr); \
     } while (0)
     const int nv = (D + 255) / 256;
     if (acc) { if (nv == 1) QV_LNB(1, 1); else if (nv == 2) QV_LNB(1, 2); else QV_LNB(1, 3); }

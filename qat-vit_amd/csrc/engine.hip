@@ -73,11 +73,13 @@ struct Plan {
     int64_t w_off[64 * 4 + 8], wT_off[64 * 4 + 8], w_stats[64 * 4 + 8], w_qp[64 * 4 + 8];
     int64_t w8_off[64 * 4 + 8], wsum_off[64 * 4 + 8], wsum_base, wsum_bytes, imgq8, h1q8, h2q8;   // int8 operands of the forward grid x grid GEMMs
     int64_t w8f_off[64 * 4 + 8];   // the int8 weight once more in fragment order (qkv, fc1 with K == 384 / 768: the strip kernel's B operand), -1 otherwise
-    int64_t w16_off[64 * 4 + 8], O16_hi, O16_lo, G16_hi, G16_lo, scal16;   // fp16 operands of the forward float x grid GEMMs (proj, fc2): shared by all blocks
+    int64_t w16_off[64 * 4 + 8], O16_hi, O16_lo, G16_hi, G16_lo, scal16;   // fp16 operands of the forward float x grid GEMMs (proj, fc2): O16 / scal16 per block, G16 shared
     int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo, tn_scratch;
+    int64_t dy16;   // scale state of the one-plane backward (dy16.hip): 4 slots per block - the gradients entering fc2, fc1, proj, qkv
     int64_t total, stats_words;
     int TP;
 };
+enum { DS_FC2 = 0, DS_FC1, DS_PROJ, DS_QKV, DS_COUNT };
 
 static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -99,6 +101,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     }
     p->stats_words = (int64_t)d.n_act * kStatSlots * kStatStride + wstat_words;
     p->stats = take(p->stats_words * 4);
+    p->dy16 = take(dy16_state_bytes(DS_COUNT * d.depth));   // (next to the observer accumulators: its place does not depend on the batch either)
     p->qp_act = take((int64_t)d.n_act * 4 * 4);
     p->qp_w = take(wqp_floats * 4);
     p->imgq = take((int64_t)d.B * d.np * d.Kpe * 2);
@@ -123,6 +126,9 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->h1q8 = take(M * D); p->h2q8 = take(M * D);
     p->mproj = take(ln_maskbits_bytes(M, (int)D)); p->m2 = take(ln_maskbits_bytes(M, (int)D));
     p->qkv8 = take(M * 3 * D); p->qkvm = take(M * 3 * D / 8);   // the quantised qkv as the attention forward saw it (codes + STE mask bits), for its backward
+    // the attention output once more as an fp16 (hi, lo) pair (proj's forward operand and, in the one-plane backward, its weight gradient's X operand) and the
+    // two pair scales {attention output, gelu} the producers write: per block since round 4 (the backward reads them)
+    p->O16_hi = take(M * D * 2); p->O16_lo = take(M * D * 2); p->scal16 = take(2 * sizeof(float));
     p->G8 = take(M * Hd); p->glut = take(256 * 4); p->Y1m = take(M * Hd / 8); p->glutq = take(256 * 4);   // (Y1m: the STE mask bits of fc1's fake-quant)   // gelu(fq(fc1 output)) as one byte per element + the 256-entry table of fp16 pairs (fc2 forward from codes)
     p->blk_stride = o - b0;
     o = b0 + p->blk_stride * d.depth;
@@ -133,16 +139,14 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
         int N, K; wshape(d, wi, &N, &K);
         p->w_off[wi] = take((int64_t)N * K * 2);
         p->wT_off[wi] = take((int64_t)N * K * 2);
+        (void)take((int64_t)N * K * 2);   // the same transposed integers as fp16, wT16_gap_bytes(N, K) behind (the one-plane dgrad's B operand)
         p->w8_off[wi] = take((int64_t)N * K);
         const int kind = (wi == 0 || wi == d.n_w - 1) ? -1 : (wi - 1) % WB_COUNT;
         p->w16_off[wi] = (kind == WB_PROJ || kind == WB_FC2) ? take((int64_t)N * K * 2) : -1;
         p->w8f_off[wi] = ((kind == WB_QKV || kind == WB_FC1) && (K == 384 || K == 768) && N % 48 == 0) ? take((int64_t)N * K) : -1;
     }
-    // the float A operands of the two forward GEMMs with a float operand, as fp16 (hi, lo) pairs: written and consumed inside one block's
-    // forward, so ONE set serves every block (the bf16 pairs next to them stay per block: the weight-gradient GEMMs read them in the backward)
-    p->O16_hi = take(M * D * 2); p->O16_lo = take(M * D * 2);
+    // gelu(fq(fc1)) as an fp16 (hi, lo) pair (QATVIT_FC2_CODES=0 only): written and consumed inside one block's forward, ONE set serves every block
     p->G16_hi = take(M * Hd * 2); p->G16_lo = take(M * Hd * 2);
-    p->scal16 = take(2 * sizeof(float));   // {attention-output pair scale, gelu pair scale}: device scalars the producers write
     p->imgq8 = take((int64_t)d.B * d.np * d.Kpe);
     p->wsum_base = o;
     for (int wi = 0; wi < d.n_w; ++wi) {
@@ -294,6 +298,12 @@ struct Ctx {
     const qatvit_fq* wfq;
     hipStream_t st;
     std::shared_ptr<Prof> prof;
+    int flags = 0;   // QATVIT_FWD_X16 (forward) / QATVIT_BWD_DY16, QATVIT_BWD_CALIBRATE (backward)
+    // ---- the one-plane backward (dy16.hip): slot k (DS_*) of block i
+    uint32_t* dy_slot(int i, int k) const { return at<uint32_t>(p.dy16) + kDyHdrWords + (int64_t)(DS_COUNT * i + k) * kDySlotWords; }
+    const float* dy_mul(int i, int k) const { return reinterpret_cast<const float*>(dy_slot(i, k) + 1); }
+    const float* dy_inv(int i, int k) const { return reinterpret_cast<const float*>(dy_slot(i, k) + 2); }
+    void* wT16(int wi) const { int N, K; wshape(d, wi, &N, &K); return ws + p.wT_off[wi] + wT16_gap_bytes(N, K); }
     template <typename T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
     template <typename T> T* blk(int64_t off, int i) const { return reinterpret_cast<T*>(ws + off + p.blk_stride * i); }
     const float* prm(int i) const { return reinterpret_cast<const float*>(params[i]); }
@@ -440,7 +450,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         float* xmid = x.blk<float>(p.x_mid, i);
         if (parts & 1) {   // ---- part 0: norm1 -> qkv   (every quantizer's observer / qparams update runs behind the producer of its statistics)
         launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
-                              qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h1q8, i) : nullptr, x.center());
+                              qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h1q8, i) : nullptr, x.center(), (x.flags & QATVIT_FWD_X16) != 0);
         if (qkv_2pass(c)) {
             const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
             if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
@@ -459,16 +469,16 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         const bool proj16 = x.f16_ok(x.widx(i, WB_PROJ)), fc2_16 = x.f16_ok(x.widx(i, WB_FC2)) && fc1_recompute();
         const bool fc2_c = fc2_16 && fc2_codes() && d.Hd % 64 == 0 && c.act_qmax - c.act_qmin <= 255;
         const bool fc1_b = fc2_c && fc1_code_bits(x, i);   // the backward reads the byte plane + mask bits: no uint16 plane is written
-        float* const scal16 = x.at<float>(p.scal16);
+        float* const scal16 = x.blk<float>(p.scal16, i);
         if (parts & 2) {   // ---- part 1: attention -> proj -> residual (+ statistics of norm2)
         const bool from_codes = qkv_2pass(c) && !qkv_injected;   // part 0 left the code plane (and ran the observer); an injected fp32 qkv takes the one-pass route
         if (launch_attn_fwd(from_codes ? nullptr : x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
-                            x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), st, proj16 ? x.at<void>(p.O16_hi) : nullptr,
-                            proj16 ? x.at<void>(p.O16_lo) : nullptr, proj16 ? scal16 : nullptr, attn_codes(x.c) ? x.blk<void>(p.qkv8, i) : nullptr,
+                            x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i), st, proj16 ? x.blk<void>(p.O16_hi, i) : nullptr,
+                            proj16 ? x.blk<void>(p.O16_lo, i) : nullptr, proj16 ? scal16 : nullptr, attn_codes(x.c) ? x.blk<void>(p.qkv8, i) : nullptr,
                             attn_codes(x.c) ? x.blk<void>(p.qkvm, i) : nullptr))
             return 1;
         if (proj16) {
-            if (x.linear_fwd_f16(x.at<void>(p.O16_hi), x.at<void>(p.O16_lo), scal16, M, x.widx(i, WB_PROJ), x.bprm(i, B_PROJB), x.blk<float>(p.Yproj, i),
+            if (x.linear_fwd_f16(x.blk<void>(p.O16_hi, i), x.blk<void>(p.O16_lo, i), scal16, M, x.widx(i, WB_PROJ), x.bprm(i, B_PROJB), x.blk<float>(p.Yproj, i),
                                  x.aidx(i, AB_PROJ)))
                 return 1;
         } else if (x.linear_fwd(x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), M, x.widx(i, WB_PROJ), nullptr, x.bprm(i, B_PROJB),
@@ -481,7 +491,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         if (parts & 4) {   // ---- part 2: norm2 -> fc1 (both passes) -> GELU
         launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
                               x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h2q8, i) : nullptr,
-                              x.center());
+                              x.center(), (x.flags & QATVIT_FWD_X16) != 0);
         if (fc1_recompute()) {
             // fc1 is a K = D GEMM whose [M, 4D] fp32 output would be written once and read twice: run it TWICE instead.  Pass 1 only
             // feeds the observer (min/max, nothing stored); pass 2 - the same kernel on the same operands, so the same bits - quantises
@@ -589,6 +599,7 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
         WQpTab tq{};
         WQuantTab tw{};
         to.n = tq.n = tw.n = d.n_w;
+        tw.wT16 = 1;
         to.per_channel = tq.per_channel = tw.per_channel = c.w_per_channel;
         to.nslots = tq.nslots = kStatSlots;
         tq.qmin = tw.qmin = c.w_qmin; tq.qmax = tw.qmax = c.w_qmax; tq.c = c.averaging_const;
@@ -650,10 +661,22 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
     return 0;
 }
 
+// Can this configuration run the one-plane backward?  It needs the forms every one-plane kernel was written for: the 208 x 384 tiles, the fused
+// attention backward (head_dim 64, 33..224 tokens, saved codes), fc1's codes + mask bits, the fused next-branch output of the LayerNorm backward.
+static bool dy16_supported(const Ctx& x) {
+    const Dims& d = x.d;
+    static const bool ln_fuse = !(getenv("QATVIT_LN_FUSE") && atoi(getenv("QATVIT_LN_FUSE")) == 0);
+    return ln_fuse && use_i8() && w_batched(d) && d.D % 384 == 0 && d.Hd % 384 == 0 && qkv_2pass(x.c) && attn_bwd_is_fused(d.T, d.H, d.D, attn_codes(x.c)) &&
+           x.f16_ok(x.widx(0, WB_PROJ)) && fc1_code_bits(x, 0) && fc2w_code_form(x, 0);
+}
+
 // stages: 0 = head + final norm; 1..depth = blocks depth-1..0; depth+1 = embedding
 // `inject`: the gradient entering stage_from (dxA = d loss / d x_in[depth - stage_from + 1] for a block stage, / d x_in[0] for the embedding
 // stage) was written by the caller; a block stage then rebuilds the masked (hi, lo) copy of it that the previous stage's fused
 // LayerNorm backward would have left for the fc2 weight / data gradient GEMMs.
+// x.flags & QATVIT_BWD_DY16: the one-plane form - every gradient that feeds a dgrad / wgrad pair (the masked residual gradient entering fc2 and proj,
+// the fc1 and qkv output gradients) is ONE fp16 plane scaled by a power of two chosen from the previous backward's maxima (dy16.hip) instead of a bf16
+// (hi, lo) pair: one MFMA pass and 2 B per element in eight GEMMs per block.  QATVIT_BWD_CALIBRATE: the pair form, recording those maxima.
 static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage_from, int stage_to, bool inject) {
     const Dims& d = x.d;
     const Plan& p = x.p;
@@ -673,6 +696,14 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
     static const bool ln_fuse = !(getenv("QATVIT_LN_FUSE") && atoi(getenv("QATVIT_LN_FUSE")) == 0);
     void* const dYh_all = x.at<void>(p.dYs_hi);
     void* const dYl_all = x.at<void>(p.dYs_lo);
+    const bool dy = (x.flags & QATVIT_BWD_DY16) != 0, cal = (x.flags & QATVIT_BWD_CALIBRATE) != 0;
+    if (dy && cal) { set_error("student backward: QATVIT_BWD_DY16 and QATVIT_BWD_CALIBRATE exclude each other"); return 1; }
+    if ((dy || cal) && !dy16_supported(x)) { set_error("student backward: the one-plane form does not cover this configuration (qatvit_student_dy16_supported)"); return 1; }
+    uint32_t* const dystate = x.at<uint32_t>(p.dy16);
+    const int nslots = DS_COUNT * d.depth;
+    if ((dy || cal) && (stage_from == 0 || inject)) launch_dy16_begin(dystate, nslots, stage_from == 0 ? dlogits : nullptr, d.B * d.C, st);
+    // calibration: the maximum of a tensor the pair form just wrote (its hi plane) into the tensor's slot
+    auto calib = [&](const void* hi, int64_t n, int blk_i, int k) { if (cal && blk_i >= 0) launch_absmax_bf16(hi, n, x.dy_slot(blk_i, k), st); };
     for (int s = stage_from; s <= stage_to; ++s) {
         if (s == 0) {
             const int base = P_BLOCK0 + B_COUNT * d.depth;
@@ -680,18 +711,108 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             launch_head_bwd(dlogits, x.at<float>(p.logits_pre), x.act_qp(x.a_head()), qa, qb, x.at<float>(p.hq), x.act_qp(x.a_norm()),
                             x.at<void>(p.w_off[wh]), x.prm(base + 2), x.wfq[wh].scale, x.wfq[wh].zero_point, c.w_per_channel, c.w_qmin, c.w_qmax,
                             G(base + 2), G(base + 3), x.at<float>(p.dh), d.B, d.D, d.C, st);
-            const LnBwdNext nx{x.blk<void>(p.m2, d.depth - 1), x.dy_colscale(x.widx(d.depth - 1, WB_FC2)), dYh_all, dYl_all};
+            LnBwdNext nx{x.blk<void>(p.m2, d.depth - 1), x.dy_colscale(x.widx(d.depth - 1, WB_FC2)), dYh_all, dYl_all};
+            if (dy) { nx.o16_mul = x.dy_mul(d.depth - 1, DS_FC2); nx.o16_amax = x.dy_slot(d.depth - 1, DS_FC2); }
             if (launch_ln_bwd_fq(0, x.at<float>(p.dh), x.blk<float>(p.x_in, d.depth), x.at<float>(p.meanF), x.at<float>(p.rstdF), x.prm(base),
                                  x.prm(base + 1), x.act_qp(x.a_norm()), qa, qb, nullptr, dxA, G(base), G(base + 1), d.M, d.D, d.T, 1, st,
                                  ln_fuse ? &nx : nullptr))
                 return 1;
+            calib(dYh_all, d.M * d.D, d.depth - 1, DS_FC2);
+        } else if (s <= d.depth && dy) {
+            // ---- one block, one-plane form.  Same dataflow as the pair form below; every dY is one fp16 plane in the hi buffer of the pair.
+            const int i = d.depth - s;
+            void* dY16 = x.at<void>(p.dYs_hi);
+            void* dY1_16 = x.at<void>(p.dY1_hi);
+            void* dqkv16 = x.at<void>(p.dqkv_hi);
+            const int w_fc2 = x.widx(i, WB_FC2), w_fc1 = x.widx(i, WB_FC1), w_proj = x.widx(i, WB_PROJ), w_qkv = x.widx(i, WB_QKV);
+            float* const scal16 = x.blk<float>(p.scal16, i);
+            auto wscale1 = [&](int wi) { return c.w_per_channel ? nullptr : x.wfq[wi].scale; };
+            // wgrad of layer wi from the plane P16 (slot k): X as fp16 integers (X_lo == nullptr), an fp16 pair, or codes + a table of fp16 pairs
+            auto wgrad16 = [&](const void* P16, int k, int wi, const void* X_hi, const void* X_lo, const void* Xc, const uint32_t* lut, const float* s_x, float* dW,
+                               float* db) -> int {
+                int N, K; wshape(d, wi, &N, &K);
+                const qatvit_fq& f = x.wfq[wi];
+                ProfScope ps(x.prof, (wi == w_proj || Xc) ? 6 : 3, 2.0 * M * N * K, st);
+                const float* rdiv = c.w_per_channel ? f.scale : nullptr;
+                if (Xc)
+                    return launch_gemm_tn_codes_dy16(P16, Xc, lut, dW, M, N, K, N, K, K, s_x, x.dy_inv(i, k), x.prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
+                                                     c.w_qmin, c.w_qmax, db, rdiv, st, x.at<float>(p.tn_scratch), kTnScratchBytes);
+                return launch_gemm_tn_dy16(P16, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, x.dy_inv(i, k), x.prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
+                                           c.w_qmin, c.w_qmax, db, rdiv, st, x.at<float>(p.tn_scratch), kTnScratchBytes);
+            };
+            auto dgrad16 = [&](const void* P16, int k, int wi, float* dX, const NTPost* post) -> int {
+                int N, K; wshape(d, wi, &N, &K);
+                ProfScope ps(x.prof, !post ? 1 : post->mode == 8 ? 4 : 5, 2.0 * M * N * K, st);
+                return launch_gemm_nt_dy16(P16, x.wT16(wi), dX, M, K, N, N, N, K, wscale1(wi), x.dy_inv(i, k), st, post);
+            };
+            // ---- MLP branch
+            if (inject && s == stage_from)
+                launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dY16, nullptr, d.M * d.D, st,
+                                x.dy_mul(i, DS_FC2), x.dy_slot(i, DS_FC2));
+            if (wgrad16(dY16, DS_FC2, w_fc2, nullptr, nullptr, x.blk<void>(p.G8, i), x.blk<uint32_t>(p.glut, i), scal16 + 1, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
+            {   // fc2 dgrad + GELU backward + fc1's STE mask -> the fc1 output gradient, one plane
+                NTPost post{};
+                post.mode = 9; post.qp = x.act_qp(x.aidx(i, AB_FC1)); post.qmin = qa; post.qmax = qb; post.colscale = x.dy_colscale(w_fc1);
+                post.out_hi = dY1_16; post.code8 = x.blk<void>(p.G8, i); post.code_mask = x.blk<void>(p.Y1m, i);
+                post.o16_mul = x.dy_mul(i, DS_FC1); post.o16_amax = x.dy_slot(i, DS_FC1);
+                if (dgrad16(dY16, DS_FC2, w_fc2, nullptr, &post)) return 1;
+            }
+            if (wgrad16(dY1_16, DS_FC1, w_fc1, x.blk<void>(p.h2q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N2)), BG(i, B_FC1W), BG(i, B_FC1B))) return 1;
+            const bool lnb = lnb_fuse() && d.D == 384;
+            LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dY16, nullptr, x.dy_mul(i, DS_PROJ), x.dy_slot(i, DS_PROJ)};
+            if (lnb) {
+                NTPost post{};
+                post.mode = 8; post.qp = x.act_qp(x.aidx(i, AB_N2)); post.qmin = qa; post.qmax = qb;
+                post.lnb_x = x.blk<float>(p.x_mid, i); post.lnb_mean = x.blk<float>(p.mean2, i); post.lnb_rstd = x.blk<float>(p.rstd2, i);
+                post.lnb_gamma = x.bprm(i, B_N2W); post.lnb_beta = x.bprm(i, B_N2B); post.lnb_dx_in = dxA; post.lnb_dgamma = BG(i, B_N2W); post.lnb_dbeta = BG(i, B_N2B);
+                post.lnb_nmask = nx_proj.maskbits; post.colscale = nx_proj.colscale; post.out_hi = dY16;
+                post.o16_mul = nx_proj.o16_mul; post.o16_amax = nx_proj.o16_amax;
+                if (dgrad16(dY1_16, DS_FC1, w_fc1, dxB, &post)) return 1;
+            } else {
+                if (dgrad16(dY1_16, DS_FC1, w_fc1, x.at<float>(p.dH), nullptr)) return 1;
+                if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_mid, i), x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W),
+                                     x.bprm(i, B_N2B), x.act_qp(x.aidx(i, AB_N2)), qa, qb, dxA, dxB, BG(i, B_N2W), BG(i, B_N2B), d.M, d.D, d.T, 0, st, &nx_proj))
+                    return 1;
+            }
+            // ---- attention branch (dxB = gradient w.r.t. x_mid)
+            // (the float X operands - attention output, gelu output - enter the one-plane weight gradients rounded to fp16 like dY itself: one pass;
+            //  QATVIT_DY16_XPAIR=1 keeps them as fp16 (hi, lo) pairs, two passes)
+            static const bool xpair = getenv("QATVIT_DY16_XPAIR") && atoi(getenv("QATVIT_DY16_XPAIR")) != 0;
+            if (wgrad16(dY16, DS_PROJ, w_proj, x.blk<void>(p.O16_hi, i), xpair ? x.blk<void>(p.O16_lo, i) : nullptr, nullptr, nullptr, scal16, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
+            if (dgrad16(dY16, DS_PROJ, w_proj, x.at<float>(p.dO), nullptr)) return 1;
+            if (launch_attn_bwd(nullptr, x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i),
+                                x.at<float>(p.delta), x.at<float>(p.dO), dqkv16, nullptr, x.dy_colscale(w_qkv), st, x.blk<void>(p.qkv8, i), x.blk<void>(p.qkvm, i),
+                                x.dy_mul(i, DS_QKV), x.dy_slot(i, DS_QKV)))
+                return 1;
+            if (wgrad16(dqkv16, DS_QKV, w_qkv, x.blk<void>(p.h1q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N1)), BG(i, B_QKVW), BG(i, B_QKVB))) return 1;
+            LnBwdNext nx_fc2{i > 0 ? x.blk<void>(p.m2, i - 1) : nullptr, i > 0 ? x.dy_colscale(x.widx(i - 1, WB_FC2)) : nullptr, dY16, nullptr,
+                             i > 0 ? x.dy_mul(i - 1, DS_FC2) : nullptr, i > 0 ? x.dy_slot(i - 1, DS_FC2) : nullptr};
+            if (lnb) {
+                NTPost post{};
+                post.mode = 8; post.qp = x.act_qp(x.aidx(i, AB_N1)); post.qmin = qa; post.qmax = qb;
+                post.lnb_x = x.blk<float>(p.x_in, i); post.lnb_mean = x.blk<float>(p.mean1, i); post.lnb_rstd = x.blk<float>(p.rstd1, i);
+                post.lnb_gamma = x.bprm(i, B_N1W); post.lnb_beta = x.bprm(i, B_N1B); post.lnb_dx_in = dxB; post.lnb_dgamma = BG(i, B_N1W); post.lnb_dbeta = BG(i, B_N1B);
+                if (i > 0) { post.lnb_nmask = nx_fc2.maskbits; post.colscale = nx_fc2.colscale; post.out_hi = dY16; }
+                // (block 0 emits no next-branch gradient; the epilogue still wants a scale / maximum target: its own slot, which nothing reads afterwards)
+                post.o16_mul = i > 0 ? nx_fc2.o16_mul : x.dy_mul(0, DS_QKV); post.o16_amax = i > 0 ? nx_fc2.o16_amax : x.dy_slot(0, DS_QKV);
+                if (dgrad16(dqkv16, DS_QKV, w_qkv, dxA, &post)) return 1;
+            } else {
+                if (dgrad16(dqkv16, DS_QKV, w_qkv, x.at<float>(p.dH), nullptr)) return 1;
+                if (launch_ln_bwd_fq(1, x.at<float>(p.dH), x.blk<float>(p.x_in, i), x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W),
+                                     x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)), qa, qb, dxB, dxA, BG(i, B_N1W), BG(i, B_N1B), d.M, d.D, d.T, 0, st,
+                                     i > 0 ? &nx_fc2 : nullptr))
+                    return 1;
+            }
         } else if (s <= d.depth) {
             const int i = d.depth - s;
             void* dYh = x.at<void>(p.dYs_hi);
             void* dYl = x.at<void>(p.dYs_lo);
             const int w_fc2 = x.widx(i, WB_FC2), w_fc1 = x.widx(i, WB_FC1), w_proj = x.widx(i, WB_PROJ), w_qkv = x.widx(i, WB_QKV);
             // ---- MLP branch
-            if (!ln_fuse || (inject && s == stage_from)) launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
+            if (!ln_fuse || (inject && s == stage_from)) {
+                launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dYh, dYl, d.M * d.D, st);
+                calib(dYh, d.M * d.D, i, DS_FC2);
+            }
             if (fc2w_code_form(x, i)) {
                 if (x.linear_wgrad_codes(dYh, dYl, M, w_fc2, x.blk<void>(p.G8, i), x.blk<uint32_t>(p.glutq, i), BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
             } else if (x.linear_wgrad(dYh, dYl, M, w_fc2, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), nullptr, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
@@ -702,6 +823,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 if (fc1_code_bits(x, i)) { post.mode = 9; post.code = nullptr; post.code8 = x.blk<void>(p.G8, i); post.code_mask = x.blk<void>(p.Y1m, i); }
                 if (x.linear_dgrad(dYh, dYl, M, w_fc2, nullptr, &post)) return 1;
             }
+            calib(x.at<void>(p.dY1_hi), d.M * d.Hd, i, DS_FC1);
             if (x.linear_wgrad(x.at<void>(p.dY1_hi), x.at<void>(p.dY1_lo), M, w_fc1, x.blk<void>(p.h2q, i), nullptr, x.act_qp(x.aidx(i, AB_N2)),
                                BG(i, B_FC1W), BG(i, B_FC1B)))
                 return 1;
@@ -723,6 +845,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             }
             // ---- attention branch (dxB = gradient w.r.t. x_mid)
             if (!ln_fuse) launch_mask_bwd(0, dxB, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), qa, qb, x.dy_colscale(w_proj), d.D, dYh, dYl, d.M * d.D, st);
+            calib(dYh, d.M * d.D, i, DS_PROJ);
             if (x.linear_wgrad(dYh, dYl, M, w_proj, x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), nullptr, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
             if (x.linear_dgrad(dYh, dYl, M, w_proj, x.at<float>(p.dO))) return 1;
             if (launch_attn_bwd(x.blk<float>(p.qkv, i), x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i),
@@ -730,6 +853,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                                 x.at<void>(p.dqkv_lo), x.dy_colscale(w_qkv), st, attn_codes(c) ? x.blk<void>(p.qkv8, i) : nullptr,
                                 attn_codes(c) ? x.blk<void>(p.qkvm, i) : nullptr))
                 return 1;
+            calib(x.at<void>(p.dqkv_hi), d.M * 3 * d.D, i, DS_QKV);
             if (x.linear_wgrad(x.at<void>(p.dqkv_hi), x.at<void>(p.dqkv_lo), M, w_qkv, x.blk<void>(p.h1q, i), nullptr, x.act_qp(x.aidx(i, AB_N1)),
                                BG(i, B_QKVW), BG(i, B_QKVB)))
                 return 1;
@@ -749,6 +873,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                                      (ln_fuse && i > 0) ? &nx_fc2 : nullptr))
                     return 1;
             }
+            if (i > 0) calib(dYh, d.M * d.D, i - 1, DS_FC2);
         } else {
             launch_embed_bwd(dxA, x.at<float>(p.Y0), x.act_qp(A_PE), qa, qb, G(P_POS), G(P_CLS), x.at<void>(p.dY0_hi), x.at<void>(p.dY0_lo), d.B,
                              d.T, d.D, st);
@@ -758,6 +883,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 return 1;
         }
     }
+    if (dy || cal) launch_dy16_end(dystate, nslots, dy ? 1 : 0, st);
     return 0;
 }
 
@@ -801,9 +927,11 @@ static int run_forward(const qatvit_cfg* cfg, void* const* params, const qatvit_
     QV_CHECK_ARG(stage_from >= 0 && stage_to <= cfg->depth + 1 && stage_from <= stage_to, "%s: bad stage range [%d,%d]", who, stage_from, stage_to);
     QV_CHECK_ARG(stage_from > 0 || images, "%s: stage 0 needs the images", who);
     QV_CHECK_ARG(stage_to <= cfg->depth || logits, "%s: the last stage needs the logits buffer", who);
-    QV_CHECK_ARG((flags & ~QATVIT_STAGE_INJECT) == 0 && !((flags & QATVIT_STAGE_INJECT) && stage_from == 0), "%s: bad flags %d", who, flags);
+    QV_CHECK_ARG((flags & ~(QATVIT_STAGE_INJECT | QATVIT_FWD_X16)) == 0 && !((flags & QATVIT_STAGE_INJECT) && stage_from == 0), "%s: bad flags %d", who, flags);
     Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream, prof_of(workspace)};
     if (make_plan(*cfg, &x.p)) return 1;
+    x.flags = flags & QATVIT_FWD_X16;
+    QV_CHECK_ARG(!x.flags || dy16_supported(x), "%s: QATVIT_FWD_X16 needs a configuration the one-plane backward covers (qatvit_student_dy16_supported)", who);
     if (fwd(x, images, logits, stage_from, stage_to, (flags & QATVIT_STAGE_INJECT) != 0)) return 1;
     QV_CHECK_LAUNCH(who);
     return 0;
@@ -825,10 +953,12 @@ int qatvit_student_forward_part(const qatvit_cfg* cfg, void* const* params, cons
                                 int32_t block, int32_t part, int32_t flags, void* stream) {
     QV_CHECK_ARG(cfg && params && act_fq && weight_fq && workspace, "qatvit_student_forward_part: null argument");
     if (check_cfg(*cfg)) return 1;
-    QV_CHECK_ARG(block >= 0 && block < cfg->depth && part >= 0 && part <= 3 && (flags & ~QATVIT_STAGE_INJECT) == 0,
+    QV_CHECK_ARG(block >= 0 && block < cfg->depth && part >= 0 && part <= 3 && (flags & ~(QATVIT_STAGE_INJECT | QATVIT_FWD_X16)) == 0,
                  "qatvit_student_forward_part: bad block %d / part %d / flags %d", block, part, flags);
     Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream, prof_of(workspace)};
     if (make_plan(*cfg, &x.p)) return 1;
+    x.flags = flags & QATVIT_FWD_X16;
+    QV_CHECK_ARG(!x.flags || dy16_supported(x), "qatvit_student_forward_part: QATVIT_FWD_X16 needs a configuration the one-plane backward covers");
     if (fwd_part(x, block, part, (flags & QATVIT_STAGE_INJECT) != 0)) return 1;
     QV_CHECK_LAUNCH("qatvit_student_forward_part");
     return 0;
@@ -840,9 +970,11 @@ static int run_backward(const qatvit_cfg* cfg, void* const* params, const qatvit
     if (check_cfg(*cfg)) return 1;
     QV_CHECK_ARG(stage_from >= 0 && stage_to <= cfg->depth + 1 && stage_from <= stage_to, "%s: bad stage range [%d,%d]", who, stage_from, stage_to);
     QV_CHECK_ARG(stage_from > 0 || dlogits, "%s: stage 0 needs dlogits", who);
-    QV_CHECK_ARG((flags & ~QATVIT_STAGE_INJECT) == 0 && !((flags & QATVIT_STAGE_INJECT) && stage_from == 0), "%s: bad flags %d", who, flags);
+    QV_CHECK_ARG((flags & ~(QATVIT_STAGE_INJECT | QATVIT_BWD_DY16 | QATVIT_BWD_CALIBRATE)) == 0 && !((flags & QATVIT_STAGE_INJECT) && stage_from == 0),
+                 "%s: bad flags %d", who, flags);
     Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), params, act_fq, weight_fq, (hipStream_t)stream, prof_of(workspace)};
     if (make_plan(*cfg, &x.p)) return 1;
+    x.flags = flags & (QATVIT_BWD_DY16 | QATVIT_BWD_CALIBRATE);
     if (bwd(x, dlogits, grads, stage_from, stage_to, (flags & QATVIT_STAGE_INJECT) != 0)) return 1;
     QV_CHECK_LAUNCH(who);
     return 0;
@@ -857,6 +989,26 @@ int qatvit_student_backward_stages(const qatvit_cfg* cfg, void* const* params, c
                                    const float* dlogits, void* const* grads, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags,
                                    void* stream) {
     return run_backward(cfg, params, act_fq, weight_fq, dlogits, grads, workspace, stage_from, stage_to, flags, stream, "qatvit_student_backward_stages");
+}
+
+int32_t qatvit_student_dy16_supported(const qatvit_cfg* cfg) {
+    if (!cfg || check_cfg(*cfg)) return 0;
+    Ctx x{*cfg, dims_of(*cfg), Plan(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (make_plan(*cfg, &x.p)) return 0;
+    return dy16_supported(x) ? 1 : 0;
+}
+
+int qatvit_student_dy16_to_pair(const qatvit_cfg* cfg, void* workspace, void* stream) {
+    QV_CHECK_ARG(cfg && workspace, "qatvit_student_dy16_to_pair: null argument");
+    if (check_cfg(*cfg)) return 1;
+    Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), nullptr, nullptr, nullptr, (hipStream_t)stream, nullptr};
+    if (make_plan(*cfg, &x.p)) return 1;
+    for (int i = 0; i < x.d.depth; ++i) {
+        if (launch_f16int_to_bf16int(x.blk<void>(x.p.h1q, i), x.d.M * x.d.D, x.st)) return 1;
+        if (launch_f16int_to_bf16int(x.blk<void>(x.p.h2q, i), x.d.M * x.d.D, x.st)) return 1;
+    }
+    QV_CHECK_LAUNCH("qatvit_student_dy16_to_pair");
+    return 0;
 }
 
 // bench.py: time every launch of one GEMM class of ONE engine (identified by its workspace) with HIP events on the stream it is launched on
@@ -917,8 +1069,8 @@ int64_t qatvit_student_tensor_offset(const qatvit_cfg* cfg, const char* name, in
         {"x_mid", p.x_mid, true}, {"h1q", p.h1q, true}, {"qkv", p.qkv, true}, {"O_hi", p.O_hi, true}, {"O_lo", p.O_lo, true}, {"Yproj", p.Yproj, true}, {"h2q", p.h2q, true},
         {"Y1", p.Y1, true}, {"G_hi", p.G_hi, true}, {"G_lo", p.G_lo, true}, {"Y2", p.Y2, true}, {"dxA", p.dxA, false}, {"dqkv_hi", p.dqkv_hi, false},
         {"dqkv_lo", p.dqkv_lo, false}, {"dO", p.dO, false},
-        {"dH", p.dH, false}, {"lse", p.lse, true}, {"O16_hi", p.O16_hi, false}, {"O16_lo", p.O16_lo, false}, {"G16_hi", p.G16_hi, false},
-        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, false}, {"G8", p.G8, true}, {"glut", p.glut, true}, {"Y1m", p.Y1m, true}, {"glutq", p.glutq, true}, {"qkv8", p.qkv8, true}, {"qkvm", p.qkvm, true},
+        {"dH", p.dH, false}, {"lse", p.lse, true}, {"O16_hi", p.O16_hi, true}, {"O16_lo", p.O16_lo, true}, {"G16_hi", p.G16_hi, false},
+        {"G16_lo", p.G16_lo, false}, {"scal16", p.scal16, true}, {"dy16", p.dy16, false}, {"dYs_hi", p.dYs_hi, false}, {"dY1_hi", p.dY1_hi, false}, {"G8", p.G8, true}, {"glut", p.glut, true}, {"Y1m", p.Y1m, true}, {"glutq", p.glutq, true}, {"qkv8", p.qkv8, true}, {"qkvm", p.qkvm, true},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) return t.off + (t.per_block ? p.blk_stride * block : 0);

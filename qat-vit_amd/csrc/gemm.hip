@@ -152,6 +152,10 @@ struct NTArgs {
     const uint8_t* post_code8;
     const uint8_t* post_mask;
     uint32_t* lutq_out;      // mode 4 (optional): the 256-entry table of bf16 (hi | lo << 16) pairs of gelu(grid value) - the table the fc2 weight gradient expands the codes through
+    // modes 18 / 19 (= 8 / 9 of the one-plane backward, launch_gemm_nt_dy16): the gradient pair out_hi / out_lo becomes ONE fp16 plane (out_hi) of
+    // value * (*o16_mul), a power of two chosen before the step (dy16.hip); max |value| goes into o16_amax (8 sub-slots, 32 B apart) for the next step's choice
+    const float* o16_mul;
+    uint32_t* o16_amax;
 };
 
 constexpr int kStandIn = 512;
@@ -177,6 +181,10 @@ template <int WM, int WN, int TM, int TNT, int SLAB = 64, int PM = 0, int RING =
 __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4, f32x4> (&acc)[TM][TNT], char* smem, int m0, int n0, int tid, int lane, int wave, int wm, int wn,
                                    int r, int g) {
     constexpr int WR = 16 * TM, WC = 16 * TNT, BM = WR * WM, BN = WC * WN, NW = WN * WM;
+    constexpr bool O16 = PM == 18 || PM == 19;             // the masked gradient leaves as one scaled fp16 plane instead of a bf16 (hi, lo) pair
+    constexpr int PMB = PM == 18 ? 8 : PM == 19 ? 9 : PM;  // the epilogue this instantiation contains
+    float o16_mul = 1.f, o16_am = 0.f;
+    if constexpr (O16) o16_mul = *p.o16_mul;
     // ---- epilogue: C = acc * alpha[col] + bias[col]; min/max of what is stored.
     // The accumulator layout (16 consecutive columns per 16 lanes, rows on registers) would give 64-B store
     // segments; stage 64-row halves of the tile through LDS instead and store whole 16-B-per-lane row runs
@@ -193,7 +201,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     // fused GELU backward: fq(Y) only takes qmax-qmin+1 (<= 256) values, so gelu'(fq(Y)) is a table (no erf/exp per element)
     float* sLut = sC + SLAB * LDC;
     bool use_lut = false;
-    constexpr bool P5 = PM == 5 || PM == 9;   // fc2 dgrad + GELU backward; 9: codes as uint8 + mask bits
+    constexpr bool P5 = PMB == 5 || PMB == 9;   // fc2 dgrad + GELU backward; 9: codes as uint8 + mask bits
     if constexpr (PM == 1 || P5) {
         use_lut = P5 || (p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256);
         if (use_lut && tid <= p.post_qmax - p.post_qmin) sLut[tid] = gelu_bwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
@@ -202,9 +210,9 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     uint32_t* sLutF = reinterpret_cast<uint32_t*>(sLut);   // mode 4: packed (hi | lo << 16) bf16 pair of gelu(grid value)
     // mode 5: the slab's uint16 codes come in by LDS-DMA next to the staged tile while the accumulators are being staged (a global load
     // per store-loop iteration is a load-use chain at 8 waves per CU: fc2 dgrad took 296 us against 160 us for the plain store)
-    constexpr int CODE_BYTES = PM == 9 ? SLAB * BN + SLAB * BN / 8 : SLAB * BN * 2;   // (mode 9: the slab's codes, then its mask bits)
+    constexpr int CODE_BYTES = PMB == 9 ? SLAB * BN + SLAB * BN / 8 : SLAB * BN * 2;   // (mode 9: the slab's codes, then its mask bits)
     constexpr bool CODE_LDS = P5 && RING >= SLAB * LDC * 4 + 1024 + CODE_BYTES && CODE_BYTES % 1024 == 0;
-    static_assert(PM != 9 || (CODE_LDS && (SLAB * BN) % 1024 == 0 && (SLAB * BN / 8) % 1024 == 0), "mode 9: whole 1-KiB pieces of codes and of mask bits");
+    static_assert(PMB != 9 || (CODE_LDS && (SLAB * BN) % 1024 == 0 && (SLAB * BN / 8) % 1024 == 0), "mode 9: whole 1-KiB pieces of codes and of mask bits");
     // two code buffers when they fit: slab h + 1's codes are requested before slab h is staged and arrive under its store loop (one
     // buffer exposes most of a 37-49 KB fetch per slab: a CU fills at ~20-30 GB/s)
     constexpr bool CODE_DB = CODE_LDS && RING >= SLAB * LDC * 4 + 1024 + 2 * CODE_BYTES;
@@ -219,7 +227,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     }
     auto code_dma = [&](int h, char* dst) -> int {   // returns the number of DMA instructions this wave issued
         int n = 0;
-        if constexpr (PM == 9) {
+        if constexpr (PMB == 9) {
             const __amdgpu_buffer_rsrc_t rC8 = make_rsrc(p.post_code8, (int64_t)p.M * p.ldc);
             const __amdgpu_buffer_rsrc_t rMk = make_rsrc(p.post_mask, (int64_t)p.M * p.ldc / 8);
             constexpr int PC = SLAB * BN / 1024, PMK = SLAB * BN / 8 / 1024;
@@ -296,7 +304,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
         return (t >= fmin_ && t <= fmax_) || qq.on == 0.f;
     };
     float4 lnb_ag[2], lnb_ab[2];
-    if constexpr (PM == 8) {
+    if constexpr (PMB == 8) {
         static_assert(RING == 0 || RING >= SLAB * LDC * 4 + 2048 + 3 * BN * 4, "ring too small for the mode-8 row operands");
         float* sRow = sC + SLAB * LDC + 512;   // published by the first slab's staging barrier
         for (int c = tid; c < BN; c += NW * 64) {
@@ -341,7 +349,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     const int rl = rt - SLAB * h + 4 * g + e;
                     const float v = accv(i, j, e) * ca[j] + cb[j];
                     sC[rl * LDC + cl] = v;
-                    if constexpr (PM != 6 && PM != 7 && PM != 8) {   // (the inference epilogues and the fused LayerNorm backward feed no observer)
+                    if constexpr (PM != 6 && PM != 7 && PMB != 8) {   // (the inference epilogues and the fused LayerNorm backward feed no observer)
                         if (m0 + SLAB * h + rl < p.M) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
                     }
                 }
@@ -363,7 +371,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
         QV_NT_STAMP(PM, 5 + 2 * h);   // slab h staged (and its codes arrived)
         constexpr int C4 = BN / 4;              // float4 per staged row
         const int rows_h = BM - SLAB * h < SLAB ? BM - SLAB * h : SLAB;
-        if constexpr (PM == 8) {
+        if constexpr (PMB == 8) {
             // one wave per staged row (k_ln_bwd_fq's lane -> column map: lane * 4 + 256 j), the next row's global operands requested one row ahead
             static_assert(BN == 384, "the fused LayerNorm backward needs the whole 384-column row in the tile");
             constexpr int NVL = 2;
@@ -433,11 +441,16 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                         const float4 cs = *reinterpret_cast<const float4*>(sCs + c);
                         const float f0 = (mk[j][0] >> lane) & 1 ? o.x * cs.x : 0.f, f1 = (mk[j][1] >> lane) & 1 ? o.y * cs.y : 0.f,
                                     f2 = (mk[j][2] >> lane) & 1 ? o.z * cs.z : 0.f, f3 = (mk[j][3] >> lane) & 1 ? o.w * cs.w : 0.f;
-                        uint2 hh, ll;
-                        split_pair(f0, f1, hh.x, ll.x);
-                        split_pair(f2, f3, hh.y, ll.y);
-                        *reinterpret_cast<uint2*>(p.out_hi + row * BN + c) = hh;
-                        *reinterpret_cast<uint2*>(p.out_lo + row * BN + c) = ll;
+                        if constexpr (O16) {
+                            o16_am = fmaxf(fmaxf(o16_am, fmaxf(fabsf(f0), fabsf(f1))), fmaxf(fabsf(f2), fabsf(f3)));
+                            *reinterpret_cast<uint2*>(p.out_hi + row * BN + c) = make_uint2(pk_f16(f0 * o16_mul, f1 * o16_mul), pk_f16(f2 * o16_mul, f3 * o16_mul));
+                        } else {
+                            uint2 hh, ll;
+                            split_pair(f0, f1, hh.x, ll.x);
+                            split_pair(f2, f3, hh.y, ll.y);
+                            *reinterpret_cast<uint2*>(p.out_hi + row * BN + c) = hh;
+                            *reinterpret_cast<uint2*>(p.out_lo + row * BN + c) = ll;
+                        }
                     }
                 }
             }
@@ -463,10 +476,10 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     off[u] = (int64_t)row * p.ldc + n0 + 4 * c4;
                     const int rls = idx < limit ? rl : 0;      // (stay inside the staged slab)
                     v[u] = *reinterpret_cast<const float4*>(sC + rls * LDC + 4 * c4);
-                    if constexpr (PM == 9) {   // .x = the four codes, .y = their four mask bits
+                    if constexpr (PMB == 9) {   // .x = the four codes, .y = their four mask bits
                         c2[u].x = *reinterpret_cast<const uint32_t*>(sCodeH + rls * BN + 4 * c4);
                         c2[u].y = ((uint32_t) reinterpret_cast<const uint8_t*>(sCodeH)[SLAB * BN + ((rls * BN + 4 * c4) >> 3)] >> (4 * (c4 & 1))) & 0xfu;
-                    } else if constexpr (PM == 5) {
+                    } else if constexpr (PMB == 5) {
                         if constexpr (CODE_LDS) c2[u] = *reinterpret_cast<const uint2*>(sCodeH + (rls * BN + 4 * c4) * 2);
                         else c2[u] = ok[u] ? *reinterpret_cast<const uint2*>(p.post_code + off[u]) : make_uint2(0u, 0u);
                     }
@@ -556,8 +569,8 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
                     float dg[U][4];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const uint32_t cd[4] = {PM == 9 ? c2[u].x : c2[u].x & 0xffffu, PM == 9 ? c2[u].x >> 8 : c2[u].x >> 16,
-                                                PM == 9 ? c2[u].x >> 16 : c2[u].y & 0xffffu, PM == 9 ? c2[u].x >> 24 : c2[u].y >> 16};
+                        const uint32_t cd[4] = {PMB == 9 ? c2[u].x : c2[u].x & 0xffffu, PMB == 9 ? c2[u].x >> 8 : c2[u].x >> 16,
+                                                PMB == 9 ? c2[u].x >> 16 : c2[u].y & 0xffffu, PMB == 9 ? c2[u].x >> 24 : c2[u].y >> 16};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) dg[u][e] = sLut[cd[e] & 0xffu];   // (unconditional: no branch between the lookups)
                     }
@@ -571,15 +584,22 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const uint32_t cde = (e & 1) ? ((e & 2) ? c2[u].y : c2[u].x) >> 16 : ((e & 2) ? c2[u].y : c2[u].x);
-                            const bool in_range = PM == 9 ? ((c2[u].y >> e) & 1u) != 0 : (cde & 0x8000u) != 0;
+                            const bool in_range = PMB == 9 ? ((c2[u].y >> e) & 1u) != 0 : (cde & 0x8000u) != 0;
                             o[e] = in_range ? cv[e] * dg[u][e] * sv[e] : 0.f;
                         }
-                        uint2 oh, ol;
-                        split_pair(o[0], o[1], oh.x, ol.x);
-                        split_pair(o[2], o[3], oh.y, ol.y);
-                        if (ok[u]) {
-                            *reinterpret_cast<uint2*>(p.out_hi + off[u]) = oh;
-                            *reinterpret_cast<uint2*>(p.out_lo + off[u]) = ol;
+                        if constexpr (O16) {
+                            if (ok[u]) {   // (rows past M hold zero accumulators anyway: the maximum needs no guard of its own)
+                                o16_am = fmaxf(fmaxf(o16_am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                                *reinterpret_cast<uint2*>(p.out_hi + off[u]) = make_uint2(pk_f16(o[0] * o16_mul, o[1] * o16_mul), pk_f16(o[2] * o16_mul, o[3] * o16_mul));
+                            }
+                        } else {
+                            uint2 oh, ol;
+                            split_pair(o[0], o[1], oh.x, ol.x);
+                            split_pair(o[2], o[3], oh.y, ol.y);
+                            if (ok[u]) {
+                                *reinterpret_cast<uint2*>(p.out_hi + off[u]) = oh;
+                                *reinterpret_cast<uint2*>(p.out_lo + off[u]) = ol;
+                            }
                         }
                     }
                 }
@@ -724,7 +744,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
             }
         }
     }
-    if constexpr (PM == 8) {   // dgamma / dbeta: the tile's column sums meet in LDS, one atomic per column per tile
+    if constexpr (PMB == 8) {   // dgamma / dbeta: the tile's column sums meet in LDS, one atomic per column per tile
         lds_barrier();
         float* sg = reinterpret_cast<float*>(smem);          // [NW][BN]
         float* sb = sg + NW * BN;
@@ -744,6 +764,10 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
             atomicAdd(&p.lnb_dgamma[c], a);
             atomicAdd(&p.lnb_dbeta[c], b);
         }
+    }
+    if constexpr (O16) {   // one atomic per wave, the sub-slot picked by the workgroup (same-address atomics serialise)
+        o16_am = wave_max(o16_am);
+        if (lane == 0) atomicMax(p.o16_amax + (blockIdx.x & (kDyAmaxSlots - 1)) * kDyAmaxStride, __builtin_bit_cast(uint32_t, o16_am));
     }
     if (p.stats) {
         mn = wave_min(mn);
@@ -933,8 +957,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void k_gemm_nt(
     // mode 8 (fused LayerNorm backward) stages 96 rows at a time in 160 KiB of LDS (the launch asks for it): 84 instead of 108 accumulator
     // registers are still live while the first slab's rows are processed
     // mode 9: 64 rows + two (codes + mask bits) buffers of 27 KiB need 154 KiB: the launch asks for 160 like mode 8
-    constexpr int SLAB = PM == 8 ? 96 : PM == 9 ? 64 : PM5_48 ? 48 : RING_ >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;
-    constexpr int EPI_LDS = (PM == 8 || PM == 9) ? 160 * 1024 : NSTAGE * STAGE;
+    constexpr int SLAB = (PM == 8 || PM == 18) ? 96 : (PM == 9 || PM == 19) ? 64 : PM5_48 ? 48 : RING_ >= 64 * (BN + 4) * 4 + 1024 ? 64 : 32;
+    constexpr int EPI_LDS = (PM == 8 || PM == 9 || PM == 18 || PM == 19) ? 160 * 1024 : NSTAGE * STAGE;
     static_assert(EPI_LDS >= SLAB * (BN + 4) * 4 + 1024, "ring too small for the epilogue slab");
     nt_epilogue<WM, WN, TM, TNT, SLAB, PM, EPI_LDS, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
     QV_NT_STAMP(PM, 12);   // stores issued
@@ -1112,7 +1136,11 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
         k_gemm_nt<TA, NS, WM, TM, TB, WN, TNT, BK, PM_, I8, F16><<<grid, WM * WN * 64, lds, st>>>(a);          \
     } while (0)
     if constexpr (F16) {   // proj / fc2 forward: plain epilogue (training: the observer needs the pre-FQ tensor) or the fused residual update (inference)
-        if (a.pm == 6) QV_PM(6); else if (a.pm == 2) QV_PM(2); else QV_PM(0);
+        if (a.pm == 6) QV_PM(6);
+        else if (a.pm == 2) QV_PM(2);
+        else if (a.pm == 18 || a.pm == 19) {   // the one-plane backward: dgrad + fused LayerNorm backward / GELU backward (launch_gemm_nt_dy16)
+            if constexpr (TA == 1 && TB == 1 && WM == 1 && WN * TNT == 24 && TM == 13) { if (a.pm == 18) QV_PM(18); else QV_PM(19); }
+        } else QV_PM(0);
     } else if constexpr (I8) {   // the grid x grid forward GEMMs
         switch (a.pm) {
             case 3: QV_PM(3); break;
@@ -1243,6 +1271,46 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
     return 0;
 }
 
+int launch_gemm_nt_dy16(const void* A16, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1, const float* s2,
+                        hipStream_t st, const NTPost* post) {
+    if (M < 1 || N % 384 != 0 || K % 32 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0 || !A16 || !B16) {
+        set_error("gemm_nt_dy16: unsupported arguments M=%d N=%d K=%d lda=%d ldb=%d ldc=%d (need N%%384==0, K%%32==0)", M, N, K, lda, ldb, ldc);
+        return 1;
+    }
+    NTArgs a{};
+    a.A0 = reinterpret_cast<const __bf16*>(A16); a.B = reinterpret_cast<const __bf16*>(B16); a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.s1 = s1; a.s2 = s2; a.stat_slots = 1;
+    size_t lds = (size_t)3 * (208 + 384) * 64;   // 111 KiB ring
+    if (post) {
+        if ((post->mode != 8 && post->mode != 9) || !post->o16_mul || !post->o16_amax || !post->qp) {
+            set_error("gemm_nt_dy16: epilogue mode %d (8 or 9 with o16_mul / o16_amax)", post->mode);
+            return 1;
+        }
+        a.post_mode = post->mode; a.pm = post->mode + 10;
+        a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.post_colscale = post->colscale;
+        a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.o16_mul = post->o16_mul; a.o16_amax = post->o16_amax;
+        a.lnb_x = post->lnb_x; a.lnb_mean = post->lnb_mean; a.lnb_rstd = post->lnb_rstd; a.lnb_gamma = post->lnb_gamma; a.lnb_beta = post->lnb_beta;
+        a.lnb_dx_in = post->lnb_dx_in; a.lnb_dgamma = post->lnb_dgamma; a.lnb_dbeta = post->lnb_dbeta;
+        a.lnb_nmask = reinterpret_cast<const unsigned long long*>(post->lnb_nmask);
+        a.post_code8 = reinterpret_cast<const uint8_t*>(post->code8); a.post_mask = reinterpret_cast<const uint8_t*>(post->code_mask);
+        if (post->mode == 9 && !(ldc % 128 == 0 && a.out_hi && a.post_code8 && a.post_mask && a.post_qmax - a.post_qmin < 256)) {
+            set_error("gemm_nt_dy16: epilogue mode 9 needs ldc %% 128 == 0, the fp16 output plane, the uint8 codes and the mask bits");
+            return 1;
+        }
+        if (post->mode == 8 && !(N == 384 && ldc == 384 && C && a.lnb_x && a.lnb_mean && a.lnb_rstd && a.lnb_gamma && a.lnb_beta && a.lnb_dx_in && a.lnb_dgamma &&
+                                 a.lnb_dbeta && (!a.out_hi || a.lnb_nmask))) {
+            set_error("gemm_nt_dy16: epilogue mode 8 needs N == ldc == 384 and the LayerNorm operands");
+            return 1;
+        }
+        lds = (size_t)160 * 1024;
+    } else if (!C) {
+        set_error("gemm_nt_dy16: null output");
+        return 1;
+    }
+    nt_launch<1, 3, 1, 13, 1, 8, 3, 32, false, true>(a, cdiv(M, 208) * (N / 384), lds, st);   // (a 4-stage ring, 148 KiB, measured the same: 105.1 vs 104.5 us)
+    return 0;
+}
+
 // fc2 forward from codes: A8 [M, lda] uint8 grid indices, lut[256] packed fp16 (hi | lo << 16) pairs, B16 [N, ldb] the weight integers as fp16
 int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1,
                          const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st, const NTPost* post) {
@@ -1341,6 +1409,7 @@ struct TNArgs {
     // QC form (fc2 weight gradient): the Q operand gelu(fq(fc1 output)) as ONE byte per element + a 256-entry table of bf16 (hi | lo << 16) pairs
     const uint8_t* Qc;    // [M, ldq] uint8 table indices (ldq in bytes)
     const uint32_t* lutQ;
+    const float* s2;      // optional second device scalar: multiplies alpha AND the bias gradient (the one-plane form: P = dY * 2^e, *s2 = 2^-e)
 };
 
 template <int ROWB>  // ROWB: bytes per LDS row of the image (256 for a 128-column tile, 768 for a 384-column tile)
@@ -1364,21 +1433,28 @@ __device__ inline bf16x8 tr_frag(const char* img, int row0, int col0, int lane) 
 // kernels) and is expanded through a 256-entry table of bf16 (hi, lo) pairs INSIDE the workgroup: codes of tile s+1 land in a staging buffer by
 // LDS-DMA during step s-1, every thread expands 24 of them between the MFMA groups of step s (8-B code read, eight table gathers, two 16-B writes
 // into the hi / lo images in the layout the LDS-DMA of the plane form produces), the MFMAs of step s+1 read them: same fragments, same bits.
-template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK, bool QC = false>
+// TP = 1, F16: the one-plane backward - P is ONE fp16 plane (the gradient scaled by a power of two, its inverse in *s2), Q holds fp16 bit patterns too
+// (grid integers as fp16, or an fp16 (hi, lo) pair / a table of fp16 pairs): v_mfma_f32_16x16x32_f16, one pass per Q plane instead of two.
+template <int TQ, int NSTAGE, int WM, int WNK, int TNT, int BK, bool QC = false, int TP = 2, bool F16 = false>
 __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
+    static_assert((TP == 2 && !F16) || (TP == 1 && F16), "bf16 pair or one fp16 plane");
+    auto mm = [](const bf16x8& a, const bf16x8& b, const f32x4& c) -> f32x4 {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    };
     constexpr int BN = 128, NW = WM * WNK;
     constexpr int TM = BN / WM / 16;                // 16-row fragments of P per wave
     constexpr int BKW = WNK * TNT * 16;             // Kw columns per workgroup (128 or 384)
     constexpr int PROWB = 256, QROWB = BKW * 2;     // LDS row bytes
     constexpr int IMGP = BK * PROWB, IMGQ = BK * QROWB;
-    constexpr int STAGE = 2 * IMGP + TQ * IMGQ;
+    constexpr int STAGE = TP * IMGP + TQ * IMGQ;
     constexpr int PP = (IMGP / 1024) / NW, PQ = (IMGQ / 1024) / NW;   // 1-KiB DMA pieces per wave per image
     static_assert((IMGP / 1024) % NW == 0 && (IMGQ / 1024) % NW == 0, "pieces must divide evenly over the waves");
-    constexpr int NDMA = 2 * PP + TQ * PQ;
+    constexpr int NDMA = TP * PP + TQ * PQ;
     constexpr int QCH = QROWB / 16;                 // 16-B chunks per Q row
-    static_assert(!QC || (TQ == 2 && NSTAGE == 2 && BK == 32 && BKW == 384 && NW == 8), "codes form: the 128 x 384 tile, 32-token steps");
+    static_assert(!QC || (NSTAGE == 2 && BK == 32 && BKW == 384 && NW == 8 && (TQ == 2 || F16)), "codes form: the 128 x 384 tile, 32-token steps");
     // QC LDS map: [3 x (P hi, P lo)] [(Q hi, Q lo) images written by the expansion] [3 x code staging] [table]
-    constexpr int QC_PST = 2 * IMGP, QC_QIMG = 3 * QC_PST, QC_QST = 2 * IMGQ, QC_CB = QC_QIMG + QC_QST, QC_CBS = BK * BKW, QC_LUT = QC_CB + 3 * QC_CBS;
+    constexpr int QC_PST = TP * IMGP, QC_QIMG = 3 * QC_PST, QC_QST = TQ * IMGQ, QC_CB = QC_QIMG + QC_QST, QC_CBS = BK * BKW, QC_LUT = QC_CB + 3 * QC_CBS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1411,15 +1487,15 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
             const int src_chunk = (lane & 15) ^ tn_sw(row);
             const uint32_t offP = (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + src_chunk * 8) * 2);
             dma16_asm(rP0, st + piece * 1024, offP);
-            dma16_asm(rP1, st + IMGP + piece * 1024, offP);
+            if constexpr (TP == 2) dma16_asm(rP1, st + IMGP + piece * 1024, offP);
         } else {
             const int piece = wave * PQ + (c - PP);
             const int L = piece * 64 + lane;                   // linear 16-B chunk index inside the image
             const int row = L / QCH, cp = L % QCH;
             const int src_chunk = cp ^ tn_sw(row);
             const uint32_t offQ = (uint32_t)(((int64_t)(mrow0 + row) * p.ldq + k0 + src_chunk * 8) * 2);
-            dma16_asm(rQ0, st + 2 * IMGP + piece * 1024, offQ);
-            if constexpr (TQ == 2) dma16_asm(rQ1, st + 2 * IMGP + IMGQ + piece * 1024, offQ);
+            dma16_asm(rQ0, st + TP * IMGP + piece * 1024, offQ);
+            if constexpr (TQ == 2) dma16_asm(rQ1, st + TP * IMGP + IMGQ + piece * 1024, offQ);
         }
     };
     auto issue = [&](int s) {
@@ -1437,8 +1513,15 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
+    if constexpr (F16) {
+        f16x8 o1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+        for (int j = 0; j < 8; ++j) o1[j] = (_Float16)1.0f;
+        ones = __builtin_bit_cast(bf16x8, o1);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    }
 
     if constexpr (QC) {
         uint32_t* sLutQ = reinterpret_cast<uint32_t*>(smem + QC_LUT);
@@ -1451,7 +1534,7 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
             const int src_chunk = (lane & 15) ^ tn_sw(row);
             const uint32_t offP = (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + src_chunk * 8) * 2);
             dma16_asm(rP0, st + piece * 1024, offP);
-            dma16_asm(rP1, st + IMGP + piece * 1024, offP);
+            if constexpr (TP == 2) dma16_asm(rP1, st + IMGP + piece * 1024, offP);
         };
         auto issue_c = [&](int s) {      // this wave's code pieces of k-step s: 12 KiB = 12 pieces over 8 waves, linear [32 tokens][384 codes]
             char* cb = smem + QC_CB + (s % 3) * QC_CBS;
@@ -1489,7 +1572,7 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
             }
             const int o = row * QROWB + ((col8 ^ tn_sw(row)) << 4);
             *reinterpret_cast<v4i32*>(qi + o) = hi;
-            *reinterpret_cast<v4i32*>(qi + IMGQ + o) = lo;
+            if constexpr (TQ == 2) *reinterpret_cast<v4i32*>(qi + IMGQ + o) = lo;
         };
         auto expand = [&](int s, int i) { lookup(s, i); pack_store(s, i); };
         static_assert((BK * BKW / 8) % (NW * 64) == 0, "whole expansion rounds");
@@ -1510,19 +1593,20 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
         }
         for (int s = 0; s < nsteps; ++s) {
             // P(s) and codes(s+1) have landed once only the requests of step s-1 - P(s+1), codes(s+2) - are outstanding
-            const int young = (s >= 1 && s + 1 < nsteps ? 2 : 0) + (s >= 1 && s + 2 < nsteps ? ncode : 0);
+            const int young = (s >= 1 && s + 1 < nsteps ? TP : 0) + (s >= 1 && s + 2 < nsteps ? ncode : 0);
             if (young == 4) wait_vmcnt<4>();
             else if (young == 3) wait_vmcnt<3>();
             else if (young == 2) wait_vmcnt<2>();
+            else if (young == 1) wait_vmcnt<1>();
             else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // A: ... and everyone's share of the images of tile s is written
             if (s + 2 < nsteps) issue_p(s + 2);          // into the P stage step s-1 read
             if (s + 3 < nsteps) issue_c(s + 3);          // into the code buffer the expansion of step s-1 consumed
             const char* st = smem + (s % 3) * QC_PST;
             const char* sq = smem + QC_QIMG;
-            bf16x8 qf[2][TNT];
+            bf16x8 qf[TQ][TNT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < TQ; ++t)
 #pragma unroll
                 for (int j = 0; j < TNT; ++j) qf[t][j] = tr_frag<QROWB>(sq + t * IMGQ, 0, wn * (16 * TNT) + 16 * j, lane);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B: every wave holds its Q fragments: the images are free
@@ -1533,16 +1617,17 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
                     if (i < NEXP) lookup(s + 1, i);
                 }
                 const bf16x8 ph = tr_frag<PROWB>(st, 0, wm * (16 * TM) + 16 * i, lane);
-                const bf16x8 pl = tr_frag<PROWB>(st + IMGP, 0, wm * (16 * TM) + 16 * i, lane);
+                bf16x8 pl = ph;
+                if constexpr (TP == 2) pl = tr_frag<PROWB>(st + IMGP, 0, wm * (16 * TM) + 16 * i, lane);
                 if (do_bias) {
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ones, accb[i], 0, 0, 0);
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, ones, accb[i], 0, 0, 0);
+                    accb[i] = mm(ph, ones, accb[i]);
+                    if constexpr (TP == 2) accb[i] = mm(pl, ones, accb[i]);
                 }
 #pragma unroll
                 for (int j = 0; j < TNT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, qf[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mm(ph, qf[0][j], acc[i][j]);
+                    if constexpr (TP == 2) acc[i][j] = mm(pl, qf[0][j], acc[i][j]);
+                    if constexpr (TQ == 2) acc[i][j] = mm(ph, qf[1][j], acc[i][j]);
                 }
             }
         }
@@ -1566,20 +1651,21 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
 #pragma unroll
             for (int t = 0; t < TQ; ++t)
 #pragma unroll
-                for (int j = 0; j < TNT; ++j) qf[t][j] = tr_frag<QROWB>(st + 2 * IMGP + t * IMGQ, 32 * kk, wn * (16 * TNT) + 16 * j, lane);
+                for (int j = 0; j < TNT; ++j) qf[t][j] = tr_frag<QROWB>(st + TP * IMGP + t * IMGQ, 32 * kk, wn * (16 * TNT) + 16 * j, lane);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bf16x8 ph = tr_frag<PROWB>(st, 32 * kk, wm * (16 * TM) + 16 * i, lane);
-                const bf16x8 pl = tr_frag<PROWB>(st + IMGP, 32 * kk, wm * (16 * TM) + 16 * i, lane);
+                bf16x8 pl = ph;
+                if constexpr (TP == 2) pl = tr_frag<PROWB>(st + IMGP, 32 * kk, wm * (16 * TM) + 16 * i, lane);
                 if (do_bias) {
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, ones, accb[i], 0, 0, 0);
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, ones, accb[i], 0, 0, 0);
+                    accb[i] = mm(ph, ones, accb[i]);
+                    if constexpr (TP == 2) accb[i] = mm(pl, ones, accb[i]);
                 }
 #pragma unroll
                 for (int j = 0; j < TNT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, qf[0][j], acc[i][j], 0, 0, 0);
-                    if constexpr (TQ == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, qf[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mm(ph, qf[0][j], acc[i][j]);
+                    if constexpr (TP == 2) acc[i][j] = mm(pl, qf[0][j], acc[i][j]);
+                    if constexpr (TQ == 2) acc[i][j] = mm(ph, qf[1][j], acc[i][j]);
                 }
             }
         }
@@ -1587,7 +1673,8 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
 
     }   // !QC
     // ---- epilogue: scale, weight-FQ STE mask, accumulate
-    const float alpha = p.s1 ? *p.s1 : 1.f;
+    const float bscale = p.s2 ? *p.s2 : 1.f;   // (exactly 1 without s2: the bf16-pair form keeps its bits)
+    const float alpha = (p.s1 ? *p.s1 : 1.f) * bscale;
     const int r = lane & 15, g = lane >> 4;
     if (p.partial) {
         // raw accumulators in their register layout, one float4 per lane per fragment: 1-KiB coalesced stores, no atomics;
@@ -1600,7 +1687,7 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int n = n0 + wm * (16 * TM) + 16 * i + 4 * g + e;
-                    if (n < p.N) atomicAdd(&p.dbias[n], accb[i][e] * (p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f));
+                    if (n < p.N) atomicAdd(&p.dbias[n], accb[i][e] * bscale * (p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f));
                 }
         }
         float4* dst = reinterpret_cast<float4*>(p.partial) + ((int64_t)vb * NW + wave) * (TM * TNT * 64);
@@ -1617,7 +1704,7 @@ __global__ __launch_bounds__(WM * WNK * 64) void k_gemm_tn(const TNArgs p) {
             const int n = n0 + wm * (16 * TM) + 16 * i + 4 * g + e;
             if (n >= p.N) continue;
             const float rdiv = p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f;
-            if (do_bias && r == 0) atomicAdd(&p.dbias[n], accb[i][e] * rdiv);
+            if (do_bias && r == 0) atomicAdd(&p.dbias[n], accb[i][e] * bscale * rdiv);
             float inv = 0.f, fzp = 0.f;
             if (p.W) {
                 const int ci = p.w_per_channel ? n : 0;
@@ -1671,7 +1758,7 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, i
         wzp[e] = wzpp[ci];
         rdv[e] = rdp[p.row_div ? n : 0];
     }
-    const float alpha = p.s1 ? *p.s1 : 1.f;
+    const float alpha = (p.s1 ? *p.s1 : 1.f) * (p.s2 ? *p.s2 : 1.f);
     // four splits' loads in flight per thread; the additions stay in split order (bit-reproducible)
     const int64_t sstride = (int64_t)p.tiles * per_tile;
     float4 a = src[0];
@@ -1727,14 +1814,18 @@ static TNArgs tn_args(const void* P_hi, const void* P_lo, const void* Q_hi, cons
     return a;
 }
 
-int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
-                   const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
-                   float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
+// DY16: P_hi is the one fp16 plane (P_lo unused), Q holds fp16 bit patterns, *s2 the plane's inverse scale
+template <bool DY16>
+static int gemm_tn_impl(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                        const float* s1, const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
+                        float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
     if (M < 1 || N % 128 != 0 || Kw % 128 != 0 || ldp % 8 != 0 || ldq % 8 != 0) {
         set_error("gemm_tn: unsupported shape M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%128==0, ld%%8==0)", M, N, Kw, ldp, ldq);
         return 1;
     }
-    TNArgs a = tn_args(P_hi, P_lo, Q_hi, Q_lo, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div);
+    constexpr int TP = DY16 ? 1 : 2;
+    TNArgs a = tn_args(P_hi, DY16 ? P_hi : P_lo, Q_hi, Q_lo, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div);
+    a.s2 = s2;
     // Kw-panel-wide tiles (128 x 384) read the heavy operand P = dY (hi, lo) once per N tile when Kw = 384; every Kw of ViT-S/B (384, 1536, 768, 3072)
     // is a multiple of 384.  (Measured at B=256: wide wins for a grid Q operand, 110/133 us vs 113/148; with a split Q (32-row steps) it wins when
     // there are enough wide tiles - fc2 wgrad, 12 tiles: 169 vs 181 us - and loses when few tiles mean many splits - proj wgrad, 3 tiles: 84 vs 56 us)
@@ -1745,17 +1836,26 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     const int grid = tiles * splits;
 #define QV_TN_LAUNCH(TQ_, NS_, WM_, WNK_, TNT_, BK_)                                                               \
     do {                                                                                                           \
-        constexpr size_t lds = (size_t)NS_ * (2 * BK_ * 256 + TQ_ * BK_ * (WNK_ * TNT_ * 32));                      \
+        constexpr size_t lds = (size_t)NS_ * (TP * BK_ * 256 + TQ_ * BK_ * (WNK_ * TNT_ * 32));                     \
+        static_assert(lds <= 160 * 1024, "LDS");                                                                   \
         constexpr int tm = 128 / WM_ / 16;                                                                         \
         const int64_t tile_f4 = (int64_t)WM_ * WNK_ * tm * TNT_ * 64;                                              \
         const bool two_phase = partial && splits > 1 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;             \
         a.partial = two_phase ? partial : nullptr;                                                                 \
-        static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_>, lds), true);                      \
+        static bool once = (allow_lds(k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, false, TP, DY16>, lds), true);     \
         (void)once;                                                                                                \
-        k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);                          \
+        k_gemm_tn<TQ_, NS_, WM_, WNK_, TNT_, BK_, false, TP, DY16><<<grid, WM_ * WNK_ * 64, lds, st>>>(a);         \
         if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, WM_, WNK_, tm, TNT_); \
     } while (0)
-    if (wide) {
+    if constexpr (DY16) {   // one P plane: the stages are 8 KiB (wide) / 16 KiB (narrow) smaller, the rings one stage deeper
+        if (wide) {
+            if (Q_lo) QV_TN_LAUNCH(2, 2, 2, 4, 6, 32);   // 2 x (8 + 48) KiB = 112 KiB
+            else QV_TN_LAUNCH(1, 5, 2, 4, 6, 32);        // 5 x (8 + 24) KiB = 160 KiB
+        } else {
+            if (Q_lo) QV_TN_LAUNCH(2, 3, 4, 2, 4, 64);   // 3 x 48 KiB
+            else QV_TN_LAUNCH(1, 4, 4, 2, 4, 64);        // 4 x 32 KiB
+        }
+    } else if (wide) {
         if (Q_lo) QV_TN_LAUNCH(2, 2, 2, 4, 6, 32);   // 2 x (16 + 48) KiB = 128 KiB
         else QV_TN_LAUNCH(1, 4, 2, 4, 6, 32);        // 4 x (16 + 24) KiB = 160 KiB: three 32-token tiles in flight (2 x 64-token stages: 117.5 -> 109 us)
     } else {
@@ -1766,30 +1866,62 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
     return 0;
 }
 
+int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                   const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
+                   float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
+    return gemm_tn_impl<false>(P_hi, P_lo, Q_hi, Q_lo, C, M, N, Kw, ldp, ldq, ldc, s1, nullptr, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div,
+                               st, partial, partial_bytes);
+}
+int launch_gemm_tn_dy16(const void* P16, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s1,
+                        const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
+                        const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
+    return gemm_tn_impl<true>(P16, nullptr, Q_hi, Q_lo, C, M, N, Kw, ldp, ldq, ldc, s1, s2, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div, st,
+                              partial, partial_bytes);
+}
+
 // Weight gradient with the Q operand as uint8 table indices + a 256-entry table of bf16 (hi | lo << 16) pairs (fc2: Q = gelu(fq(fc1 output))): the
 // 128 x 384 tile of launch_gemm_tn's split-Q form, the same MFMAs in the same order - bit-identical to it on the expanded planes.
-int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
-                         const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
-                         const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
-    if (M < 1 || N % 128 != 0 || Kw % 384 != 0 || ldp % 8 != 0 || ldq % 16 != 0 || !P_hi || !P_lo || !Qc || !lutQ || !C) {
+template <bool DY16, int TQ = 2>   // TQ = 1 (one-plane form only): the hi half of every table entry alone - X rounded to fp16, one MFMA pass
+static int gemm_tn_codes_impl(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                              const float* s1, const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
+                              float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
+    if (M < 1 || N % 128 != 0 || Kw % 384 != 0 || ldp % 8 != 0 || ldq % 16 != 0 || !P_hi || (!DY16 && !P_lo) || !Qc || !lutQ || !C) {
         set_error("gemm_tn_codes: unsupported arguments M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%384==0, ldp%%8==0, ldq%%16==0)", M, N, Kw, ldp, ldq);
         return 1;
     }
-    TNArgs a = tn_args(P_hi, P_lo, nullptr, nullptr, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div);
-    a.Qc = reinterpret_cast<const uint8_t*>(Qc); a.lutQ = lutQ;
+    constexpr int TP = DY16 ? 1 : 2;
+    TNArgs a = tn_args(P_hi, DY16 ? P_hi : P_lo, nullptr, nullptr, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div);
+    a.Qc = reinterpret_cast<const uint8_t*>(Qc); a.lutQ = lutQ; a.s2 = s2;
     const int tiles = (N / 128) * (Kw / 384);
     const int splits = tn_plan(a, M, 32, tiles);
     const int grid = tiles * splits;
-    constexpr size_t lds = 3 * (2 * 32 * 256) + (2 * 32 * 768) + 3 * (32 * 384) + 1024;   // 133 KiB
+    constexpr size_t lds = 3 * (TP * 32 * 256) + (TQ * 32 * 768) + 3 * (32 * 384) + 1024;   // 133 KiB (one P plane: 109 KiB; one Q plane too: 85 KiB)
     constexpr int tm = 4;
     const int64_t tile_f4 = (int64_t)2 * 4 * tm * 6 * 64;
     const bool two_phase = partial && splits > 1 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;
     a.partial = two_phase ? partial : nullptr;
-    static bool once = (allow_lds(k_gemm_tn<2, 2, 2, 4, 6, 32, true>, lds), true);
+    static bool once = (allow_lds(k_gemm_tn<TQ, 2, 2, 4, 6, 32, true, TP, DY16>, lds), true);
     (void)once;
-    k_gemm_tn<2, 2, 2, 4, 6, 32, true><<<grid, 512, lds, st>>>(a);
+    k_gemm_tn<TQ, 2, 2, 4, 6, 32, true, TP, DY16><<<grid, 512, lds, st>>>(a);
     if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, 2, 4, tm, 6);
     return 0;
+}
+int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                         const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
+                         const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
+    return gemm_tn_codes_impl<false>(P_hi, P_lo, Qc, lutQ, C, M, N, Kw, ldp, ldq, ldc, s1, nullptr, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias,
+                                     row_div, st, partial, partial_bytes);
+}
+// the one-plane form: P16 = the gradient as one fp16 plane, lutQ16 = the table of fp16 (hi | lo << 16) pairs (what fc2's FORWARD expands the same codes through)
+int launch_gemm_tn_codes_dy16(const void* P16, const void* Qc, const uint32_t* lutQ16, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s1,
+                              const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
+                              const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
+    static const int xpair = getenv("QATVIT_DY16_XPAIR") ? atoi(getenv("QATVIT_DY16_XPAIR")) : 0;   // QATVIT_DY16_XPAIR=1: the float X operands as fp16 (hi, lo) pairs
+    if (!xpair)
+        return gemm_tn_codes_impl<true, 1>(P16, nullptr, Qc, lutQ16, C, M, N, Kw, ldp, ldq, ldc, s1, s2, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias,
+                                           row_div, st, partial, partial_bytes);
+    return gemm_tn_codes_impl<true>(P16, nullptr, Qc, lutQ16, C, M, N, Kw, ldp, ldq, ldc, s1, s2, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div,
+                                    st, partial, partial_bytes);
 }
 
 }  // namespace qv

@@ -91,6 +91,12 @@ __device__ inline uint32_t pk_bf16(float a, float b) {
     const qv_f32x2 v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, qv_bf16x2));
 }
+// two floats -> packed fp16 (round to nearest even): one v_cvt_pk_f16_f32
+typedef _Float16 qv_f16x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pk_f16(float a, float b) {
+    const qv_f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, qv_f16x2));
+}
 __device__ inline void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
     const qv_f32x2 v = {a, b};
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, qv_bf16x2));

@@ -81,6 +81,10 @@ struct NTPost {
     const void* lnb_nmask = nullptr;
     // mode 2 only: the gelu(C) pair as fp16 instead of bf16 (the fp16 teacher forward); out_lo may then be NULL (one-pass form)
     int out_f16 = 0;
+    // launch_gemm_nt_dy16 with mode 8 / 9: the gradient the epilogue emits is ONE fp16 plane (out_hi; out_lo unused) of value * (*o16_mul),
+    // and max |value| is accumulated into o16_amax (dy16.hip: Dy16Slot::amax)
+    const float* o16_mul = nullptr;
+    uint32_t* o16_amax = nullptr;
 };
 
 // ---- gemm.hip  (all operands bf16; a float operand is a (hi, lo) pair, lo == nullptr for a grid operand)
@@ -91,6 +95,13 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
                       hipStream_t st, const NTPost* post = nullptr,
                       const void* B8f = nullptr);   // B8f: the same weight integers in fragment order (launch_w8_fragment_order): enables the strip kernel
+// The one-plane backward ("dY as one fp16 plane"): the dgrad C[M,N] = A16[M,K] . B16[N,K]^T * (*s1) * (*s2) with the gradient
+// operand A16 as ONE fp16 plane pre-scaled by a power of two (its inverse arrives in *s2) and the transposed weight integers B16 as fp16 (exact):
+// one v_mfma_f32_16x16x32_f16 pass, 2 B per gradient element.  post: nullptr (plain fp32 output: proj dgrad), mode 8 (fused LayerNorm backward)
+// or mode 9 (fused GELU backward) with o16_mul / o16_amax set - the masked gradient for the next layer then leaves as one fp16 plane too.
+// N % 384 == 0, K % 32 == 0.
+int launch_gemm_nt_dy16(const void* A16, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1, const float* s2,
+                        hipStream_t st, const NTPost* post = nullptr);
 // ---- i8strip.hip: the K = 384 two-pass forward GEMMs (qkv, fc1), A-stationary; returns true when it covered (and launched) the request
 bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
@@ -113,6 +124,14 @@ int launch_gemm_tn(const void* P_hi, const void* P_lo, const void* Q_hi, const v
 int launch_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
                          const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
                          const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
+// the one-plane forms of the two weight-gradient launchers: P16 = the gradient as ONE fp16 plane scaled by a power of two (*s2 = its inverse; the bias
+// gradient is multiplied by it too), Q = fp16 bit patterns (grid integers, an fp16 (hi, lo) pair, or codes + a table of fp16 pairs); *s1 = Q's scale
+int launch_gemm_tn_dy16(const void* P16, const void* Q_hi, const void* Q_lo, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s1,
+                        const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
+                        const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
+int launch_gemm_tn_codes_dy16(const void* P16, const void* Qc, const uint32_t* lutQ16, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s1,
+                              const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
+                              const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st,
                        void* out8 = nullptr, int center = 0);
@@ -122,9 +141,10 @@ int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const
 // STE mask of an [M, D] tensor as wave ballots: ceil(D / 256) * 4 64-bit words per row (written by launch_resid_fq_lnstats mode 1)
 inline int64_t ln_maskbits_bytes(int64_t M, int D) { return M * ((D + 255) / 256) * 32; }
 // optional second output of launch_ln_bwd_fq: split(dx_out * mask * colscale) for the next branch's GEMMs
-struct LnBwdNext { const void* maskbits; const float* colscale; void* out_hi; void* out_lo; };
+struct LnBwdNext { const void* maskbits; const float* colscale; void* out_hi; void* out_lo; const float* o16_mul = nullptr; uint32_t* o16_amax = nullptr; };   // o16_*: out_hi is ONE fp16 plane (dy16.hip)
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
-                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8 = nullptr, int center = 0);
+                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8 = nullptr, int center = 0,
+                          bool out_f16 = false);   // out_f16: the integers as fp16 bit patterns (X operand of the one-plane weight gradient)
 // inference: LayerNorm + quantise (frozen qparams) in one pass -> int8 (q - center); out8 == nullptr: row statistics only; row_stride > 1: every
 // row_stride-th row (cls tokens)
 int launch_ln_quant8(const float* x, const float* gamma, const float* beta, float eps, const float* qp, int qmin, int qmax, int center, void* out8,
@@ -132,7 +152,7 @@ int launch_ln_quant8(const float* x, const float* gamma, const float* beta, floa
 int launch_cls_rows(const float* cls, const float* pos, float* x, int B, int T, int D, hipStream_t st);
 int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, void* G_hi, void* G_lo, int64_t n, hipStream_t st);
 int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, const float* col_scale, int ncols,
-                    void* dst_hi, void* dst_lo, int64_t n, hipStream_t st);
+                    void* dst_hi, void* dst_lo, int64_t n, hipStream_t st, const float* o16_mul = nullptr, uint32_t* o16_amax = nullptr);
 int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                      const float* qp, int qmin, int qmax, const float* dx_in, float* dx_out, float* dgamma, float* dbeta, int64_t M, int D, int T,
                      int cls_only, hipStream_t st, const LnBwdNext* next = nullptr);
@@ -157,12 +177,27 @@ struct WQuantTab {
     void* w16[kMaxW];   // optional: the same integers as fp16 (B operand of the fp16-pair forward GEMMs: proj, fc2)
     void* w8f[kMaxW];   // optional: the int8 integers once more in fragment order (w8f_offset: B operand of the strip kernel; N % 48 == 0, K % 64 == 0)
     int N[kMaxW], K[kMaxW], blk0[kMaxW + 1]; int n, per_channel, qmin, qmax;
+    int wT16;           // nonzero: every wqT[i] is followed, wT16_gap_bytes(N, K) further on, by the same transposed integers as fp16 (the table itself is at the 4-KiB kernel-argument limit)
 };
+__host__ __device__ inline int64_t wT16_gap_bytes(int N, int K) { return ((int64_t)N * K * 2 + 255) & ~(int64_t)255; }
 int launch_w_observe_all(WObsTab& t, hipStream_t st);      // fills blk0
 int launch_w_qparams_all(WQpTab& t, hipStream_t st);       // fills blk0
 int launch_w_quant_all(WQuantTab& t, hipStream_t st);      // fills blk0
 int launch_zero_i32(int32_t* p, int64_t n, hipStream_t st);
 int launch_wquant(const float* W, const float* qp, int per_channel, int qmin, int qmax, void* wq, void* wqT, int N, int K, hipStream_t st);
+
+// ---- dy16.hip: scale state of the one-plane backward.  Every gradient tensor that feeds a dgrad / wgrad GEMM pair has a slot:
+//   words [kDyAmaxStride * j], j < kDyAmaxSlots: max |value| of this step's tensor as float bits (atomicMax by the producer's waves; non-negative floats
+//   order like their bit patterns), word 1: mul = 2^e the producer multiplies by, word 2: inv = 2^-e the consumers multiply by, word 3: max |value| of
+//   the previous step (float).  Header words: 0 = max |dlogits| of the previous step, 1 = of this step, 2 = overflow flag (some |value| * mul > 65504).
+//   begin: e from the previous step's maximum, rescaled by this step's max |dlogits| over the previous one, such that the predicted maximum lands in
+//   [2^7, 2^8) - 2^8 of headroom to fp16's largest number, 2^21 below it before the first subnormal; end: folds the maxima, raises the flag.
+constexpr int kDyHdrWords = 64, kDySlotWords = 256, kDyAmaxStride = 32, kDyAmaxSlots = 8;
+inline int64_t dy16_state_bytes(int nslots) { return 4ll * (kDyHdrWords + (int64_t)nslots * kDySlotWords); }
+int launch_dy16_begin(uint32_t* state, int nslots, const float* dlogits, int n_dlogits, hipStream_t st);   // dlogits == nullptr: no rescaling
+int launch_dy16_end(uint32_t* state, int nslots, int check_overflow, hipStream_t st);
+int launch_absmax_bf16(const void* hi, int64_t n, uint32_t* amax, hipStream_t st);      // calibration: max |hi part| of a bf16 (hi, lo) pair, n % 8 == 0
+int launch_f16int_to_bf16int(void* plane, int64_t n, hipStream_t st);                  // fallback: grid integers stored as fp16 -> bf16, in place, n % 8 == 0
 
 // ---- attn.hip
 int attn_padded_tokens(int T);
@@ -172,6 +207,9 @@ int launch_attn_fwd(const float* qkv, const float* qp, int qmin, int qmax, int B
                     void* cmask = nullptr);   // codes / cmask (optional): uint8 clamp(q) - qmin [B*T, 3D] and the STE mask bits [B*T, 3D/8], for the backward
 int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B, int T, int H, int D, const void* O_hi, const void* O_lo,
                     const float* lse, float* delta, const float* dO, void* dqkv_hi, void* dqkv_lo, const float* col_scale, hipStream_t st,
-                    const void* codes = nullptr, const void* cmask = nullptr);   // with the forward's codes the pre-FQ qkv is not read at all
+                    const void* codes = nullptr, const void* cmask = nullptr,   // with the forward's codes the pre-FQ qkv is not read at all
+                    const float* o16_mul = nullptr, uint32_t* o16_amax = nullptr);   // the one-plane form: dqkv_hi = ONE fp16 plane (fused kernel only)
+// true where launch_attn_bwd takes the fused kernel (the only one with the one-plane output)
+bool attn_bwd_is_fused(int T, int H, int D, bool codes);
 
 }  // namespace qv

@@ -18,6 +18,8 @@ no ``drop_last``, qat_trainer.py:228-254) runs inside it without any allocation 
 from __future__ import annotations
 
 import ctypes
+import os
+import warnings
 import weakref
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -28,6 +30,15 @@ from torch.ao.quantization.fake_quantize import FusedMovingAvgObsFakeQuantize
 from . import native
 
 STAGE_INJECT = 1  # QATVIT_STAGE_INJECT
+FWD_X16 = 2       # QATVIT_FWD_X16
+BWD_DY16 = 2      # QATVIT_BWD_DY16
+BWD_CALIBRATE = 4  # QATVIT_BWD_CALIBRATE
+
+
+def dy16_default() -> bool:
+    """QATVIT_DY16=0 keeps every backward in the bf16 (hi, lo) pair form (round 3's arithmetic); default: the one-plane form where the
+    configuration allows it (include/qatvit.h, QATVIT_BWD_DY16)."""
+    return os.environ.get("QATVIT_DY16", "1") != "0"
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -230,6 +241,12 @@ class StudentEngine:
         self.capacity = 0
         self.workspace: Optional[torch.Tensor] = None
         self._pins = 0                           # live captured hipGraphs: the workspace address must not change under them
+        # the one-plane backward (include/qatvit.h, QATVIT_BWD_DY16): on when the configuration allows it; the scale history lives in the
+        # workspace, so a fresh workspace starts with one calibrating (pair-form) step
+        self.dy16 = dy16_default() and bool(self.lib.qatvit_student_dy16_supported(ctypes.byref(self.cfg)))
+        self._dy16_calibrated = False
+        self._fwd_x16 = False                    # how the most recent forward wrote h1q / h2q
+        self.dy16_fallbacks = 0                  # backward passes repeated in the pair form after an overflow
         self._reserve(batch)
         # ---- flat gradient buffer, laid out in backward-stage order so that finished buckets are contiguous
         self.layout = FlatGradLayout([p.numel() for p in ps], self.cfg.depth)
@@ -274,6 +291,9 @@ class StudentEngine:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         native.check(L.qatvit_student_init(cp, self.workspace.data_ptr(), native.stream_ptr()), "qatvit_student_init")
         self.capacity = batch
+        self._dy16_calibrated = False
+        off = L.qatvit_student_tensor_offset(cp, b"dy16", 0)
+        self._dy16_flag = self.workspace[off + 8:off + 12].view(torch.int32)   # header word 2: overflow
 
     # ------------------------------------------------------------------ FQ state arena
     def _rehome_fq_state(self):
@@ -325,8 +345,11 @@ class StudentEngine:
         images = images.contiguous()
         logits = torch.empty(c.batch, c.num_classes, dtype=torch.float32, device=self.device)
         self.generation += 1
-        native.check(self.lib.qatvit_student_forward(ctypes.byref(c), self._ptr_params, self._act_structs, self._w_structs, images.data_ptr(),
-                                                     logits.data_ptr(), self.workspace.data_ptr(), native.stream_ptr()), "qatvit_student_forward")
+        # a training forward of a calibrated engine leaves the X operands of the qkv / fc1 weight gradients as fp16 integers: its backward is one-plane
+        self._fwd_x16 = self.dy16 and self._dy16_calibrated and self.sync_state
+        native.check(self.lib.qatvit_student_forward_stages(ctypes.byref(c), self._ptr_params, self._act_structs, self._w_structs, images.data_ptr(),
+                                                            logits.data_ptr(), self.workspace.data_ptr(), 0, c.depth + 1, FWD_X16 if self._fwd_x16 else 0,
+                                                            native.stream_ptr()), "qatvit_student_forward")
         return logits
 
     def _grad_buffers(self):
@@ -335,21 +358,57 @@ class StudentEngine:
         gptr = (ctypes.c_void_p * len(views))(*[v.data_ptr() for v in views])
         return flat, views, gptr
 
-    def backward(self, dlogits: torch.Tensor, cfg: Optional[native.Cfg] = None):
-        c = cfg if cfg is not None else self.cfg
-        dlogits = dlogits.contiguous()
+    def _run_backward(self, dlogits: torch.Tensor, c: native.Cfg, flags: int):
         flat, views, gptr = self._grad_buffers()
         L, cp, st = self.lib, ctypes.byref(c), native.stream_ptr()
 
         def run(s0, s1):
-            native.check(L.qatvit_student_backward(cp, self._ptr_params, self._act_structs, self._w_structs, dlogits.data_ptr(), gptr,
-                                                   self.workspace.data_ptr(), s0, s1, st), "qatvit_student_backward")
+            native.check(L.qatvit_student_backward_stages(cp, self._ptr_params, self._act_structs, self._w_structs, dlogits.data_ptr(), gptr,
+                                                          self.workspace.data_ptr(), s0, s1, flags, st), "qatvit_student_backward")
 
         if self.pg is None:
             run(0, self.layout.last_stage)
         else:
             staged_backward_allreduce(flat, self.layout, self.bucket_bytes, self.pg, run)
         return views
+
+    def dy16_overflowed(self) -> bool:
+        """Did the last one-plane backward meet a gradient that did not fit its fp16 plane?  Blocks on the stream; in a data-parallel group the
+        answer is agreed on (MAX over the ranks) so that every rank repeats the backward, and its collectives, or none does."""
+        flag = self._dy16_flag
+        if self.pg is not None:
+            flag = flag.clone()
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.pg)
+        return bool(flag.item())
+
+    def backward(self, dlogits: torch.Tensor, cfg: Optional[native.Cfg] = None, x16: Optional[bool] = None):
+        c = cfg if cfg is not None else self.cfg
+        dlogits = dlogits.contiguous()
+        x16 = self._fwd_x16 if x16 is None else x16
+        if not self.dy16:
+            return self._run_backward(dlogits, c, 0)
+        if not x16:                                     # first step on this workspace: the pair form, recording every gradient tensor's maximum
+            views = self._run_backward(dlogits, c, BWD_CALIBRATE)
+            self._dy16_calibrated = True
+            return views
+        views = self._run_backward(dlogits, c, BWD_DY16)
+        if torch.cuda.is_current_stream_capturing():    # a hipGraph capture cannot ask: GraphedStudentStep checks after each replay
+            return views
+        if self.dy16_overflowed():
+            views = self.dy16_fallback(dlogits, c)
+        return views
+
+    def dy16_fallback(self, dlogits: torch.Tensor, c: native.Cfg):
+        """The scales predicted from the previous step did not hold (the flag is raised when max |value| * 2^e > 65504): the same backward again in
+        the pair form - bit-identical to a step that never left it - which also re-records the maxima."""
+        self.dy16_fallbacks += 1
+        if self.dy16_fallbacks == 1:
+            warnings.warn("qat-vit_amd: a gradient outgrew its fp16 plane (scale predicted from the previous step); this backward was repeated in the "
+                          "bf16-pair form. Harmless if rare (engine.dy16_fallbacks counts them); QATVIT_DY16=0 keeps the pair form throughout.",
+                          RuntimeWarning, stacklevel=3)
+        native.check(self.lib.qatvit_student_dy16_to_pair(ctypes.byref(c), self.workspace.data_ptr(), native.stream_ptr()), "qatvit_student_dy16_to_pair")
+        self._fwd_x16 = False
+        return self._run_backward(dlogits, c, BWD_CALIBRATE)
 
     # ------------------------------------------------------------------ stage-level access (parity tests, include/qatvit.h "stages")
     def tensor(self, name: str, block: int, shape, dtype=torch.float32, cfg: Optional[native.Cfg] = None) -> torch.Tensor:
@@ -364,31 +423,32 @@ class StudentEngine:
         return self.workspace[off:off + n * torch.empty((), dtype=dtype).element_size()].view(dtype).view(*shape)
 
     def forward_stages(self, images: Optional[torch.Tensor], stage_from: int, stage_to: int, inject: bool = False,
-                       logits: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                       logits: Optional[torch.Tensor] = None, x16: bool = False) -> Optional[torch.Tensor]:
         c = self.cfg
         if stage_to == c.depth + 1 and logits is None:
             logits = torch.empty(c.batch, c.num_classes, dtype=torch.float32, device=self.device)
         self.generation += 1
         native.check(self.lib.qatvit_student_forward_stages(
             ctypes.byref(c), self._ptr_params, self._act_structs, self._w_structs, images.data_ptr() if images is not None else None,
-            logits.data_ptr() if logits is not None else None, self.workspace.data_ptr(), stage_from, stage_to, STAGE_INJECT if inject else 0,
-            native.stream_ptr()), "qatvit_student_forward_stages")
+            logits.data_ptr() if logits is not None else None, self.workspace.data_ptr(), stage_from, stage_to,
+            (STAGE_INJECT if inject else 0) | (FWD_X16 if x16 else 0), native.stream_ptr()), "qatvit_student_forward_stages")
         return logits
 
-    def forward_part(self, block: int, part: int, inject: bool = False) -> None:
+    def forward_part(self, block: int, part: int, inject: bool = False, x16: bool = False) -> None:
         """qatvit_student_forward_part: part 0 / 1 / 2 of one block (inputs: x_in / pre-FQ qkv / x_mid of that block)."""
         self.generation += 1
         native.check(self.lib.qatvit_student_forward_part(ctypes.byref(self.cfg), self._ptr_params, self._act_structs, self._w_structs,
-                                                          self.workspace.data_ptr(), block, part, STAGE_INJECT if inject else 0, native.stream_ptr()),
+                                                          self.workspace.data_ptr(), block, part, (STAGE_INJECT if inject else 0) | (FWD_X16 if x16 else 0),
+                                                          native.stream_ptr()),
                      "qatvit_student_forward_part")
 
-    def backward_stages(self, dlogits: Optional[torch.Tensor], stage_from: int, stage_to: int, inject: bool = False):
-        """Returns per-parameter gradient views (zero for the stages that did not run)."""
+    def backward_stages(self, dlogits: Optional[torch.Tensor], stage_from: int, stage_to: int, inject: bool = False, mode: int = 0):
+        """Returns per-parameter gradient views (zero for the stages that did not run).  mode: 0 (pair form), BWD_CALIBRATE or BWD_DY16."""
         c = self.cfg
         flat, views, gptr = self._grad_buffers()
         native.check(self.lib.qatvit_student_backward_stages(
             ctypes.byref(c), self._ptr_params, self._act_structs, self._w_structs, dlogits.contiguous().data_ptr() if dlogits is not None else None,
-            gptr, self.workspace.data_ptr(), stage_from, stage_to, STAGE_INJECT if inject else 0, native.stream_ptr()), "qatvit_student_backward_stages")
+            gptr, self.workspace.data_ptr(), stage_from, stage_to, (STAGE_INJECT if inject else 0) | mode, native.stream_ptr()), "qatvit_student_backward_stages")
         return views
 
 
@@ -399,6 +459,7 @@ class _StudentStep(torch.autograd.Function):
         out = engine.forward(images)
         ctx.generation = engine.generation
         ctx.step_cfg = engine.cfg
+        ctx.x16 = engine._fwd_x16
         return out
 
     @staticmethod
@@ -418,7 +479,7 @@ class _StudentStep(torch.autograd.Function):
                 "saved activations of ONE forward per model. Call backward() before the next forward (gradient accumulation: "
                 "forward/backward per micro-batch)."
             )
-        grads = eng.backward(dlogits, ctx.step_cfg)
+        grads = eng.backward(dlogits, ctx.step_cfg, ctx.x16)
         for p, g in zip(eng.params, grads):
             if p.grad is None:
                 p.grad = g

@@ -52,6 +52,7 @@ class GraphedStudentStep:
             self.engine = None
             raise
         self._grads = [p.grad for p in model.parameters()]   # from here on the pin lasts as long as this object (close() / __del__ release it)
+        self._x16 = eng._fwd_x16                   # the captured backward is the one-plane form: its overflow flag is read after every replay
 
     def close(self) -> None:
         """Drops the graph and releases THIS object's pin on the engine's workspace (idempotent).  The pin is a count on the engine: a
@@ -93,4 +94,13 @@ class GraphedStudentStep:
         for p, g in zip(self.model.parameters(), self._grads):   # zero_grad(set_to_none=True) in the loop must not drop the static buffers
             p.grad = g
         self.graph.replay()
+        if self._x16 and self.engine.dy16_overflowed():
+            # a gradient outgrew its fp16 plane (engine.backward asks this itself in eager mode; a capture cannot): the backward again, eagerly, in the
+            # pair form, from the logits the replay left - into the buffers .grad points at
+            out = self.out.detach().requires_grad_(True)
+            with torch.enable_grad():
+                loss, _ = F.kd_ce_loss(out, self.t, self.y, *self.hp)
+                (dlogits,) = torch.autograd.grad(loss, out)
+            for g, v in zip(self._grads, self.engine.dy16_fallback(dlogits, self.engine.cfg)):
+                g.copy_(v)
         return self.out, self.loss, self.parts

@@ -39,6 +39,8 @@ SIGNATURES = {
     "qatvit_gemm_tn_scratch_bytes": (c_int64, []),
     "qatvit_gemm_tn": (c_int, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
     "qatvit_gemm_tn_codes": (c_int, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
+    "qatvit_gemm_nt_dy16": (c_int, [c_void_p] * 3 + [c_int32] * 6 + [c_void_p] * 3),
+    "qatvit_gemm_tn_dy16": (c_int, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p] * 5 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
     "qatvit_attn_padded_tokens": (c_int32, [c_int32]),
     "qatvit_attn_forward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 4),
     "qatvit_attn_forward_f16": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 9),
@@ -54,6 +56,8 @@ SIGNATURES = {
     "qatvit_student_forward_part": (c_int, [c_void_p] * 5 + [c_int32, c_int32, c_int32, c_void_p]),
     "qatvit_student_backward_stages": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
     "qatvit_student_tensor_offset": (c_int64, [c_void_p, c_char_p, c_int32]),
+    "qatvit_student_dy16_supported": (c_int32, [c_void_p]),
+    "qatvit_student_dy16_to_pair": (c_int, [c_void_p, c_void_p, c_void_p]),
     "qatvit_teacher_workspace_bytes": (c_int64, [c_void_p]),
     "qatvit_teacher_forward": (c_int, [c_void_p] * 8),
     "qatvit_teacher_forward_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -99,7 +103,7 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library drift
             fn.restype, fn.argtypes = res, args
-        if L.qatvit_abi_version() != 3:
+        if L.qatvit_abi_version() != 4:
             raise RuntimeError("libqatvit.so ABI version mismatch")
         _lib = L
     return _lib

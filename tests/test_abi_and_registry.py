@@ -22,7 +22,7 @@ def test_header_symbols_exported(native_lib):
     assert names == set(native.SIGNATURES), names ^ set(native.SIGNATURES)
     for n in names:
         assert getattr(native_lib, n) is not None
-    assert native_lib.qatvit_abi_version() == 3
+    assert native_lib.qatvit_abi_version() == 4
     assert native_lib.qatvit_target_arch() == b"gfx950"
     assert native_lib.qatvit_fq_workspace_bytes(1) >= 24
 

@@ -228,9 +228,9 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
             tb.codes(st, "attn.qkv", qkv_ints(eng, i, fqm[f"{pre}.attn.qkv.{A}"]), tr.codes(f"{pre}.attn.qkv.{A}").reshape(M, 3 * D), lim)
             o = eng.tensor("O_hi", i, (M, D), torch.bfloat16).float() + eng.tensor("O_lo", i, (M, D), torch.bfloat16).float()
             tb.close(st, "attention out (bf16 pair, bwd)", o, tr.proj_in[i].reshape(M, D), tol)
-            if f16:   # the fp16 (hi, lo) pair the proj forward GEMM actually read (one buffer shared by all blocks: this block's)
-                sc = eng.tensor("scal16", 0, (2,))
-                o16 = (eng.tensor("O16_hi", 0, (M, D), torch.float16).float() + eng.tensor("O16_lo", 0, (M, D), torch.float16).float()) * sc[0]
+            if f16:   # the fp16 (hi, lo) pair the proj forward GEMM actually read (per block: the one-plane proj weight gradient reads it again)
+                sc = eng.tensor("scal16", i, (2,))
+                o16 = (eng.tensor("O16_hi", i, (M, D), torch.float16).float() + eng.tensor("O16_lo", i, (M, D), torch.float16).float()) * sc[0]
                 tb.close(st, "attention out (fp16 pair, fwd)", o16, tr.proj_in[i].reshape(M, D), tol)
             yp = eng.tensor("Yproj", i, (M, D))
             tb.close(st, "attn.proj pre-FQ", yp, tr.pre(f"{pre}.attn.proj.{A}").reshape(M, D), tol)
@@ -259,13 +259,13 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
                 gl = eng.tensor("G_hi", i, (M, Hd), torch.bfloat16).float() + eng.tensor("G_lo", i, (M, Hd), torch.bfloat16).float()
                 tb.close(st, "gelu out (bf16 pair, bwd)", gl, tr.fc2_in[i].reshape(M, Hd), tol)
             if f16 and fc2_codes:   # what the fc2 forward GEMM reads: one byte per element + the 256-entry table of fp16 (hi, lo) pairs
-                sc = eng.tensor("scal16", 0, (2,))
+                sc = eng.tensor("scal16", i, (2,))
                 lut = eng.tensor("glut", i, (256,), torch.int32)
                 pair = (lut & 0xffff).to(torch.int16).view(torch.float16).float() + ((lut >> 16) & 0xffff).to(torch.int16).view(torch.float16).float()
                 g16 = pair[eng.tensor("G8", i, (M, Hd), torch.uint8).long()] * sc[1]
                 tb.close(st, "gelu out (codes + fp16 pair table, fwd)", g16, tr.fc2_in[i].reshape(M, Hd), tol)
             elif f16:
-                sc = eng.tensor("scal16", 0, (2,))
+                sc = eng.tensor("scal16", i, (2,))
                 g16 = (eng.tensor("G16_hi", 0, (M, Hd), torch.float16).float() + eng.tensor("G16_lo", 0, (M, Hd), torch.float16).float()) * sc[1]
                 tb.close(st, "gelu out (fp16 pair, fwd)", g16, tr.fc2_in[i].reshape(M, Hd), tol)
         if part == 3 or (part == 2 and not split_fc2):
@@ -361,7 +361,7 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
             else:
                 eng.tensor("G16_hi", 0, (M, Hd), torch.float16).copy_(g16h)
                 eng.tensor("G16_lo", 0, (M, Hd), torch.float16).copy_((gs - g16h.float()).to(torch.float16))
-            eng.tensor("scal16", 0, (2,))[1] = 2.0 ** -kexp
+            eng.tensor("scal16", i, (2,))[1] = 2.0 ** -kexp
         reset_act_observers([7 + 6 * i])
         eng.forward_part(i, 3, inject=True)
         cmp_part(tab, st, i, 3)
@@ -411,10 +411,35 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
     v = eng.backward_stages(None, depth + 1, depth + 1, inject=True)
     check_grads("bwd embed", v, range(0, 4))
     assert len(names) == n_par
+    # ---- the same block stages in the ONE-PLANE form (include/qatvit.h QATVIT_BWD_DY16: every dY an fp16 plane, one MFMA pass per GEMM): per stage a
+    # calibrating pair-form run on the same injected gradient (records the maxima the scales come from), then the one-plane run, same bars
+    tab16 = Table()
+    if eng.dy16:
+        for s in range(1, depth + 1):
+            i = depth - s
+            if i not in blocks:
+                continue
+            for nm in ("h1q", "h2q"):   # the X operand of the qkv / fc1 weight gradients as fp16 integers (what a QATVIT_FWD_X16 forward writes)
+                hq = eng.tensor(nm, i, (M, D), torch.bfloat16)
+                hq.view(torch.float16).copy_(hq.float().to(torch.float16))
+            dxA.copy_(tr.g_block_in[i + 1].reshape(M, D).cuda())
+            eng.backward_stages(None, s, s, inject=True, mode=E.BWD_CALIBRATE)   # (its weight gradients read the fp16 planes as bf16: discarded)
+            dxA.copy_(tr.g_block_in[i + 1].reshape(M, D).cuda())
+            v = eng.backward_stages(None, s, s, inject=True, mode=E.BWD_DY16)
+            assert not eng.dy16_overflowed()
+            for k in range(4 + 12 * i, 4 + 12 * i + 12):
+                tab16.close(f"bwd block{i}", "d " + name_of[k].replace("model.", ""), v[k], tr.grads[name_of[k]])
+            tab16.close(f"bwd block{i}", f"d x_in[{i}]", dxA, tr.g_block_in[i].reshape(M, D))
+        with open(os.path.join(ROOT, "gpurun_out", f"round4_stage_table_dy16_{golden_tag}.txt"), "w") as f:
+            f.write(f"# one-plane backward (QATVIT_BWD_DY16), teacher-forced block stages, {arch} batch {B}, {backend}: native stage on the oracle's input vs the oracle\n")
+            for st, n, k, ne, val, _ in tab16.rows:
+                f.write(f"{st:<14}{n:<34}{k:<8}{ne:>12}{val:>14.3e}\n")
+            f.write(f"\nworst rel L2 {max(r[4] for r in tab16.rows):.2e} (pair form, same stages: {max(r[4] for r in tab.rows if r[0].startswith('bwd block')):.2e})\n")
     path = os.path.join(ROOT, "gpurun_out", f"round3_stage_flip_table_{golden_tag}.txt")
     tab.write(path, f"# teacher-forced stage parity, {arch} batch {B}, {backend} qconfig, {'KD' if teacher else 'CE only'}; native stage on the oracle's input vs the oracle "
                     f"(torch {torch.__version__} CPU eager QAT); produced by tests/test_gpu_stage_parity.py")
     tab.check()
+    tab16.check()
     assert not coarse_bad, ("one injection per block: rows beyond 3x the largest stock-torch-on-this-GPU deviation of that tensor", coarse_bad[:8], n_within, n_cmp)
     assert n_within >= 0.8 * n_cmp, (n_within, n_cmp)
     return tab
