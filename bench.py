@@ -205,11 +205,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
 
-        tmo = datetime.timedelta(seconds=float(os.environ.get("BENCH_DIST_TIMEOUT_S", "180")))   # a dead peer ends the run in minutes, not in c10d's default 10 - 30
+        # a dead peer ends the run in minutes, not in c10d's default 10 - 30.  The limit also covers the rank-0-only sections (per-kernel legs' bookkeeping,
+        # hbm_kernel_rates: seconds) during which the other ranks already wait in the next collective - hence minutes, not seconds
+        tmo = datetime.timedelta(seconds=float(os.environ.get("BENCH_DIST_TIMEOUT_S", "600")))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
             dist.init_process_group(backend, timeout=tmo)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
     import qat_vit_amd
     from qat_vit_amd import functional as F
@@ -265,6 +269,33 @@ def main():
 
     dt = timed_steps(step, args.steps, args.warmup, world, dev)     # the headline: no profiling hooks are active
 
+    # ---- N > 1: the record proves what ran - group size, transport, library version, one distinct device per rank, the bucket plan and the collective
+    # time left exposed behind the last backward kernel (HIP events on the compute stream, extra steps outside the headline)
+    rccl = None
+    if world > 1:
+        pr = torch.cuda.get_device_properties(local)
+        ident = ":".join(f"{getattr(pr, a, -1):02x}" for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")) + f" uuid={getattr(pr, 'uuid', '?')}"
+        devs = [None] * world
+        dist.all_gather_object(devs, {"rank": rank, "local_rank": local, "device": ident, "name": pr.name})
+        eng.exposed_events = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        exp_ms = [a.elapsed_time(b) for a, b in eng.exposed_events]
+        eng.exposed_events = None
+        t = torch.tensor([sum(exp_ms) / max(1, len(exp_ms))], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        one_device = bool(os.environ.get("BENCH_ONE_DEVICE"))
+        if not one_device:
+            assert len({d["device"] for d in devs}) == world, f"ranks share a device: {devs}"
+        rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                "devices": devs, "one_device_rehearsal": one_device,
+                "bucket_bytes": eng.bucket_bytes, "bucket_count": len(eng.layout.buckets(eng.bucket_bytes)),
+                "gradient_bytes_per_step": eng.grad_numel * 4, "fq_state_broadcast_bytes_per_step": eng.fq_arena.numel(),
+                "exposed_allreduce_ms": round(float(t.item()), 4),
+                "exposed_note": "stream time from the end of the last backward kernel to the join of the last bucket's all-reduce, mean of 3 extra steps, MAX over ranks"}
+
     ws = eng.workspace.data_ptr()
 
     def profile_kind(kind, nsteps):
@@ -284,23 +315,30 @@ def main():
             "metric": "images/sec QAT student step (fwd+bwd+allreduce)",
             "value": round(imgs / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (emulated: int8 MFMA for grid x grid products, 16-bit MFMA on exact-grid / hi+lo split operands; exact-integer or fp32 accumulate)",
+            "dtype": ("f32 (emulated: int8 MFMA for grid x grid products; forward float operands as fp16 hi+lo pairs; backward gradients as ONE fp16 plane scaled per "
+                      "tensor - 2^-12 per element, <= 4e-4 relative L2 per stage against the fp32 reference, bf16-pair fallback on overflow; fp32 / exact-integer accumulate)")
+                     if eng.dy16 else
+                     "f32 (emulated: int8 MFMA for grid x grid products, 16-bit MFMA on exact-grid / hi+lo split operands; exact-integer or fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{args.student}_patch16_224 student + QATWrapper, {args.backend} qconfig, "
                                    f"{'vit_base teacher KD (native teacher forward inside the timed step)' if args.teacher else 'no teacher'}, "
                                    f"batch {args.batch}/GPU, 224x224x3 (BASELINE configs[{2 if args.teacher else 1}])",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(args.graph)},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(args.graph),
+                       "backward_form": "one fp16 plane per gradient tensor (QATVIT_BWD_DY16)" if eng.dy16 else "bf16 (hi, lo) pairs",
+                       "one_plane_fallbacks_in_timed_region": eng.dy16_fallbacks},
         }
+        if rccl is not None:
+            res["rccl"] = rccl
     # ---- per-kernel legs: every rank runs the same extra steps (collectives stay matched), rank 0 times its own launches
-    KINDS = {1: "k_gemm_nt split-A, plain epilogue (proj / fc2 forward on fp16 pairs, proj dgrad on bf16 pairs)",
-             4: "k_gemm_nt split-A dgrad + LayerNorm backward fused into the epilogue (fc1 / qkv dgrad, mode 8)",
-             5: "k_gemm_nt split-A fc2 dgrad + GELU backward fused into the epilogue (mode 9: codes + mask bits; mode 5: uint16 codes)",
+    KINDS = {1: "k_gemm_nt, plain epilogue (proj / fc2 forward on fp16 pairs; proj dgrad on one fp16 plane - bf16 pairs with QATVIT_DY16=0)",
+             4: "k_gemm_nt dgrad + LayerNorm backward fused into the epilogue (fc1 / qkv dgrad, mode 8; gradient operand = one fp16 plane, or a bf16 pair with QATVIT_DY16=0)",
+             5: "k_gemm_nt fc2 dgrad + GELU backward fused into the epilogue (mode 9: codes + mask bits; gradient operand / output = one fp16 plane, or bf16 pairs with QATVIT_DY16=0)",
              2: "k_gemm_nt grid A on int8 MFMA, plain epilogue (patch embedding; qkv when it runs once)",
              7: "k_i8_strip<3> A-stationary int8 strip kernel, statistics-only pass (qkv and fc1 first passes; csrc/i8strip.hip)",
              8: "k_i8_strip<4> A-stationary int8 strip kernel, fc1 code pass (gelu(fq(.)) as uint8 codes + STE mask bits + two 256-entry tables)",
              9: "k_i8_strip<7> A-stationary int8 strip kernel, qkv code pass (uint8 codes + STE mask bits in the attention layout)",
-             3: "k_gemm_tn<1,..> + k_tn_reduce: weight gradients with grid X (qkv / fc1 / patch-embed; split dY: 2 bf16 passes issued)",
-             6: "k_gemm_tn<2,..> + k_tn_reduce: weight gradients with split X (proj; fc2 with X as codes expanded in the kernel; 3 bf16 passes issued)"}
+             3: "k_gemm_tn<1,..> + k_tn_reduce: weight gradients with grid X (qkv / fc1 / patch-embed; dY one fp16 plane: 1 pass - or a bf16 pair: 2)",
+             6: "k_gemm_tn + k_tn_reduce: weight gradients with float X (proj: X fp16; fc2: X as codes expanded in the kernel; 1 pass - 3 bf16 passes with QATVIT_DY16=0)"}
     SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_plain", 7: "nt_int8_stats_pass",
              8: "nt_int8_fc1_store_pass", 9: "nt_int8_qkv_code_pass", 3: "tn_grid_x", 6: "tn_split_x"}
     prof = {}
@@ -324,20 +362,22 @@ def main():
         qkv2 = os.environ.get("QATVIT_QKV_2PASS", "1") != "0" and os.environ.get("QATVIT_ATTN_CODES", "1") != "0" and os.environ.get("QATVIT_I8", "1") != "0"
         # ALGORITHMIC HBM bytes per step of each class: every operand once, in the format the kernel reads / writes it;
         # weights once per launch; split-reduction partials, mask bit planes (1/32 of an fp32 plane) and re-reads are NOT counted
-        lnb = 4 * Mr * Dm * 4                                # fused LayerNorm backward: x, dx_in read; dx_out, masked (hi, lo) pair written
+        dy = 2 if eng.dy16 else 4                            # bytes per element of a backward gradient operand: one fp16 plane, or a bf16 (hi, lo) pair
+        xf = 2 if eng.dy16 else 4                            # ... of the float X operand of the proj weight gradient (fp16 / bf16 pair); fc2's X is codes either way
+        lnb = 3 * Mr * Dm * 4 + Mr * Dm * dy                 # fused LayerNorm backward: x, dx_in read; dx_out and the masked gradient for the next branch written
         step_bytes = {
             1: dep * ((Mr * Dm * 4 + Dm * Dm * 2 + Mr * Dm * 4)                                  # proj forward: fp16 pair in, fp32 out
                       + (Mr * Hd * (1 if codes else 4) + Dm * Hd * 2 + Mr * Dm * 4)              # fc2 forward: codes (or fp16 pair) in, fp32 out
-                      + (Mr * Dm * 4 + Dm * Dm * 2 + Mr * Dm * 4)),                              # proj dgrad: bf16 pair in, fp32 out
-            4: dep * ((Mr * Hd * 4 + Dm * Hd * 2 + lnb) + (Mr * 3 * Dm * 4 + 3 * Dm * Dm * 2 + lnb)),   # fc1 dgrad, qkv dgrad (+ LayerNorm backward)
-            5: dep * (Mr * Dm * 4 + Dm * Hd * 2 + (Mr * Hd * 9 // 8 if bits else Mr * Hd * 2) + Mr * Hd * 4),   # fc2 dgrad: pair in, codes (+ mask bits) in, pair out
+                      + (Mr * Dm * dy + Dm * Dm * 2 + Mr * Dm * 4)),                             # proj dgrad: gradient in, fp32 out
+            4: dep * ((Mr * Hd * dy + Dm * Hd * 2 + lnb) + (Mr * 3 * Dm * dy + 3 * Dm * Dm * 2 + lnb)),   # fc1 dgrad, qkv dgrad (+ LayerNorm backward)
+            5: dep * (Mr * Dm * dy + Dm * Hd * 2 + (Mr * Hd * 9 // 8 if bits else Mr * Hd * 2) + Mr * Hd * dy),   # fc2 dgrad: gradient in, codes (+ mask bits) in, gradient out
             2: (Mpe * Kpe + Dm * Kpe + Mpe * Dm * 4) + (0 if qkv2 else dep * (Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 4)),   # patch embedding (+ one-pass qkv: fp32 out)
             7: dep * ((Mr * Dm + Hd * Dm) + ((Mr * Dm + 3 * Dm * Dm) if qkv2 else 0)),          # statistics passes: operands in, nothing stored
             8: dep * (Mr * Dm + Hd * Dm + Mr * Hd * (1 if codes else 4) + (Mr * Hd // 8 if bits else Mr * Hd * 2) + (0 if fc2w else Mr * Hd * 4)),   # fc1 storing pass: codes (or fp16 pair) + mask bits (or uint16 code) [+ bf16 pair]
             9: dep * (Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 9 // 8),                            # qkv code pass: 1 B + 1 bit per element out
             3: (Mpe * Dm * 4 + Mpe * Kpe * 2 + Dm * Kpe * 4)
-               + dep * ((Mr * 3 * Dm * 4 + Mr * Dm * 2 + 3 * Dm * Dm * 4) + (Mr * Hd * 4 + Mr * Dm * 2 + Hd * Dm * 4)),   # qkv, fc1 wgrad
-            6: dep * ((Mr * Dm * 4 + Mr * Dm * 4 + Dm * Dm * 4) + (Mr * Dm * 4 + Mr * Hd * (1 if fc2w else 4) + Hd * Dm * 4)),   # proj, fc2 wgrad (Q as codes)
+               + dep * ((Mr * 3 * Dm * dy + Mr * Dm * 2 + 3 * Dm * Dm * 4) + (Mr * Hd * dy + Mr * Dm * 2 + Hd * Dm * 4)),   # qkv, fc1 wgrad
+            6: dep * ((Mr * Dm * dy + Mr * Dm * xf + Dm * Dm * 4) + (Mr * Dm * dy + Mr * Hd * (1 if fc2w else 4) + Hd * Dm * 4)),   # proj, fc2 wgrad (Q as codes)
         }
         gemms = {}
         for kind, (ms, cnt, fl) in prof.items():
@@ -367,7 +407,7 @@ def main():
         hbm_bound = g.get("roofline_bound") == "hbm"
         traffic, traffic_note = None, None
         try:   # HBM-side bytes per launch: NOT measured by this run - offline rocprofv3 --pmc passes at B=256 shapes (tools/pmc_traffic.sh)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round3_gemm_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round4_gemm_pmc_traffic.json")))
             if args.batch == 256 and args.student == "vit_small" and str(dom) in pm:
                 traffic = round(pm[str(dom)]["bytes_per_launch"])
                 traffic_note = "STATIC, not measured in this run: " + pm[str(dom)]["note"]
@@ -386,7 +426,7 @@ def main():
             "note": f"per launch: algorithmic bytes (every operand once in its stored format: DESIGN.md section 4) and algorithmic FLOPs 2*M*N*K / HIP-event time of that "
                     f"launch on its launch stream, {nprof} steps run right after the timed region (no event is recorded inside the timed region).  The bound is the "
                     "roofline that binds at the kernel's arithmetic intensity (flop_per_byte against the ridge peak_flops / peak_bytes); the other side is in "
-                    "mfma_side.  Split-A launches issue two 16-bit MFMA passes (hi and lo): issued MFMA work is 2x the algorithmic figure",
+                    "mfma_side.  Launches on a (hi, lo) pair issue two 16-bit MFMA passes (issued MFMA work 2x the algorithmic figure); the one-plane backward issues one",
         }
         res["mfma_gemms"] = {SHORT[k]: v for k, v in gemms.items()}
     if rank == 0 and not args.no_kernel_rates:
@@ -409,9 +449,10 @@ def main():
                 d3 = timed_steps(t_only, k, 2, 1, dev)
                 e["teacher_forward_ms"] = round(1e3 * d3 / k, 3)
                 e["student_step_ms"] = round(1e3 * (d2 - d3) / k, 3)
-                from qat_vit_amd.teacher import DEFAULT_PASSES
+                from qat_vit_amd import teacher as _teacher
+                t_eng = next(iter(_teacher._ENGINES.values()), None)   # the engine that ran (its effective form: the fp16 forms fall back to 3 passes for dims % 384 != 0)
                 e["teacher_form"] = {3: "bf16 pairs x bf16 pairs, 3 MFMA passes", 2: "fp16 activation pair x fp16 weights, 2 MFMA passes",
-                                     1: "fp16 x fp16, 1 MFMA pass"}[int(os.environ.get("QATVIT_TEACHER_PASSES", DEFAULT_PASSES))]
+                                     1: "fp16 x fp16, 1 MFMA pass"}[t_eng.passes if t_eng is not None else _teacher.DEFAULT_PASSES]
             extras[tag] = e
             del st2, _m, _x, _y, t_only
             eng2.workspace = None

@@ -26,6 +26,7 @@ VIT_CONFIGS = {
     "vit_base_patch16_224": (768, 12, 12),
     # reduced shapes for fast fixtures (not a reference model name)
     "vit_tiny_test": (128, 2, 2),
+    "vit_small_depth2_test": (384, 2, 6),   # ViT-S width at 197 tokens, two blocks: the smallest model the one-plane backward covers (smoke)
 }
 
 

@@ -302,44 +302,6 @@ __global__ __launch_bounds__(256) void k_cls_rows(const float* __restrict__ cls,
 __device__ inline float gelu(float x) { return gelu_fwd(x); }
 __device__ inline float dgelu(float x) { return gelu_bwd(x); }
 
-__global__ __launch_bounds__(256) void k_fq_gelu(const float* __restrict__ Y, const float* __restrict__ qp, int qmin, int qmax,
-                                                 __bf16* __restrict__ G_hi, __bf16* __restrict__ G_lo, int64_t n4) {
-    const QP q = load_qp(qp);
-    // fq(Y) takes at most qmax-qmin+1 (<= 256) values, so gelu(fq(Y)) and its (hi, lo) split are a table: no erf, no conversions per
-    // element.  Entries are produced by the same gelu() on the same grid value, so the result is bit-identical to the direct form.
-    __shared__ uint32_t lut[256];   // lo16 = bf16 hi part, hi16 = bf16 lo part
-    const bool use_lut = q.on != 0.f && qmax - qmin < 256;
-    if (use_lut) {
-        if ((int)threadIdx.x <= qmax - qmin) {
-            const float g = gelu(((float)((int)threadIdx.x + qmin) - q.zp) * q.s);
-            const __bf16 h = (__bf16)g;
-            const __bf16 l = (__bf16)(g - (float)h);
-            lut[threadIdx.x] = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
-        }
-        __syncthreads();
-        const float fmn = (float)qmin, fmx = (float)qmax;
-        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-            const float4 v = reinterpret_cast<const float4*>(Y)[i];
-            const uint32_t a = lut[(int)(fminf(fmaxf(rintf(v.x * q.inv) + q.zp, fmn), fmx) - fmn)];
-            const uint32_t b = lut[(int)(fminf(fmaxf(rintf(v.y * q.inv) + q.zp, fmn), fmx) - fmn)];
-            const uint32_t c = lut[(int)(fminf(fmaxf(rintf(v.z * q.inv) + q.zp, fmn), fmx) - fmn)];
-            const uint32_t d = lut[(int)(fminf(fmaxf(rintf(v.w * q.inv) + q.zp, fmn), fmx) - fmn)];
-            uint2 hi, lo;
-            hi.x = (a & 0xffffu) | (b << 16); hi.y = (c & 0xffffu) | (d << 16);
-            lo.x = (a >> 16) | (b & 0xffff0000u); lo.y = (c >> 16) | (d & 0xffff0000u);
-            *reinterpret_cast<uint2*>(G_hi + i * 4) = hi;
-            *reinterpret_cast<uint2*>(G_lo + i * 4) = lo;
-        }
-        return;
-    }
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 v = reinterpret_cast<const float4*>(Y)[i];
-        bool in;
-        store_split4(G_hi, G_lo, i * 4, gelu(fqv(v.x, q, qmin, qmax, in)), gelu(fqv(v.y, q, qmin, qmax, in)), gelu(fqv(v.z, q, qmin, qmax, in)),
-                     gelu(fqv(v.w, q, qmin, qmax, in)));
-    }
-}
-
 // GELU_BWD=0: dY = d * mask(Y);  GELU_BWD=1: dY = d * gelu'(fq(Y)) * mask(Y); optionally * col_scale[col]
 // (per-channel weight scale of the consuming layer, folded here because dgrad's reduction runs over that axis).
 // Output: the (hi, lo) bf16 pair both the dgrad and the wgrad GEMM read.
@@ -758,11 +720,6 @@ int launch_ln_quant8(const float* x, const float* gamma, const float* beta, floa
 }
 int launch_cls_rows(const float* cls, const float* pos, float* x, int B, int T, int D, hipStream_t st) {
     k_cls_rows<<<cdiv((int64_t)B * D, 256), 256, 0, st>>>(cls, pos, x, B, T, D);
-    return 0;
-}
-
-int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, void* G_hi, void* G_lo, int64_t n, hipStream_t st) {
-    k_fq_gelu<<<flat_grid(n / 4), 256, 0, st>>>(Y, qp, qmin, qmax, reinterpret_cast<__bf16*>(G_hi), reinterpret_cast<__bf16*>(G_lo), n / 4);
     return 0;
 }
 

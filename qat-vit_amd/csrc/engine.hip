@@ -120,7 +120,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->lse = take((int64_t)d.B * d.H * p->TP * 4);
     p->Yproj = take(M * D * 4);
     p->h2q = take(M * D * 2);
-    p->Y1 = take(M * Hd * 4);
+    p->Y1 = take(M * Hd * 2);   // uint16 codes of fc1's output (QATVIT_FC1_BITS=0 only; the fp32 pre-FQ tensor never exists)
     p->G_hi = take(M * Hd * 2); p->G_lo = take(M * Hd * 2);
     p->Y2 = take(M * D * 4);
     p->h1q8 = take(M * D); p->h2q8 = take(M * D);
@@ -218,12 +218,6 @@ struct ProfScope {
         if (on) (void)hipEventRecord(pr->ev[slot + 1], st);
     }
 };
-
-// QATVIT_FC1_RECOMPUTE=0: fc1 once, fp32 output, separate fq+gelu pass (the pre-recompute path; keeps Y1 as fp32 for diagnostics)
-static bool fc1_recompute() {
-    static const int on = getenv("QATVIT_FC1_RECOMPUTE") ? atoi(getenv("QATVIT_FC1_RECOMPUTE")) : 1;
-    return on != 0;
-}
 
 // QATVIT_I8=0: the grid x grid forward GEMMs (patch-embed, qkv, fc1) on bf16 MFMA instead of int8 MFMA (bit-identical results)
 static bool use_i8() {
@@ -433,7 +427,7 @@ struct Ctx {
 // fc1's codes for the backward as the uint8 plane + mask bits (needs the forward's fc2-from-codes form, the int8 storing pass, the tall dgrad tile)
 static bool fc1_code_bits(const Ctx& x, int i) {
     const Dims& d = x.d;
-    return fc1_bits() && fc1_recompute() && use_i8() && fc2_codes() && x.f16_ok(x.widx(i, WB_FC2)) && d.Hd % 384 == 0 && d.D % 64 == 0 && d.Hd % 128 == 0 &&
+    return fc1_bits() && use_i8() && fc2_codes() && x.f16_ok(x.widx(i, WB_FC2)) && d.Hd % 384 == 0 && d.D % 64 == 0 && d.Hd % 128 == 0 &&
            x.c.act_qmax - x.c.act_qmin <= 255;
 }
 // fc2's weight gradient from the byte plane + bf16-pair table (needs the code-bits form above and the 128 x 384 wgrad tile)
@@ -466,7 +460,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
                                      x.blk<float>(p.qkv, i), x.aidx(i, AB_QKV)))
             return 1;
         }
-        const bool proj16 = x.f16_ok(x.widx(i, WB_PROJ)), fc2_16 = x.f16_ok(x.widx(i, WB_FC2)) && fc1_recompute();
+        const bool proj16 = x.f16_ok(x.widx(i, WB_PROJ)), fc2_16 = x.f16_ok(x.widx(i, WB_FC2));
         const bool fc2_c = fc2_16 && fc2_codes() && d.Hd % 64 == 0 && c.act_qmax - c.act_qmin <= 255;
         const bool fc1_b = fc2_c && fc1_code_bits(x, i);   // the backward reads the byte plane + mask bits: no uint16 plane is written
         float* const scal16 = x.blk<float>(p.scal16, i);
@@ -492,7 +486,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
                               x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h2q8, i) : nullptr,
                               x.center(), (x.flags & QATVIT_FWD_X16) != 0);
-        if (fc1_recompute()) {
+        {
             // fc1 is a K = D GEMM whose [M, 4D] fp32 output would be written once and read twice: run it TWICE instead.  Pass 1 only
             // feeds the observer (min/max, nothing stored); pass 2 - the same kernel on the same operands, so the same bits - quantises
             // with the fresh qparams and stores gelu(fq(.)) as the (hi, lo) pair fc2 reads plus a uint16 code (grid index | in-range
@@ -510,11 +504,6 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
             if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
                              x.aidx(i, AB_FC1), &p2, false))
                 return 1;
-        } else {
-            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B),
-                             x.blk<float>(p.Y1, i), x.aidx(i, AB_FC1)))
-                return 1;
-            launch_fq_gelu(x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), d.M * d.Hd, st);
         }
         }
         if (parts & 8) {   // ---- part 3: fc2 -> residual (+ statistics of the next LayerNorm)
@@ -819,7 +808,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             {   // fc2 dgrad with the GELU backward + fc1's STE mask fused into its epilogue: dY1 = (dYs . W_fc2) * gelu'(fq(Y1)) * mask(Y1)
                 NTPost post{x.blk<float>(p.Y1, i), x.act_qp(x.aidx(i, AB_FC1)), qa, qb, x.dy_colscale(w_fc1), x.at<void>(p.dY1_hi),
                             x.at<void>(p.dY1_lo)};
-                if (fc1_recompute()) { post.Y = nullptr; post.mode = 5; post.code = x.blk<void>(p.Y1, i); }   // the Y1 slot holds the uint16 codes
+                post.Y = nullptr; post.mode = 5; post.code = x.blk<void>(p.Y1, i);   // the Y1 slot holds the uint16 codes
                 if (fc1_code_bits(x, i)) { post.mode = 9; post.code = nullptr; post.code8 = x.blk<void>(p.G8, i); post.code_mask = x.blk<void>(p.Y1m, i); }
                 if (x.linear_dgrad(dYh, dYl, M, w_fc2, nullptr, &post)) return 1;
             }

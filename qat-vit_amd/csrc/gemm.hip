@@ -103,9 +103,8 @@ struct NTArgs {
     const int32_t* i8_wsum;  // [N] row sums of the int8 weight: C = (acc + (center - zp) * wsum[n]) * alpha + bias
     const float* i8_aqp;     // qparams {s, 1/s, zp, on} of the A operand's quantizer (zp enters the correction)
     int i8_center;
-    int pm;                  // which epilogue the kernel instantiation contains (template parameter PM): 0 plain, 1 = postY, 2 = gelu fwd, 3 / 4 / 5
+    int pm;                  // which epilogue the kernel instantiation contains (template parameter PM): 0 plain, 2 = gelu fwd, 3 / 4 / 5
     uint16_t* post_code;     // mode 4: out, mode 5: in
-    const float* postY;
     const float* post_qp;
     int post_qmin, post_qmax;
     const float* post_colscale;
@@ -200,11 +199,9 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
     float* sC = reinterpret_cast<float*>(smem); // [SLAB][LDC]
     // fused GELU backward: fq(Y) only takes qmax-qmin+1 (<= 256) values, so gelu'(fq(Y)) is a table (no erf/exp per element)
     float* sLut = sC + SLAB * LDC;
-    bool use_lut = false;
     constexpr bool P5 = PMB == 5 || PMB == 9;   // fc2 dgrad + GELU backward; 9: codes as uint8 + mask bits
-    if constexpr (PM == 1 || P5) {
-        use_lut = P5 || (p.post_qp[3] != 0.f && p.post_qmax - p.post_qmin < 256);
-        if (use_lut && tid <= p.post_qmax - p.post_qmin) sLut[tid] = gelu_bwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
+    if constexpr (P5) {
+        if (tid <= p.post_qmax - p.post_qmin) sLut[tid] = gelu_bwd(((float)(tid + p.post_qmin) - p.post_qp[2]) * p.post_qp[0]);
         // (published by the __syncthreads() between staging and the store loop below)
     }
     uint32_t* sLutF = reinterpret_cast<uint32_t*>(sLut);   // mode 4: packed (hi | lo << 16) bf16 pair of gelu(grid value)
@@ -611,29 +608,7 @@ __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4
             if (row < p.M) {
                 const float4 v = *reinterpret_cast<const float4*>(sC + rl * LDC + 4 * c4);
                 const int64_t off = (int64_t)row * p.ldc + n0 + 4 * c4;
-                if constexpr (PM == 1) {
-                    const float4 y = *reinterpret_cast<const float4*>(p.postY + off);
-                    const float qs = p.post_qp[0], qinv = p.post_qp[1], qzp = p.post_qp[2], qon = p.post_qp[3];
-                    const float fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
-                    float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (p.post_colscale) cs = *reinterpret_cast<const float4*>(p.post_colscale + n0 + 4 * c4);
-                    const float yv[4] = {y.x, y.y, y.z, y.w}, cv[4] = {v.x, v.y, v.z, v.w}, sv[4] = {cs.x, cs.y, cs.z, cs.w};
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                    bf16x4 oh, ol;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float t = rintf(yv[e] * qinv) + qzp;
-                        const bool in = (t >= fmin_ && t <= fmax_) || qon == 0.f;
-                        float dg;
-                        if (use_lut) dg = sLut[(int)(fminf(fmaxf(t, fmin_), fmax_) - fmin_)];
-                        else dg = gelu_bwd(qon != 0.f ? (fminf(fmaxf(t, fmin_), fmax_) - qzp) * qs : yv[e]);
-                        const float o = in ? cv[e] * dg * sv[e] : 0.f;
-                        oh[e] = (__bf16)o;
-                        ol[e] = (__bf16)(o - (float)oh[e]);
-                    }
-                    *reinterpret_cast<bf16x4*>(p.out_hi + off) = oh;
-                    *reinterpret_cast<bf16x4*>(p.out_lo + off) = ol;
-                } else if constexpr (P4) {
+                if constexpr (P4) {
                     const float qinv = p.post_qp[1], qzp = p.post_qp[2], fmin_ = (float)p.post_qmin, fmax_ = (float)p.post_qmax;
                     const float cv[4] = {v.x, v.y, v.z, v.w};
                     uint32_t w[4], cd[4];
@@ -1152,7 +1127,6 @@ static void nt_launch(const NTArgs& a, int grid, size_t lds, hipStream_t st) {
         }
     } else {
         switch (a.pm) {
-            case 1: QV_PM(1); break;
             case 2: QV_PM(2); break;
             case 3: QV_PM(3); break;
             case 4: QV_PM(4); break;
@@ -1235,10 +1209,8 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
         if (!a.out_hi || (!a.out_lo && !f16_gelu)) { set_error("gemm_nt: fused GELU epilogue needs out_hi / out_lo"); return 1; }
         if (post->out_f16 && !f16) { set_error("gemm_nt: the fp16 GELU pair is written by the fp16 form only"); return 1; }
     } else if (post) {
-        a.pm = 1;
-        a.postY = post->Y; a.post_qp = post->qp; a.post_qmin = post->qmin; a.post_qmax = post->qmax; a.post_colscale = post->colscale;
-        a.out_hi = reinterpret_cast<__bf16*>(post->out_hi); a.out_lo = reinterpret_cast<__bf16*>(post->out_lo);
-        if (!a.postY || !a.post_qp || !a.out_hi || !a.out_lo) { set_error("gemm_nt: incomplete fused GELU-backward epilogue arguments"); return 1; }
+        set_error("gemm_nt: the GELU-backward epilogue reads fc1's codes (mode 5 or 9); the form that re-quantised a stored fp32 tensor is gone");
+        return 1;
     } else if (!C) {
         set_error("gemm_nt: null output");
         return 1;

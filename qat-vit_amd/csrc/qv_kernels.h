@@ -150,7 +150,6 @@ int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, 
 int launch_ln_quant8(const float* x, const float* gamma, const float* beta, float eps, const float* qp, int qmin, int qmax, int center, void* out8,
                      float* mean, float* rstd, int64_t nrows, int64_t row_stride, int D, hipStream_t st);
 int launch_cls_rows(const float* cls, const float* pos, float* x, int B, int T, int D, hipStream_t st);
-int launch_fq_gelu(const float* Y, const float* qp, int qmin, int qmax, void* G_hi, void* G_lo, int64_t n, hipStream_t st);
 int launch_mask_bwd(int gelu_bwd, const float* d, const float* Y, const float* qp, int qmin, int qmax, const float* col_scale, int ncols,
                     void* dst_hi, void* dst_lo, int64_t n, hipStream_t st, const float* o16_mul = nullptr, uint32_t* o16_amax = nullptr);
 int launch_ln_bwd_fq(int acc, const float* dH, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,

@@ -91,7 +91,7 @@ class FlatGradLayout:
 
 
 def staged_backward_allreduce(flat: torch.Tensor, layout: FlatGradLayout, bucket_bytes: int, pg,
-                              run_stages: Callable[[int, int], None]) -> None:
+                              run_stages: Callable[[int, int], None], exposed: Optional[list] = None) -> None:
     """Run the backward stage by stage; as soon as a bucket's stages have been enqueued, start its all-reduce
     (async: RCCL / gloo run it on their own stream / thread) and go on differentiating earlier layers.  Returns
     with every slice averaged over the group (the caller's stream waits on the collectives).
@@ -104,10 +104,17 @@ def staged_backward_allreduce(flat: torch.Tensor, layout: FlatGradLayout, bucket
         run_stages(s0, s1)
         seg = flat[a:b]
         works.append((dist.all_reduce(seg, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=pg, async_op=True), seg))
+    ev = None
+    if exposed is not None and flat.is_cuda:   # (bench.py) the stream time between the last backward kernel and the join of the last collective
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     for w, seg in works:
         w.wait()
         if not avg:
             seg.div_(world)
+    if ev is not None:
+        ev[1].record()
+        exposed.append(ev)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -256,6 +263,7 @@ class StudentEngine:
         self.pg = None
         self.sync_state = True      # set per call by student_forward: grad mode of the caller (False under no_grad)
         self.bucket_bytes = 16 << 20
+        self.exposed_events: Optional[list] = None   # bench.py sets a list: (start, end) event pairs of the exposed collective time, one per backward
         self.generation = 0         # bumped by every forward: the workspace holds the activations of exactly one forward
         self._build_fq_structs()
 
@@ -369,7 +377,7 @@ class StudentEngine:
         if self.pg is None:
             run(0, self.layout.last_stage)
         else:
-            staged_backward_allreduce(flat, self.layout, self.bucket_bytes, self.pg, run)
+            staged_backward_allreduce(flat, self.layout, self.bucket_bytes, self.pg, run, self.exposed_events)
         return views
 
     def dy16_overflowed(self) -> bool:

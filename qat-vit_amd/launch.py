@@ -6,9 +6,10 @@ Stands where the reference starts its own workers (``/root/reference/scripts/tra
 * every worker is polled; as soon as ONE exits non-zero (or dies on a signal) the rest are terminated (SIGTERM, then SIGKILL) and the launcher
   returns non-zero - without it rank 0 sits in RCCL / the c10d store until their ~10-minute timeouts;
 * the whole run has a wall-clock limit;
-* the rendezvous port is bound by THIS process first and handed over at the last moment (SO_REUSEADDR), and a worker that cannot bind it fails
-  fast - at which point the rule above ends the run;
-* stdout of rank 0 is relayed (the one JSON line of bench.py); stderr of every rank goes to the launcher's stderr.
+* the rendezvous port is one this process found free a moment before the workers start (it is released again before they bind it: another process
+  can still take it in between - a worker that cannot bind it then fails fast, at which point the rule above ends the run);
+* stdout of rank 0 is drained continuously by a reader thread (a worker that prints more than a pipe buffer must not block in write()) and returned;
+  stderr of every rank goes to the launcher's stderr.
 Workers are always fresh child processes: a process that has initialised the GPU is never re-executed."""
 from __future__ import annotations
 
@@ -16,6 +17,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 from typing import Dict, List, Optional, Tuple
 
@@ -35,13 +37,18 @@ def run_workers(n: int, cmd: List[str], env: Optional[Dict[str, str]] = None, wa
     worker exited 0 within the limit."""
     base = dict(os.environ if env is None else env)
     port = free_port()
-    procs = []
-    for r in range(n):
-        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                 HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    procs: List[subprocess.Popen] = []
+    chunks: List[str] = []
+    reader: Optional[threading.Thread] = None
     t0, rc, why = time.time(), 0, ""
     try:
+        for r in range(n):   # (inside the try: a spawn failure for rank k must not leak ranks 0..k-1)
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                     HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+            if r == 0:
+                reader = threading.Thread(target=lambda f=procs[0].stdout: chunks.extend(iter(lambda: f.read(65536), "")), daemon=True)
+                reader.start()
         while True:
             codes = [q.poll() for q in procs]
             bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
@@ -64,11 +71,9 @@ def run_workers(n: int, cmd: List[str], env: Optional[Dict[str, str]] = None, wa
         for q in live:
             if q.poll() is None:
                 q.kill()
-    out0 = ""
-    try:
-        out0 = procs[0].communicate(timeout=grace_s)[0] or ""
-    except Exception:  # noqa: BLE001
-        pass
+    if reader is not None:
+        reader.join(timeout=grace_s)     # (rank 0 has exited or was killed: its pipe reaches end of file)
+    out0 = "".join(chunks)
     if why:
         print(f"launch: {why}; the other workers were stopped", file=sys.stderr)
     return rc, out0

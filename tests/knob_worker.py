@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_knobs.py: one training step of a ViT-S-width, depth-2 student (batch 4, fixed seeds) under whatever QATVIT_* knobs the
+"""Worker of tests/test_gpu_knobs.py: two training steps (no optimizer step in between) of a ViT-S-width, depth-2 student (batch 4, fixed seeds) under whatever QATVIT_* knobs the
 environment holds; writes logits, loss, every parameter gradient and the activation quantizers' state to the .pt file given as argv[1]."""
 import os
 import sys
@@ -19,13 +19,19 @@ def main():
     g = torch.Generator().manual_seed(4)
     x = torch.randn(4, 3, 224, 224, generator=g).cuda()
     y = torch.randint(0, 10, (4,), generator=g).cuda()
-    out = p(x)
-    loss, _ = F.kd_ce_loss(out, None, y, 4.0, 0.5, 0.1)
-    loss.backward()
-    torch.cuda.synchronize()
-    res = {"logits": out.detach().cpu(), "loss": loss.detach().cpu(), "grads": {n: q.grad.detach().cpu() for n, q in p.named_parameters()},
-           "fq": {n: (m.scale.detach().cpu(), m.zero_point.detach().cpu(), m.activation_post_process.min_val.detach().cpu(),
-                      m.activation_post_process.max_val.detach().cpu()) for n, m in fq_modules(p).items()}}
+    res = {}
+    for step in (1, 2):   # step 1 calibrates the one-plane backward (it IS the bf16-pair form); step 2 runs whatever form the knobs leave as the default
+        for q in p.parameters():
+            q.grad = None
+        out = p(x)
+        loss, _ = F.kd_ce_loss(out, None, y, 4.0, 0.5, 0.1)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[step] = {"logits": out.detach().cpu(), "loss": loss.detach().cpu(), "grads": {n: q.grad.detach().cpu() for n, q in p.named_parameters()},
+                     "fq": {n: (m.scale.detach().cpu(), m.zero_point.detach().cpu(), m.activation_post_process.min_val.detach().cpu(),
+                                m.activation_post_process.max_val.detach().cpu()) for n, m in fq_modules(p).items()}}
+    from qat_vit_amd.engine import engine_of
+    res["one_plane"] = bool(engine_of(p)._fwd_x16)
     torch.save(res, sys.argv[1])
 
 

@@ -44,6 +44,16 @@ def test_bench_starts_its_own_workers(native_lib):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 16 * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    # the N > 1 record proves what ran: group size, transport, one entry per rank, the bucket plan, the exposed collective time
+    rc = d["rccl"]
+    assert rc["world_size"] == 2 and rc["backend"] == "gloo" and rc["one_device_rehearsal"] is True and rc["nccl_version"] is None
+    assert [e["rank"] for e in rc["devices"]] == [0, 1] and all(e["device"] for e in rc["devices"])
+    assert rc["bucket_count"] >= 1 and rc["gradient_bytes_per_step"] > 4 * 21_000_000 and rc["exposed_allreduce_ms"] >= 0.0
+    # a group of another size than --gpus is refused
+    env3 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29917")
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8", "--no-cpu-baseline",
+                         "--no-kernel-rates", "--no-extras"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env3)
+    assert r3.returncode != 0 and "WORLD_SIZE" in (r3.stderr + r3.stdout)
     # a failing worker makes the launcher fail (the driver must not read a half result as success)
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8",
                           "--backend", "no_such_backend", "--no-cpu-baseline", "--no-kernel-rates", "--no-extras"], capture_output=True, text=True,

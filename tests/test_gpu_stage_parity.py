@@ -19,8 +19,10 @@ four parts per block (x_in -> norm1 -> qkv | qkv -> attention -> proj -> residua
   (b) relative L2 <= 1e-3 on every pre-fake-quant tensor, every float GEMM operand, the residual stream, the residual-stream
       gradient and every parameter gradient of the stage (backward: one stage per block on the teacher-forced forward state).
 
-A second, informational table repeats the forward with ONE injection per block (what VERDICT r1 asked for) next to the same experiment
-on the stock torch tree on this GPU - the live fp32 floor of that coarser granularity; it must stay within 3x that floor.
+A second table repeats the forward with ONE injection per block next to the same experiment on the stock torch tree - on this GPU and on the
+host CPU with the reduction order of every Linear layer permuted (three permutations): independent fp32 evaluations, the live floor DISTRIBUTION of that coarser granularity; asserted per row against ITS OWN
+block's samples (at most 5 % of the rows beyond 2x the largest sample + 1e-4, none beyond 4x, median ratio <= 1.25; the stock samples' own
+leave-one-out ratios - the null distribution - are written next to it).
 
 Reference call sites: forward ``ddp_model(images)`` qat_trainer.py:341, loss :343-349, ``loss.backward()`` :359.
 Tables are written to gpurun_out/ (committed copies: profiles/round3_stage_flip_table_*.txt)."""
@@ -203,7 +205,7 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
               tr.codes(f"model.patch_embed.proj.{A}").permute(0, 2, 3, 1).reshape(-1, D))
     tab.close("embed", "x_in[0] (cls, pos added)", eng.tensor("x_in", 0, (M, D)), tr.block_in[0].reshape(M, D))
     Hd = c.mlp_hidden
-    if os.environ.get("QATVIT_FC1_RECOMPUTE", "1") == "0" or os.environ.get("QATVIT_ATTN_CODES", "1") == "0":
+    if os.environ.get("QATVIT_ATTN_CODES", "1") == "0":
         pytest.skip("diagnostic knob set: the per-tensor checks below read the code planes of the default path (uint16 fc1 codes, qkv codes)")
     f16 = os.environ.get("QATVIT_F16", "1") != "0"
     fc2_codes = f16 and os.environ.get("QATVIT_FC2_CODES", "1") != "0"
@@ -277,8 +279,36 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
     # ---- (informational) ONE injection per block, next to the same experiment on the stock torch tree on this GPU: the live floor of
     # that granularity (in-block amplification: a flipped key perturbs a whole head; a flipped norm2 element ~5 % of its row's fc1 codes)
     coarse = Table()
-    coarse_rows, floor_max = [], {}
+    coarse_rows = []
     n_cmp = n_within = 0
+    perm_seeds = (101, 102, 103)
+
+    def floor_sample(i, device, perm_seed=None):
+        """One independent fp32 evaluation of block i on the oracle's block input by the STOCK torch tree (fresh observers): per tensor the fraction of
+        codes (relative L2 for the block output) that differ from the oracle - the deviation between two correct evaluations at this granularity.
+        perm_seed (CPU): the reduction dimension of the block's four Linear layers is permuted (weight columns and input features alike) - the same
+        mathematical function, every dot product summed in another order.  (The host CPU at 1 .. 16 threads is NOT an independent evaluation: oneDNN
+        splits the rows, every thread count gave the oracle's bits - measured, round 4.)"""
+        pre = f"model.blocks.{i}"
+        blk = copy.deepcopy(po0.model.blocks[i]).to(device)
+        if perm_seed is not None:
+            gp = torch.Generator().manual_seed(perm_seed + i)
+            for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+                perm = torch.randperm(lin.weight.shape[1], generator=gp)
+                with torch.no_grad():
+                    lin.weight.copy_(lin.weight[:, perm].clone())
+                lin.register_forward_pre_hook(lambda mod, inp, perm=perm: (inp[0][..., perm],))
+        caps = capture_fq_io(blk)
+        with torch.no_grad():
+            bo = blk(tr.block_in[i].to(device))
+        fl = {}
+        for nm in ("norm1", "attn.qkv", "attn.proj", "norm2", "mlp.fc1", "mlp.fc2"):
+            fm = dict(blk.named_modules())[f"{nm}.{A}"]
+            cg = torch.round(caps[f"{nm}.{A}"][1] / fm.scale).cpu().reshape(-1)
+            fl[nm] = (cg != tr.codes(f"{pre}.{nm}.{A}").reshape(-1)).float().mean().item()
+        fl[f"x_in[{i + 1}] (block output)"] = rel_l2(bo.cpu().numpy(), tr.block_in[i + 1].numpy())
+        return fl
+
     for i in blocks:
         st, pre = f"block{i}", f"model.blocks.{i}"
         reset_act_observers(range(2 + 6 * i, 8 + 6 * i))
@@ -287,35 +317,38 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
         n0 = len(coarse.rows)
         for part in range(3):
             cmp_part(coarse, st, i, part, lim=1.0, tol=1.0, split_fc2=False)
-        blk = copy.deepcopy(po0.model.blocks[i]).cuda()              # fresh observers, stock torch, this GPU
-        caps = capture_fq_io(blk)
-        with torch.no_grad():
-            bo = blk(tr.block_in[i].cuda())
-        floor = {}
-        for nm in ("norm1", "attn.qkv", "attn.proj", "norm2", "mlp.fc1", "mlp.fc2"):
-            fm = dict(blk.named_modules())[f"{nm}.{A}"]
-            cg = torch.round(caps[f"{nm}.{A}"][1] / fm.scale).cpu().reshape(-1)
-            floor[nm] = (cg != tr.codes(f"{pre}.{nm}.{A}").reshape(-1)).float().mean().item()
-        floor[f"x_in[{i + 1}] (block output)"] = rel_l2(bo.cpu().numpy(), tr.block_in[i + 1].numpy())
+        # the floor as a DISTRIBUTION: stock torch on this GPU and on the host CPU with permuted reduction orders - independent fp32 evaluations of the
+        # same block on the same input
+        samples = [("gpu", floor_sample(i, "cuda"))] + [(f"cpu-perm{n}", floor_sample(i, "cpu", n)) for n in perm_seeds]
         for k in range(n0, len(coarse.rows)):
             r = coarse.rows[k]
-            if r[1] in floor:
-                coarse.rows[k] = r + (floor[r[1]],)
+            if r[1] in samples[0][1]:
+                vals = [fl[r[1]] for _, fl in samples]
+                coarse.rows[k] = r + (max(vals),)
                 n_cmp += 1
-                n_within += r[4] <= 3 * floor[r[1]] + 1e-4
-                kind = r[1] if not r[1].startswith("x_in[") else "block output"
-                floor_max[kind] = max(floor_max.get(kind, 0.0), floor[r[1]])
-                coarse_rows.append((st, kind, r[1], r[4], floor[r[1]]))
-        del blk
-    # At this granularity a quantizer's codes also move with its SCALE (a different max element after an upstream flip), for the stock tree exactly as
-    # for ours, and WHICH block that hits differs between two correct evaluations (measured: stock torch on this GPU vs the CPU oracle reaches 1 - 9 % of
-    # mlp.fc2's codes in some blocks and 0.1 % in others).  Every row is therefore asserted against 3x the LARGEST stock-torch-on-this-GPU deviation
-    # of the same tensor over the blocks (+ 1e-4); rows within 3x the floor of their own block are counted and reported.
-    coarse_bad = [(st, name, v, f, floor_max[kind]) for st, kind, name, v, f in coarse_rows if v > 3 * floor_max[kind] + 1e-4]
-    coarse.bad = []
-    coarse.write(os.path.join(ROOT, "gpurun_out", f"round3_block_level_vs_floor_{golden_tag}.txt"),
-                 f"# ONE injection per block (coarse): native block on the oracle's block input vs the oracle, and the same for the stock torch tree on the same GPU "
-                 f"(last column = that floor); {arch} batch {B}, {backend}; native within 3x floor + 1e-4 in {n_within} of {n_cmp} rows")
+                n_within += r[4] <= 2 * max(vals) + 1e-4
+                coarse_rows.append((st, r[1], r[4], vals))
+    # Every row against ITS OWN block's floor distribution.  ratio = native deviation / largest of the block's independent stock evaluations.  The same
+    # ratio for every stock sample against the OTHER evaluations of its block (leave one out, the native one included) is the null distribution: what
+    # "one of five interchangeable fp32 evaluations" looks like - heavy-tailed (one flipped scale bit moves 1e-5 of a tensor's codes and is amplified
+    # through the block; measured: 21 % of stock samples above 1, single ones up to 3.8).  Asserted: (a) at most 5 % of the native rows beyond 2x + 1e-4,
+    # (b) none beyond 4x + 1e-4 (a systematic excess in one block), (c) median ratio <= 1.25 (a systematic excess everywhere).
+    coarse_bad = [(st, name, v, max(vals)) for st, name, v, vals in coarse_rows if v > 2 * max(vals) + 1e-4]
+    coarse_cap = [(st, name, v, max(vals)) for st, name, v, vals in coarse_rows if v > 4 * max(vals) + 1e-4]
+    sig = [(v, vals) for _, _, v, vals in coarse_rows if max(vals + [v]) > 1e-4]          # rows with a measurable deviation
+    ratios = sorted(v / (max(vals) + 1e-12) for v, vals in sig)
+    null = sorted(vals[k] / (max(vals[:k] + vals[k + 1:] + [v]) + 1e-12) for v, vals in sig for k in range(len(vals)))
+    med = ratios[len(ratios) // 2] if ratios else 0.0
+    coarse.write(os.path.join(ROOT, "gpurun_out", f"round4_block_level_vs_floor_{golden_tag}.txt"),
+                 f"# ONE injection per block (coarse): native block on the oracle's block input vs the oracle; last column = the largest deviation of {1 + len(perm_seeds)} "
+                 f"independent stock-torch evaluations of the same block on the same input (this GPU; host CPU with {len(perm_seeds)} permutations of every Linear layer's reduction order) from the oracle; "
+                 f"{arch} batch {B}, {backend}; native within 2x that + 1e-4 in {n_within} of {n_cmp} rows; ratio native / largest stock sample: median {med:.2f}, "
+                 f"max {(ratios[-1] if ratios else 0):.2f}; the same ratio of each stock sample against the other evaluations of its block (leave one out): "
+                 f"median {(null[len(null) // 2] if null else 0):.2f}, above 1 in {sum(r > 1 for r in null)} of {len(null)}, above 2 in {sum(r > 2 for r in null)}, max {(null[-1] if null else 0):.2f}")
+    with open(os.path.join(ROOT, "gpurun_out", f"round4_block_level_floor_samples_{golden_tag}.txt"), "w") as f:
+        f.write(f"# per block and tensor: native deviation from the oracle, then every stock-torch sample's deviation (gpu; cpu with permuted reduction order x {len(perm_seeds)})\n")
+        for st, name, v, vals in coarse_rows:
+            f.write(f"{st:<10}{name:<28}{v:12.3e}   " + " ".join(f"{x:10.3e}" for x in vals) + ("   <-- beyond 2x max + 1e-4" if v > 2 * max(vals) + 1e-4 else "") + "\n")
 
     # ---- the asserted run: injection at every fake-quantizer input that follows an amplifier (four parts per block)
     for i in blocks:
@@ -440,8 +473,9 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
                     f"(torch {torch.__version__} CPU eager QAT); produced by tests/test_gpu_stage_parity.py")
     tab.check()
     tab16.check()
-    assert not coarse_bad, ("one injection per block: rows beyond 3x the largest stock-torch-on-this-GPU deviation of that tensor", coarse_bad[:8], n_within, n_cmp)
-    assert n_within >= 0.8 * n_cmp, (n_within, n_cmp)
+    assert not coarse_cap, ("one injection per block: rows beyond 4x the largest of that block's independent stock-torch deviations", coarse_cap[:8])
+    assert len(coarse_bad) <= 0.05 * n_cmp, ("one injection per block: more than 5 % of the rows beyond 2x their own block's floor", coarse_bad[:8], n_within, n_cmp)
+    assert med <= 1.25, ("one injection per block: the native deviation is systematically above the stock evaluations'", med)
     return tab
 
 
