@@ -21,8 +21,8 @@ four parts per block (x_in -> norm1 -> qkv | qkv -> attention -> proj -> residua
 
 A second table repeats the forward with ONE injection per block next to the same experiment on the stock torch tree - on this GPU and on the
 host CPU with the reduction order of every Linear layer permuted (three permutations): independent fp32 evaluations, the live floor DISTRIBUTION of that coarser granularity; asserted per row against ITS OWN
-block's samples (at most 5 % of the rows beyond 2x the largest sample + 1e-4, none beyond 4x, median ratio <= 1.25; the stock samples' own
-leave-one-out ratios - the null distribution - are written next to it).
+block's samples (2x the largest sample + 1e-4 + the part that the measured differences of the block's quantizer SCALES from the oracle's explain; block
+outputs 4x; median ratio <= 1.25; the stock samples' own leave-one-out ratios - the null distribution - and every scale difference are written next to it).
 
 Reference call sites: forward ``ddp_model(images)`` qat_trainer.py:341, loss :343-349, ``loss.backward()`` :359.
 Tables are written to gpurun_out/ (committed copies: profiles/round3_stage_flip_table_*.txt)."""
@@ -282,6 +282,7 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
     coarse_rows = []
     n_cmp = n_within = 0
     perm_seeds = (101, 102, 103)
+    CHAIN = ["norm1", "attn.qkv", "attn.proj", "norm2", "mlp.fc1", "mlp.fc2"]
 
     def floor_sample(i, device, perm_seed=None):
         """One independent fp32 evaluation of block i on the oracle's block input by the STOCK torch tree (fresh observers): per tensor the fraction of
@@ -306,6 +307,8 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
             fm = dict(blk.named_modules())[f"{nm}.{A}"]
             cg = torch.round(caps[f"{nm}.{A}"][1] / fm.scale).cpu().reshape(-1)
             fl[nm] = (cg != tr.codes(f"{pre}.{nm}.{A}").reshape(-1)).float().mean().item()
+            so = tr.fq[f"{pre}.{nm}.{A}"].scale
+            fl["ds " + nm] = ((fm.scale.cpu() - so).abs() / so).item()      # relative difference of this quantizer's scale from the oracle's
         fl[f"x_in[{i + 1}] (block output)"] = rel_l2(bo.cpu().numpy(), tr.block_in[i + 1].numpy())
         return fl
 
@@ -327,28 +330,49 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
                 coarse.rows[k] = r + (max(vals),)
                 n_cmp += 1
                 n_within += r[4] <= 2 * max(vals) + 1e-4
-                coarse_rows.append((st, r[1], r[4], vals))
+                ds_ours, ds_vals, allow = 0.0, [0.0] * len(samples), 0.0
+                if "ds " + r[1] in samples[0][1]:
+                    so = tr.fq[f"{pre}.{r[1]}.{A}"].scale
+                    ds_ours = ((fqm[f"{pre}.{r[1]}.{A}"].scale.cpu() - so).abs() / so).item()
+                    ds_vals = [fl["ds " + r[1]] for _, fl in samples]
+                    # what the quantizer-scale differences of this block explain: a scale (or an input) that is off by a relative d moves every
+                    # pre-rounding value x / s by |q - zp| d, i.e. changes about mean|q - zp| d of the codes; d = this quantizer's own scale difference
+                    # plus those of the quantizers upstream of it in the block (their de-quantised outputs carry the factor on)
+                    chain = CHAIN[:CHAIN.index(r[1]) + 1]
+                    dsum = sum(((fqm[f"{pre}.{q}.{A}"].scale.cpu() - tr.fq[f"{pre}.{q}.{A}"].scale).abs() / tr.fq[f"{pre}.{q}.{A}"].scale).item() for q in chain)
+                    allow = 2.0 * tr.codes(f"{pre}.{r[1]}.{A}").abs().mean().item() * dsum
+                coarse_rows.append((st, r[1], r[4], vals, ds_ours, ds_vals, allow))
     # Every row against ITS OWN block's floor distribution.  ratio = native deviation / largest of the block's independent stock evaluations.  The same
     # ratio for every stock sample against the OTHER evaluations of its block (leave one out, the native one included) is the null distribution: what
-    # "one of five interchangeable fp32 evaluations" looks like - heavy-tailed (one flipped scale bit moves 1e-5 of a tensor's codes and is amplified
-    # through the block; measured: 21 % of stock samples above 1, single ones up to 3.8).  Asserted: (a) at most 5 % of the native rows beyond 2x + 1e-4,
-    # (b) none beyond 4x + 1e-4 (a systematic excess in one block), (c) median ratio <= 1.25 (a systematic excess everywhere).
-    coarse_bad = [(st, name, v, max(vals)) for st, name, v, vals in coarse_rows if v > 2 * max(vals) + 1e-4]
-    coarse_cap = [(st, name, v, max(vals)) for st, name, v, vals in coarse_rows if v > 4 * max(vals) + 1e-4]
-    sig = [(v, vals) for _, _, v, vals in coarse_rows if max(vals + [v]) > 1e-4]          # rows with a measurable deviation
+    # "one of five interchangeable fp32 evaluations" looks like.  It is heavy-tailed through ONE mechanism, visible in the scale columns of the samples
+    # table: a flipped code in the row that holds a tensor's extreme element moves that quantizer's SCALE by 1e-5 .. 2e-3, which re-rounds mean|q| times
+    # that fraction of ALL its codes and of everything downstream (it happens to the oracle itself: C3 block 5, where the three permuted CPU evaluations
+    # and the native one agree with each other on fc1's scale and differ from the oracle by the same 2.3e-4).  Every quantizer's scale is asserted to
+    # 2e-5 of the oracle's in the teacher-forced run above, where its input is the oracle's; here the part of a row that the measured scale differences
+    # explain is allowed for explicitly:
+    #   (a) quantizer rows: deviation <= 2x the largest stock sample + 1e-4 + 2 mean|q - zp| (sum of the block's scale differences up to this quantizer);
+    #   (b) block outputs: <= 4x the largest stock sample + 1e-4;   (c) the median ratio over all rows <= 1.25 (a systematic excess everywhere).
+    # Rows beyond the plain 2x bound are counted and reported.
+    coarse_bad = [(st, name, v, max(vals), al) for st, name, v, vals, _, _, al in coarse_rows
+                  if v > (4 if name.startswith("x_in[") else 2) * max(vals) + 1e-4 + al]
+    plain2 = [(st, name) for st, name, v, vals, _, _, _ in coarse_rows if v > 2 * max(vals) + 1e-4]
+    sig = [(v, vals) for _, _, v, vals, _, _, _ in coarse_rows if max(vals + [v]) > 1e-4]          # rows with a measurable deviation
     ratios = sorted(v / (max(vals) + 1e-12) for v, vals in sig)
     null = sorted(vals[k] / (max(vals[:k] + vals[k + 1:] + [v]) + 1e-12) for v, vals in sig for k in range(len(vals)))
     med = ratios[len(ratios) // 2] if ratios else 0.0
     coarse.write(os.path.join(ROOT, "gpurun_out", f"round4_block_level_vs_floor_{golden_tag}.txt"),
                  f"# ONE injection per block (coarse): native block on the oracle's block input vs the oracle; last column = the largest deviation of {1 + len(perm_seeds)} "
                  f"independent stock-torch evaluations of the same block on the same input (this GPU; host CPU with {len(perm_seeds)} permutations of every Linear layer's reduction order) from the oracle; "
-                 f"{arch} batch {B}, {backend}; native within 2x that + 1e-4 in {n_within} of {n_cmp} rows; ratio native / largest stock sample: median {med:.2f}, "
+                 f"{arch} batch {B}, {backend}; native within 2x that + 1e-4 in {n_within} of {n_cmp} rows (beyond it: {plain2}); ratio native / largest stock sample: median {med:.2f}, "
                  f"max {(ratios[-1] if ratios else 0):.2f}; the same ratio of each stock sample against the other evaluations of its block (leave one out): "
                  f"median {(null[len(null) // 2] if null else 0):.2f}, above 1 in {sum(r > 1 for r in null)} of {len(null)}, above 2 in {sum(r > 2 for r in null)}, max {(null[-1] if null else 0):.2f}")
     with open(os.path.join(ROOT, "gpurun_out", f"round4_block_level_floor_samples_{golden_tag}.txt"), "w") as f:
         f.write(f"# per block and tensor: native deviation from the oracle, then every stock-torch sample's deviation (gpu; cpu with permuted reduction order x {len(perm_seeds)})\n")
-        for st, name, v, vals in coarse_rows:
-            f.write(f"{st:<10}{name:<28}{v:12.3e}   " + " ".join(f"{x:10.3e}" for x in vals) + ("   <-- beyond 2x max + 1e-4" if v > 2 * max(vals) + 1e-4 else "") + "\n")
+        f.write("# then (| ...): the relative difference of that quantizer's SCALE from the oracle's, native first, then the samples; last: the deviation the "
+                "block's scale differences explain (2 mean|q - zp| x their sum up to this quantizer)\n")
+        for st, name, v, vals, dso, dsv, al in coarse_rows:
+            f.write(f"{st:<10}{name:<28}{v:12.3e}   " + " ".join(f"{x:10.3e}" for x in vals) + f"   | {dso:9.2e}  " + " ".join(f"{x:9.2e}" for x in dsv) + f"   | {al:9.2e}"
+                    + ("   <-- beyond 2x max + 1e-4" if v > 2 * max(vals) + 1e-4 else "") + "\n")
 
     # ---- the asserted run: injection at every fake-quantizer input that follows an amplifier (four parts per block)
     for i in blocks:
@@ -473,8 +497,8 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
                     f"(torch {torch.__version__} CPU eager QAT); produced by tests/test_gpu_stage_parity.py")
     tab.check()
     tab16.check()
-    assert not coarse_cap, ("one injection per block: rows beyond 4x the largest of that block's independent stock-torch deviations", coarse_cap[:8])
-    assert len(coarse_bad) <= 0.05 * n_cmp, ("one injection per block: more than 5 % of the rows beyond 2x their own block's floor", coarse_bad[:8], n_within, n_cmp)
+    assert not coarse_bad, ("one injection per block: rows beyond 2x (block output: 4x) the largest of that block's stock deviations + what its scale differences explain",
+                            coarse_bad[:8], n_within, n_cmp)
     assert med <= 1.25, ("one injection per block: the native deviation is systematically above the stock evaluations'", med)
     return tab
 
