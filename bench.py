@@ -337,11 +337,10 @@ def main():
              7: "k_i8_strip<3> A-stationary int8 strip kernel, statistics-only pass (qkv and fc1 first passes; csrc/i8strip.hip)",
              8: "k_i8_strip<4> A-stationary int8 strip kernel, fc1 code pass (gelu(fq(.)) as uint8 codes + STE mask bits + two 256-entry tables)",
              9: "k_i8_strip<7> A-stationary int8 strip kernel, qkv code pass (uint8 codes + STE mask bits in the attention layout)",
-             10: "k_i8_strip<.., FUSED> qkv / fc1: statistics pass, grid barrier + observer update, code pass in ONE launch (A fetched once)",
              3: "k_gemm_tn<1,..> + k_tn_reduce: weight gradients with grid X (qkv / fc1 / patch-embed; dY one fp16 plane: 1 pass - or a bf16 pair: 2)",
              6: "k_gemm_tn + k_tn_reduce: weight gradients with float X (proj: X fp16; fc2: X as codes expanded in the kernel; 1 pass - 3 bf16 passes with QATVIT_DY16=0)"}
     SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_plain", 7: "nt_int8_stats_pass",
-             8: "nt_int8_fc1_store_pass", 9: "nt_int8_qkv_code_pass", 10: "nt_int8_fused_two_pass", 3: "tn_grid_x", 6: "tn_split_x"}
+             8: "nt_int8_fc1_store_pass", 9: "nt_int8_qkv_code_pass", 3: "tn_grid_x", 6: "tn_split_x"}
     prof = {}
     nprof = 0 if (args.graph or args.no_kernel_legs) else 3
     for kind in KINDS:
@@ -376,7 +375,6 @@ def main():
             7: dep * ((Mr * Dm + Hd * Dm) + ((Mr * Dm + 3 * Dm * Dm) if qkv2 else 0)),          # statistics passes: operands in, nothing stored
             8: dep * (Mr * Dm + Hd * Dm + Mr * Hd * (1 if codes else 4) + (Mr * Hd // 8 if bits else Mr * Hd * 2) + (0 if fc2w else Mr * Hd * 4)),   # fc1 storing pass: codes (or fp16 pair) + mask bits (or uint16 code) [+ bf16 pair]
             9: dep * (Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 9 // 8),                            # qkv code pass: 1 B + 1 bit per element out
-            10: dep * ((Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 9 // 8) + (Mr * Dm + Hd * Dm + Mr * Hd * 9 // 8)),   # fused qkv + fc1 launches: A once, codes + mask bits out
             3: (Mpe * Dm * 4 + Mpe * Kpe * 2 + Dm * Kpe * 4)
                + dep * ((Mr * 3 * Dm * dy + Mr * Dm * 2 + 3 * Dm * Dm * 4) + (Mr * Hd * dy + Mr * Dm * 2 + Hd * Dm * 4)),   # qkv, fc1 wgrad
             6: dep * ((Mr * Dm * dy + Mr * Dm * xf + Dm * Dm * 4) + (Mr * Dm * dy + Mr * Hd * (1 if fc2w else 4) + Hd * Dm * 4)),   # proj, fc2 wgrad (Q as codes)
@@ -386,7 +384,7 @@ def main():
             if ms <= 0 or cnt == 0:
                 continue
             rate = fl / (ms * 1e-3) / 1e12
-            peak = I8_PEAK_TOPS if kind in (2, 7, 8, 9, 10) else BF16_PEAK_TFLOPS
+            peak = I8_PEAK_TOPS if kind in (2, 7, 8, 9) else BF16_PEAK_TFLOPS
             lps = cnt / nprof
             by = step_bytes[kind] / lps if (args.student in ("vit_small", "vit_base") and lps > 0) else None
             g = {"kernel": KINDS[kind], "ms_per_step": round(ms / nprof, 3), "launches_per_step": round(lps, 1),
@@ -420,7 +418,7 @@ def main():
             "kernel": "qv::" + g["kernel"] + " - the GEMM kernel with the largest share of the step (208x384 tiles)",
             "achieved": g["algorithmic_GBps"] if hbm_bound else g["algorithmic_T(FL)OPs"],
             "peak": HBM_PEAK_GBS if hbm_bound else g["peak"],
-            "unit": "GB/s" if hbm_bound else ("TOP/s" if dom in (2, 7, 8, 9, 10) else "TFLOP/s"),
+            "unit": "GB/s" if hbm_bound else ("TOP/s" if dom in (2, 7, 8, 9) else "TFLOP/s"),
             "frac": g["frac_of_hbm_peak"] if hbm_bound else g["frac_of_peak"],
             "traffic": traffic, "traffic_note": traffic_note, "launches": int(g["launches_per_step"] * nprof), "avg_us_per_launch": g["avg_us_per_launch"],
             "flop_per_byte": g.get("flop_per_byte"), "ridge_flop_per_byte": g.get("ridge_flop_per_byte"),

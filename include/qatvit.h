@@ -364,7 +364,6 @@ int qatvit_optim_adamw(const void* param_ptrs, const void* grad_ptrs, const void
  * kind: 1 = NT with split (hi+lo) A operand and the plain epilogue (proj / fc2 forward, proj dgrad), 2 = NT with grid A operand on int8 MFMA, plain
  * epilogue (patch embedding; qkv when it runs once), 7 = its statistics-only passes (qkv, fc1), 8 = the fc1 storing pass, 9 = the qkv code pass, 3 = TN (wgrad) with grid X operand (qkv / fc1 / patch-embed; the bracket holds k_gemm_tn + k_tn_reduce), 6 = TN with split X operand (proj / fc2), 4 = NT split-A dgrad with the LayerNorm backward fused into its epilogue (fc1 / qkv dgrad), 5 = fc2 dgrad with
  * the GELU backward fused into its epilogue.
- * 10 = the fused two-pass launch (statistics pass + observer update + code pass of qkv / fc1 in one kernel: csrc/i8strip.hip).
  * stop() synchronises on the recorded events and returns the summed kernel time, launch count and the summed
  * algorithmic FLOPs (2*M*N*K per launch, one pass). */
 int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launches);

@@ -184,7 +184,7 @@ static int check_cfg(const qatvit_cfg& c) {
 // qatvit_profile_stop): stop only marks the session closed and unlinks it - the object dies with its last holder; qatvit_student_init drops a
 // session whose workspace is being re-bound (a re-allocated workspace must not inherit it).
 struct Prof {
-    int kind = 0;  // 1 NT split-A plain epilogue, 2 NT grid-A (int8), 3 TN, 4 NT split-A dgrad + fused LayerNorm backward, 5 fc2 dgrad + fused GELU', 6 TN split X, 7 / 8 / 9 int8 passes, 10 fused two-pass launch
+    int kind = 0;  // 1 NT split-A plain epilogue, 2 NT grid-A (int8), 3 TN, 4 NT split-A dgrad + fused LayerNorm backward, 5 fc2 dgrad + fused GELU', 6 TN split X, 7 / 8 / 9 int8 passes
     std::vector<hipEvent_t> ev;
     size_t used = 0;
     double flops = 0.0;
@@ -298,19 +298,6 @@ struct Ctx {
     const float* dy_mul(int i, int k) const { return reinterpret_cast<const float*>(dy_slot(i, k) + 1); }
     const float* dy_inv(int i, int k) const { return reinterpret_cast<const float*>(dy_slot(i, k) + 2); }
     void* wT16(int wi) const { int N, K; wshape(d, wi, &N, &K); return ws + p.wT_off[wi] + wT16_gap_bytes(N, K); }
-    // both passes of a two-pass GEMM (qkv, fc1) + the observer / qparams update of its output quantizer in ONE launch (i8strip.hip FUSED); header words 3 - 5 of
-    // the dy16 state hold its time-out flag and the two barrier words.  false -> not covered: the caller issues the three launches
-    bool linear_fwd_grid_fused(const void* A8, int M, int wi, const float* a_qp, const float* bias, int ai_out, const NTPost* post2) const {
-        int N, K; wshape(d, wi, &N, &K);
-        if (!use_i8() || !w_batched(d) || p.w8f_off[wi] < 0) return false;
-        const qatvit_fq& f = wfq[wi];
-        const qatvit_fq& o = act[ai_out];
-        uint32_t* hdr = at<uint32_t>(p.dy16);
-        ProfScope ps(prof, 10, 2.0 * M * N * K, st);
-        return launch_i8_strip_fused(A8, at<void>(p.w8f_off[wi]), at<int32_t>(p.wsum_off[wi]), a_qp, center(), M, N, K, K, N, a_qp, c.w_per_channel ? nullptr : f.scale,
-                                     c.w_per_channel ? f.scale : nullptr, bias, act_stats(ai_out), kStatSlots, o.min_val, o.max_val, o.scale, o.zero_point, o.observer_on,
-                                     o.fake_quant_on, c.averaging_const, act_qp(ai_out), hdr + 4, hdr + 3, st, post2);
-    }
     template <typename T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
     template <typename T> T* blk(int64_t off, int i) const { return reinterpret_cast<T*>(ws + off + p.blk_stride * i); }
     const float* prm(int i) const { return reinterpret_cast<const float*>(params[i]); }
@@ -459,18 +446,16 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
                               qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h1q8, i) : nullptr, x.center(), (x.flags & QATVIT_FWD_X16) != 0);
         if (qkv_2pass(c)) {
+            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
+            if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
+                                  x.aidx(i, AB_QKV), &p1))
+                return 1;
             NTPost p2{};
             p2.mode = 7; p2.qp = x.act_qp(x.aidx(i, AB_QKV)); p2.qmin = qa; p2.qmax = qb;
             p2.out8 = x.blk<void>(p.qkv8, i); p2.out8_mask = x.blk<void>(p.qkvm, i); p2.code_T = (int)d.T; p2.code_hd = (int)(d.D / d.H);
-            if (!x.linear_fwd_grid_fused(x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), x.aidx(i, AB_QKV), &p2)) {
-                const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
-                if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
-                                      x.aidx(i, AB_QKV), &p1))
-                    return 1;
-                if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
-                                      x.aidx(i, AB_QKV), &p2, false))
-                    return 1;
-            }
+            if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
+                                  x.aidx(i, AB_QKV), &p2, false))
+                return 1;
         } else if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB),
                                      x.blk<float>(p.qkv, i), x.aidx(i, AB_QKV)))
             return 1;
@@ -506,21 +491,19 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
             // feeds the observer (min/max, nothing stored); pass 2 - the same kernel on the same operands, so the same bits - quantises
             // with the fresh qparams and stores gelu(fq(.)) as the (hi, lo) pair fc2 reads plus a uint16 code (grid index | in-range
             // bit) for the backward.  The fp32 pre-FQ tensor and the separate fq+gelu pass (620 MB per block) disappear.
+            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
+            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
+                             x.aidx(i, AB_FC1), &p1))
+                return 1;
             NTPost p2{nullptr, x.act_qp(x.aidx(i, AB_FC1)), qa, qb, nullptr, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), 4,
                       x.blk<void>(p.Y1, i)};
             if (fc2_c) { p2.out8 = x.blk<void>(p.G8, i); p2.lut_out = x.blk<uint32_t>(p.glut, i); p2.out16_scale = scal16 + 1; }
             if (fc1_b) { p2.code = nullptr; p2.out8_mask = x.blk<void>(p.Y1m, i); }
             if (fc1_b && fc2w_code_form(x, i)) { p2.out_hi = p2.out_lo = nullptr; p2.lutq_out = x.blk<uint32_t>(p.glutq, i); }   // no 4-byte plane of gelu(fq(fc1)) at all
             else if (fc2_16) { p2.out16_hi = x.at<void>(p.G16_hi); p2.out16_lo = x.at<void>(p.G16_lo); p2.out16_scale = scal16 + 1; }
-            if (!x.linear_fwd_grid_fused(x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), x.aidx(i, AB_FC1), &p2)) {
-                const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
-                if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
-                                 x.aidx(i, AB_FC1), &p1))
-                    return 1;
-                if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
-                                 x.aidx(i, AB_FC1), &p2, false))
-                    return 1;
-            }
+            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
+                             x.aidx(i, AB_FC1), &p2, false))
+                return 1;
         }
         }
         if (parts & 8) {   // ---- part 3: fc2 -> residual (+ statistics of the next LayerNorm)
@@ -922,7 +905,7 @@ int qatvit_student_init(const qatvit_cfg* cfg, void* workspace, void* stream) {
         g_profs.erase(workspace);
     }
     launch_ws_init(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + p.stats), p.stats_words / 2, (hipStream_t)stream);
-    // the one-plane backward's scale history (no history: the first backward calibrates) and the fused strip launch's barrier words / time-out flag
+    // the one-plane backward's scale history starts empty (the first backward on a workspace calibrates)
     launch_zero_i32(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + p.dy16), dy16_state_bytes(DS_COUNT * cfg->depth) / 4, (hipStream_t)stream);
     QV_CHECK_LAUNCH("qatvit_student_init");
     return 0;
@@ -1021,7 +1004,7 @@ int qatvit_student_dy16_to_pair(const qatvit_cfg* cfg, void* workspace, void* st
 
 // bench.py: time every launch of one GEMM class of ONE engine (identified by its workspace) with HIP events on the stream it is launched on
 int qatvit_profile_start(const void* workspace, int32_t kind, int32_t max_launches) {
-    QV_CHECK_ARG(workspace && kind >= 1 && kind <= 10 && max_launches > 0, "qatvit_profile_start: bad arguments");
+    QV_CHECK_ARG(workspace && kind >= 1 && kind <= 9 && max_launches > 0, "qatvit_profile_start: bad arguments");
     auto pr = std::make_shared<Prof>();
     pr->ev.assign((size_t)max_launches * 2, nullptr);
     for (auto& e : pr->ev)

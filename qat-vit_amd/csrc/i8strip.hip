@@ -65,13 +65,6 @@ struct I8StripArgs {
     uint32_t* lutq_out;
     float* out16_scale;
     unsigned long long* dbg;   // experiments only: s_memtime stamps of workgroups 0 and 100 ([2][8 waves][32])
-    // FUSED launch (statistics pass, grid barrier, observer / qparams update, code pass in ONE kernel): the output quantizer's buffers and the barrier words
-    float* running_min; float* running_max; float* scale; int32_t* zero_point;
-    const int64_t* observer_on; const int64_t* fake_quant_on;
-    float avg_const;
-    float* qp_out;             // {scale, 1 / scale, zp, on}: what k_qparams publishes (the attention forward / the backward read it later)
-    uint32_t* sync;            // two zero-initialised words: arrivals behind the statistics pass / behind the qparams read; the kernel leaves them zero
-    uint32_t* fault;           // set to 1 if the grid barrier timed out (a workgroup of the launch was not resident): the results are then invalid
 };
 
 // LDS image of one [208][64 B] k-tile of A: two 64-B tile rows share one 128-B LDS row; chunk ((row & 1) * 4 + k-chunk) XOR (LDS row & 7)
@@ -91,13 +84,8 @@ __device__ inline void strip_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\
 // NTL column tiles of 384 per workgroup: N == gridDim.y * NTL * 384; NWV waves, each 16 TM rows x WC = 384 / NWV columns; K = 64 KT.
 // (TM, KT) = (13, 6): 208-row strips of K = 384 (ViT-S: 243 strips at batch 256, one round); (7, 12): 112-row strips of K = 768 (ViT-B: 226 strips at
 // batch 128, all 6 / 8 column tiles in one workgroup) - the strip has to fit LDS next to the constants and the staging patches.
-// FUSED: MODE names the code pass (7 or 4); the kernel first runs the statistics pass over the strip it holds, meets every other workgroup of the launch at
-// a grid barrier (all of them are resident: one per CU, the launcher checks the count against the CU count), derives the output quantizer's parameters from
-// the accumulated min / max - every workgroup for itself, the same arithmetic k_qparams runs, workgroup 0 also writes the module's buffers - and goes on
-// with the code pass on the A strip that is still in LDS.  One launch instead of three, A fetched once.
-template <int MODE, int NTL, int NWV = 8, bool R255 = false, int TM_ = 13, int KT_ = 6, bool FUSED = false>
+template <int MODE, int NTL, int NWV = 8, bool R255 = false, int TM_ = 13, int KT_ = 6>
 __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArgs p) {
-    static_assert(!FUSED || MODE == 7 || MODE == 4, "the fused launch ends in a code pass");
     constexpr int TM = TM_, TNT = 24 / NWV, WC = 16 * TNT, BM = 16 * TM, BN = 384, KT = KT_, PF = 3, NT_ = NWV * 64;
     static_assert(TM <= 2 * NWV, "the strip's 1-KiB DMA pieces are dealt in two rounds");
     static_assert(NWV == 8 || NWV == 12, "8 waves x 48 columns or 12 waves x 32 columns");
@@ -177,18 +165,16 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
         return Consts{*reinterpret_cast<const float4*>(sCa + c), *reinterpret_cast<const float4*>(sCb + c)};
     };
 
-    // MODE 4: the two 256-entry tables of gelu(grid value) and the fp16 pair's scale: data-independent, one workgroup writes them (q0 / q2 = scale and
-    // zero point of the output's quantizer)
-    auto write_tables = [&](float q0, float q2) {
+    if constexpr (MODE == 4) {   // the two 256-entry tables of gelu(grid value) and the fp16 pair's scale: data-independent, one workgroup writes them
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 256) {
-            const float ga = fabsf(((float)p.qmin - q2) * q0), gb = fabsf(((float)p.qmax - q2) * q0);
+            const float ga = fabsf(((float)p.qmin - p.qp[2]) * p.qp[0]), gb = fabsf(((float)p.qmax - p.qp[2]) * p.qp[0]);
             int ex;
             (void)frexpf(fmaxf(ga, gb), &ex);
             const float gs = ldexpf(1.0f, 14 - ex);
             if (p.out16_scale && tid == 0) *p.out16_scale = ldexpf(1.0f, ex - 14);
             uint32_t wq = 0u, wh = 0u;
             if (tid <= p.qmax - p.qmin) {
-                const float gv = gelu_fwd(((float)(tid + p.qmin) - q2) * q0);
+                const float gv = gelu_fwd(((float)(tid + p.qmin) - p.qp[2]) * p.qp[0]);
                 const __bf16 gh = (__bf16)gv;
                 const __bf16 gl = (__bf16)(gv - (float)gh);
                 wq = (uint32_t)__builtin_bit_cast(uint16_t, gh) | ((uint32_t)__builtin_bit_cast(uint16_t, gl) << 16);
@@ -200,8 +186,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
             if (p.lut_out) p.lut_out[tid] = wh;
             if (p.lutq_out) p.lutq_out[tid] = wq;
         }
-    };
-    if constexpr (MODE == 4 && !FUSED) write_tables(p.qp[0], p.qp[2]);
+    }
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's A pieces have landed, its constants are written ...
     QV_STAMP();   // own DMA landed
@@ -209,15 +194,10 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
     asm volatile("" ::: "memory");
     QV_STAMP();   // strip complete
 
-    float mn = INFINITY, mx = -INFINITY;                 // statistics pass
+    float mn = INFINITY, mx = -INFINITY;                 // MODE 3
     const bool ragged = m0 + BM > p.M;                   // (uniform) the last strip holds rows past M: they read as zero and must not be observed / stored
-    float qp_inv = 0.f, qp_zp = 0.f;                     // code pass: 1 / scale and zero point of the output's quantizer
-    if constexpr (!FUSED && MODE != 3) { qp_inv = p.qp[1]; qp_zp = p.qp[2]; }
 
     i32x4 acc[TM][TNT];
-    // one pass over the workgroup's column tiles; PM = 3: statistics, 7 / 4: codes
-    auto run_pass = [&](auto pm_tag) {
-    constexpr int PM = decltype(pm_tag)::value;
 #pragma clang loop unroll(disable)
     for (int nt = 0; nt < NTL; ++nt) {
         // the zero-point correction (center - zp) * wsum[n] is the INITIAL accumulator: the first k-step's MFMAs read it as their C operand
@@ -253,7 +233,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
         // wave priorities (code passes): MFMA phase above every quantise phase, so a wave's k-loop runs dense under its SIMD partner's epilogue; between
         // two waves that are both quantising, the one favoured alternates per column tile (at equal priority the older wave always wins and finishes
         // ~20 k cycles before its partner, which then runs alone at the one-wave VALU rate): 45.1 -> 42.0 us (qkv), 57.0 -> 54.7 us (fc1)
-        if constexpr (PM != 3) __builtin_amdgcn_s_setprio(2);
+        if constexpr (MODE != 3) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             // request k-step kt + 1 (of this column tile or the next: the next tile's first fragments are then in flight BEFORE the epilogue's
@@ -263,12 +243,12 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
             kstep(kt, bb[kt & 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PM != 3) {
+        if constexpr (MODE != 3) {
             if (((wave >> 2) + nt) % (NWV / 4) == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (wave is an SGPR: a scalar branch)
         }
         QV_STAMP();   // k-loop done
 
-        if constexpr (PM == 3) {
+        if constexpr (MODE == 3) {
             // integer min / max per column over this lane's 13 tokens, then the (monotone: ca > 0) float map once per column
             int tid3 = threadIdx.x;                      // (opaque copy: the ragged strip's 13 row predicates are otherwise computed up front and spilled)
             asm volatile("" : "+v"(tid3));
@@ -306,7 +286,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
             // code = clamp(u, 0, qmax - qmin).  In range <=> 0 <= u <= range <=> the BIT PATTERN of u, as an unsigned integer, is <= that of range:
             // non-negative floats order like their bits, a negative u has the sign bit set (u is never -0: rint(.) + zoff with zoff >= +0), a NaN
             // is above every finite pattern - one integer compare, no clamp needed for the test
-            const float qinv = qp_inv, zoff = qp_zp - (float)p.qmin, frange = (float)(p.qmax - p.qmin);
+            const float qinv = p.qp[1], zoff = p.qp[2] - (float)p.qmin, frange = (float)(p.qmax - p.qmin);
             const uint32_t range_bits = __builtin_bit_cast(uint32_t, frange);
             const int tilebase = nbase + nt * BN;
             // (lane-derived values are re-derived from an opaque copy of the thread id: kept live across the k-loop they are spilled, and every
@@ -317,8 +297,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
             char* sW = sStage + wave * WSTG;             // this wave's staging area: [64][48 B] codes, then [64][16 B]: the 4 mask bits of fragment j, lane group g in byte 4 j + g
             char* sWm = sW + 16 * CH * WC;
             // output geometry of this wave's 48 columns
-            const int which = PM == 7 ? tilebase / p.D : 0, cm0 = PM == 7 ? tilebase % p.D + wave * WC : 0, Hh = PM == 7 ? p.D >> 6 : 0;
-            const float invT = PM == 7 ? 1.0f / (float)p.code_T : 0.f;
+            const int which = MODE == 7 ? tilebase / p.D : 0, cm0 = MODE == 7 ? tilebase % p.D + wave * WC : 0, Hh = MODE == 7 ? p.D >> 6 : 0;
+            const float invT = MODE == 7 ? 1.0f / (float)p.code_T : 0.f;
 #pragma unroll
             for (int c0 = 0; c0 < TM; c0 += CH) {        // chunks of 4 row fragments (64 rows); the last one holds 1 (16 rows)
                 const int nf = TM - c0 < CH ? TM - c0 : CH;
@@ -361,7 +341,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
                     uint32_t mx4 = *reinterpret_cast<const uint32_t*>(sWm + rl * 16 + 4 * c) & 0x0f0f0f0fu;
                     mx4 = (mx4 | (mx4 >> 4)) & 0x00ff00ffu;
                     const uint16_t mv = (uint16_t)((mx4 | (mx4 >> 8)) & 0xffffu);
-                    if constexpr (PM == 4) {
+                    if constexpr (MODE == 4) {
                         // (24-bit multiplies: row < 2^22 and ldc < 2^24 are checked by the launcher; the 32-bit forms run at a quarter of the rate)
                         const uint32_t eo = __umul24((uint32_t)row, (uint32_t)p.ldc) + (uint32_t)(tilebase + wave * WC + 16 * c);
                         if (ok) {
@@ -385,9 +365,9 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
             QV_STAMP();   // tile's epilogue done
         }
     }
-    };   // run_pass
-    // the workgroup's min / max into the observer's accumulator (statistics pass)
-    auto publish_stats = [&]() {
+
+    QV_STAMP();   // end
+    if constexpr (MODE == 3) {
         float* sRed = reinterpret_cast<float*>(sStage);
         mn = wave_min(mn);
         mx = wave_max(mx);
@@ -398,86 +378,16 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
             for (int w = 1; w < NWV; ++w) { mn = fminf(mn, sRed[w]); mx = fmaxf(mx, sRed[16 + w]); }
         }
         if (tid == 0) stat_atomic(p.stats, p.stat_slots, mn, mx);
-    };
-
-    if constexpr (!FUSED) {
-        run_pass(std::integral_constant<int, MODE>{});
-        QV_STAMP();   // end
-        if constexpr (MODE == 3) publish_stats();
-    } else {
-        run_pass(std::integral_constant<int, 3>{});
-        publish_stats();
-        // ---- grid barrier + observer / qparams update.  Every workgroup of the launch is resident (launcher), so spinning cannot dead-lock; the spin is
-        // bounded all the same (a wave that never leaves would hang the device): on a time-out the fault word is set and the pass goes on with stale
-        // parameters - the host sees the flag.
-        const uint32_t nwg = gridDim.x * gridDim.y;
-        float* sQp = reinterpret_cast<float*>(sStage + NWV * WSTG);   // {scale, 1 / scale, zp} of the output's quantizer: behind the staging areas (16 B the fused launch adds)
-        if (wave == 0) {
-            if (lane == 0) {
-                __threadfence();                                 // this workgroup's min / max atomics are visible before its arrival is
-                atomicAdd(&p.sync[0], 1u);
-                uint32_t spins = 0;
-                while (__hip_atomic_load(&p.sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) { atomicExch(p.fault, 1u); break; }
-                }
-            }
-            // (lanes 1 .. 63 wait at the wave's reconvergence point; then the whole wave folds the accumulator pairs - the arithmetic of qparams_body)
-            const int l = lane;
-            uint32_t omn = l < p.stat_slots ? __hip_atomic_load(&p.stats[l * kStatStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOrdPosInf;
-            uint32_t omx = l < p.stat_slots ? __hip_atomic_load(&p.stats[l * kStatStride + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOrdNegInf;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                omn = min(omn, (uint32_t)__shfl_xor((int)omn, o, 64));
-                omx = max(omx, (uint32_t)__shfl_xor((int)omx, o, 64));
-            }
-            float rmn = __hip_atomic_load(p.running_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), rmx = __hip_atomic_load(p.running_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float sc = __hip_atomic_load(p.scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int32_t zp = __hip_atomic_load(p.zero_point, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool obs_on = *p.observer_on != 0, fq_on = *p.fake_quant_on != 0;
-            if (obs_on) { rmn = ema(rmn, ord2f(omn), p.avg_const); rmx = ema(rmx, ord2f(omx), p.avg_const); }
-            if (fq_on && rmn <= rmx) choose_qparams(rmn, rmx, p.qmin, p.qmax, false, &sc, &zp);
-            if (lane == 0) {
-                sQp[0] = sc; sQp[1] = __fdiv_rn(1.0f, sc); sQp[2] = (float)zp;
-                __threadfence();                                 // everything above was READ before this workgroup reports so
-                atomicAdd(&p.sync[1], 1u);
-                if (blockIdx.x == 0 && blockIdx.y == 0) {
-                    // the one writer: once every workgroup has read the old state, publish the new one, re-arm the accumulators and the barrier words
-                    uint32_t spins = 0;
-                    while (__hip_atomic_load(&p.sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1u << 22)) { atomicExch(p.fault, 1u); break; }
-                    }
-                    if (obs_on) { *p.running_min = rmn; *p.running_max = rmx; }
-                    if (fq_on && rmn <= rmx) { *p.scale = sc; *p.zero_point = zp; }
-                    p.qp_out[0] = sc; p.qp_out[1] = __fdiv_rn(1.0f, sc); p.qp_out[2] = (float)zp; p.qp_out[3] = fq_on ? 1.f : 0.f;
-                    for (int k = 0; k < p.stat_slots; ++k) { p.stats[k * kStatStride] = kOrdPosInf; p.stats[k * kStatStride + 1] = kOrdNegInf; }
-                    __threadfence();
-                    p.sync[0] = 0u; p.sync[1] = 0u;
-                }
-            }
-        }
-        load_b(0, 0, bb[0]);                                     // the code pass' first weight fragments travel under the barrier
-        strip_lds_barrier();                                     // sQp is published
-        qp_inv = sQp[1]; qp_zp = sQp[2];
-        if constexpr (MODE == 4) write_tables(sQp[0], sQp[2]);
-        run_pass(std::integral_constant<int, MODE>{});
-        QV_STAMP();   // end
     }
 }
 
-template <int MODE, int NTL, int NWV, bool R255, int TM, int KT, bool FUSED = false>
+template <int MODE, int NTL, int NWV, bool R255, int TM, int KT>
 static void strip_launch_r(const I8StripArgs& a, hipStream_t st) {
-    constexpr int kLds = KT * 16 * TM * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : NWV * (64 * (384 / NWV) + 64 * 16)) + (FUSED ? 16 : 0);
+    constexpr int kLds = KT * 16 * TM * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : NWV * (64 * (384 / NWV) + 64 * 16));
     static_assert(kLds <= 160 * 1024, "strip + constants + staging patches exceed the LDS");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, NWV, R255, TM, KT, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, NWV, R255, TM, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
     (void)once;
-    k_i8_strip<MODE, NTL, NWV, R255, TM, KT, FUSED><<<dim3(cdiv(a.M, 16 * TM), a.N / (NTL * 384)), NWV * 64, kLds, st>>>(a);
-}
-template <int MODE, int NTL, int TM = 13, int KT = 6>
-static void strip_launch_fused(const I8StripArgs& a, hipStream_t st) {   // (12 waves: the code pass' shape; the statistics pass measured the same at 8 and 12)
-    if (a.qmax - a.qmin == 255) strip_launch_r<MODE, NTL, 12, true, TM, KT, true>(a, st);
-    else strip_launch_r<MODE, NTL, 12, false, TM, KT, true>(a, st);
+    k_i8_strip<MODE, NTL, NWV, R255, TM, KT><<<dim3(cdiv(a.M, 16 * TM), a.N / (NTL * 384)), NWV * 64, kLds, st>>>(a);
 }
 template <int MODE, int NTL, int NWV, int TM, int KT>
 static void strip_launch_w(const I8StripArgs& a, hipStream_t st) {
@@ -535,49 +445,6 @@ bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const
         a.ldc = ldc; a.lut_out = post->lut_out; a.lutq_out = post->lutq_out; a.out16_scale = post->out16_scale;
         if (wide) { if (ntl == 8) strip_launch<4, 8, 7, 12>(a, st); else strip_launch<4, 6, 7, 12>(a, st); }
         else if (ntl == 4) strip_launch<4, 4>(a, st); else strip_launch<4, 3>(a, st);
-        return true;
-    }
-    return false;
-}
-
-// Both passes of a two-pass GEMM in ONE launch (see k_i8_strip, FUSED): running_min .. fake_quant_on = the OUTPUT quantizer's buffers, stats its
-// accumulator, qp_out the {scale, 1 / scale, zp, on} slot k_qparams would publish, sync two zeroed words, fault the time-out flag.  false -> not covered
-// (the caller runs the statistics pass, k_qparams and the code pass as three launches).
-bool launch_i8_strip_fused(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
-                           const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, float* running_min,
-                           float* running_max, float* scale, int32_t* zero_point, const int64_t* observer_on, const int64_t* fake_quant_on, float avg_const,
-                           float* qp_out, uint32_t* sync, uint32_t* fault, hipStream_t st, const NTPost* post) {
-    static const int on = (getenv("QATVIT_I8_STRIP") ? atoi(getenv("QATVIT_I8_STRIP")) : 1) && (getenv("QATVIT_I8_FUSED") ? atoi(getenv("QATVIT_I8_FUSED")) : 1);
-    if (!on || !B8f || !post || (K != 384 && K != 768) || lda % 16 != 0 || !s1 || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24)) return false;
-    if (!stats || stat_slots < 1 || stat_slots > 64 || !running_min || !running_max || !scale || !zero_point || !observer_on || !fake_quant_on || !qp_out || !sync || !fault) return false;
-    const int ntl = K == 384 ? (N % (4 * 384) == 0 ? 4 : N % (3 * 384) == 0 ? 3 : 0) : (N == 6 * 384 ? 6 : N == 8 * 384 ? 8 : 0);
-    if (!ntl) return false;
-    const bool wide = K == 768;
-    // the grid barrier needs every workgroup resident at once: one per CU (the strip alone is half of a CU's LDS)
-    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-    if (cdiv(M, wide ? 112 : 208) * (N / (ntl * 384)) > cus) return false;
-    I8StripArgs a{};
-    a.A = reinterpret_cast<const int8_t*>(A8); a.Bf = reinterpret_cast<const i32x4*>(B8f); a.M = M; a.N = N; a.lda = lda;
-    a.s1 = s1; a.s2 = s2; a.col_scale = col_scale; a.bias = bias; a.wsum = wsum; a.aqp = a_qp; a.center = center;
-    a.stats = stats; a.stat_slots = stat_slots;
-    a.running_min = running_min; a.running_max = running_max; a.scale = scale; a.zero_point = zero_point; a.observer_on = observer_on; a.fake_quant_on = fake_quant_on;
-    a.avg_const = avg_const; a.qp_out = qp_out; a.sync = sync; a.fault = fault;
-    a.qmin = post->qmin; a.qmax = post->qmax;
-    a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.out8_mask = reinterpret_cast<uint8_t*>(post->out8_mask);
-    if (!a.out8 || !a.out8_mask || a.qmax - a.qmin >= 256) return false;
-    if (post->mode == 7) {
-        const int D = N / 3;
-        if (post->code_hd != 64 || D % 384 != 0 || post->code_T < 1 || post->code_T >= 1024) return false;
-        a.code_T = post->code_T; a.D = D;
-        if (wide) { if (ntl == 8) strip_launch_fused<7, 8, 7, 12>(a, st); else strip_launch_fused<7, 6, 7, 12>(a, st); }
-        else if (ntl == 4) strip_launch_fused<7, 4>(a, st); else strip_launch_fused<7, 3>(a, st);
-        return true;
-    }
-    if (post->mode == 4) {
-        if (post->out_hi || post->out_lo || post->code || post->out16_hi || post->out16_lo || !post->lut_out || !post->lutq_out || ldc % 128 != 0) return false;
-        a.ldc = ldc; a.lut_out = post->lut_out; a.lutq_out = post->lutq_out; a.out16_scale = post->out16_scale;
-        if (wide) { if (ntl == 8) strip_launch_fused<4, 8, 7, 12>(a, st); else strip_launch_fused<4, 6, 7, 12>(a, st); }
-        else if (ntl == 4) strip_launch_fused<4, 4>(a, st); else strip_launch_fused<4, 3>(a, st);
         return true;
     }
     return false;

@@ -106,11 +106,6 @@ int launch_gemm_nt_dy16(const void* A16, const void* B16, float* C, int M, int N
 bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
                      const NTPost* post, bool force = false);
-// statistics pass + observer / qparams update + code pass of a two-pass GEMM in ONE launch (grid barrier; i8strip.hip FUSED); false -> not covered
-bool launch_i8_strip_fused(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
-                           const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, float* running_min,
-                           float* running_max, float* scale, int32_t* zero_point, const int64_t* observer_on, const int64_t* fake_quant_on, float avg_const,
-                           float* qp_out, uint32_t* sync, uint32_t* fault, hipStream_t st, const NTPost* post);
 // byte offset of element (n, k) of an [N, K] int8 weight in fragment order: [48-column group][64-deep k-step][16-column fragment][lane = 16 (k % 64 / 16) + n % 16][k % 16]
 __host__ __device__ inline int64_t w8f_offset(int n, int k, int K) {
     const int cg = n / 48, cr = n % 48, j = cr / 16, r = cr % 16, kt = k / 64, kk = k % 64;

@@ -302,7 +302,6 @@ class StudentEngine:
         self._dy16_calibrated = False
         off = L.qatvit_student_tensor_offset(cp, b"dy16", 0)
         self._dy16_flag = self.workspace[off + 8:off + 12].view(torch.int32)   # header word 2: overflow
-        self._strip_fault = self.workspace[off + 12:off + 16].view(torch.int32)  # header word 3: the fused two-pass launch's grid barrier timed out
 
     # ------------------------------------------------------------------ FQ state arena
     def _rehome_fq_state(self):
@@ -384,9 +383,6 @@ class StudentEngine:
     def dy16_overflowed(self) -> bool:
         """Did the last one-plane backward meet a gradient that did not fit its fp16 plane?  Blocks on the stream; in a data-parallel group the
         answer is agreed on (MAX over the ranks) so that every rank repeats the backward, and its collectives, or none does."""
-        if int(self._strip_fault.item()):
-            raise RuntimeError("qat-vit_amd: the grid barrier of a fused two-pass GEMM launch timed out (a workgroup was not resident: is the GPU shared?); "
-                               "this forward's codes are invalid. QATVIT_I8_FUSED=0 runs the passes as separate launches.")
         flag = self._dy16_flag
         if self.pg is not None:
             flag = flag.clone()
