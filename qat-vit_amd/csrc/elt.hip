@@ -110,11 +110,15 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
                                                           float* __restrict__ x_new, float* __restrict__ mean, float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           uint32_t* __restrict__ stats, int stat_slots, int64_t M, int D, int T,
-                                                          unsigned long long* __restrict__ maskbits) {
+                                                          unsigned long long* __restrict__ maskbits, const QpLate late) {
     // maskbits (MODE 1, optional): the STE mask of fq(Y), one bit per element, as wave ballots - word [(row * NV + j) * 4 + e] holds in
     // bit `lane` the mask of column lane * 4 + 256 j + e.  k_ln_bwd_fq (same lane -> column mapping) reads it back with scalar loads,
     // so the backward never touches the fp32 Y again.
-    const QP q = load_qp(qpY);
+    // late.stats: the qparams of Y's quantizer are resolved here (qv_qparams.h QpLate) instead of by a k_qparams launch in front of this kernel
+    __shared__ float sQp[4];
+    QP q;
+    if (late.stats) { const float4 r = qp_late_resolve(late, sQp); q = QP{r.x, r.y, r.z, r.w}; }
+    else q = load_qp(qpY);
     const int lane = threadIdx.x & 63;
     bool act[NV];
     int cc[NV];
@@ -200,10 +204,13 @@ __global__ __launch_bounds__(256) void k_resid_fq_lnstats(const float* __restric
 __global__ __launch_bounds__(256) void k_ln_apply_quant(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ qp,
                                                         int qmin, int qmax, __bf16* __restrict__ out, int64_t M, int D,
-                                                        int8_t* __restrict__ out8, int center, int out_f16) {
+                                                        int8_t* __restrict__ out8, int center, int out_f16, const QpLate late) {
     // out = q - zp as bf16 (the exact operand of the weight-gradient GEMM); out8 (optional) = q - center as int8 (the operand of the
     // int8-MFMA forward GEMM)
-    const QP q = load_qp(qp);
+    __shared__ float sQp[4];
+    QP q;
+    if (late.stats) { const float4 r = qp_late_resolve(late, sQp); q = QP{r.x, r.y, r.z, r.w}; }   // (QpLate: no k_qparams launch in front of this kernel)
+    else q = load_qp(qp);
     const int d4 = D / 4;
     const int64_t n4 = M * d4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -689,10 +696,11 @@ int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qm
 
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
                             float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
-                            int64_t M, int D, int T, hipStream_t st, void* maskbits) {
+                            int64_t M, int D, int T, hipStream_t st, void* maskbits, const QpLate* late) {
     if (D % 4 != 0 || D > 256 * kMaxV) { set_error("resid_fq_lnstats: D=%d unsupported (need D%%4==0, D<=768)", D); return 1; }
     unsigned long long* mbits = mode != 1 ? nullptr : reinterpret_cast<unsigned long long*>(maskbits);
-#define QV_RESID(MODE_, NV_) k_resid_fq_lnstats<MODE_, NV_><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T, mbits)
+    const QpLate lt = late ? *late : QpLate{};
+#define QV_RESID(MODE_, NV_) k_resid_fq_lnstats<MODE_, NV_><<<rows_grid(M), 256, 0, st>>>(x_prev, Y, qpY, qmin, qmax, cls, pos, x_new, mean, rstd, gamma, beta, eps, stats, stat_slots, M, D, T, mbits, lt)
     const int nv = (D + 255) / 256;
     if (mode == 0) { if (nv == 1) QV_RESID(0, 1); else if (nv == 2) QV_RESID(0, 2); else QV_RESID(0, 3); }
     else if (mode == 1) { if (nv == 1) QV_RESID(1, 1); else if (nv == 2) QV_RESID(1, 2); else QV_RESID(1, 3); }
@@ -702,9 +710,9 @@ int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const
 }
 
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
-                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8, int center, bool out_f16) {
+                          int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8, int center, bool out_f16, const QpLate* late) {
     k_ln_apply_quant<<<flat_grid(M * (D / 4)), 256, 0, st>>>(x, mean, rstd, gamma, beta, qp, qmin, qmax, reinterpret_cast<__bf16*>(out_bf16), M, D,
-                                                             reinterpret_cast<int8_t*>(out8), center, out_f16 ? 1 : 0);
+                                                             reinterpret_cast<int8_t*>(out8), center, out_f16 ? 1 : 0, late ? *late : QpLate{});
     return 0;
 }
 

@@ -75,6 +75,7 @@ struct Plan {
     int64_t w8f_off[64 * 4 + 8];   // the int8 weight once more in fragment order (qkv, fc1 with K == 384 / 768: the strip kernel's B operand), -1 otherwise
     int64_t w16_off[64 * 4 + 8], O16_hi, O16_lo, G16_hi, G16_lo, scal16;   // fp16 operands of the forward float x grid GEMMs (proj, fc2): O16 / scal16 per block, G16 shared
     int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo, tn_scratch;
+    int64_t qp_staged;   // staging records of the late-resolved quantizers (qv_kernels.h QpLate): kQpStagedWords words per activation quantizer
     int64_t dy16;   // scale state of the one-plane backward (dy16.hip): 4 slots per block - the gradients entering fc2, fc1, proj, qkv
     int64_t total, stats_words;
     int TP;
@@ -101,6 +102,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     }
     p->stats_words = (int64_t)d.n_act * kStatSlots * kStatStride + wstat_words;
     p->stats = take(p->stats_words * 4);
+    p->qp_staged = take((int64_t)d.n_act * kQpStagedWords * 4);
     p->dy16 = take(dy16_state_bytes(DS_COUNT * d.depth));   // (next to the observer accumulators: its place does not depend on the batch either)
     p->qp_act = take((int64_t)d.n_act * 4 * 4);
     p->qp_w = take(wqp_floats * 4);
@@ -309,18 +311,53 @@ struct Ctx {
     int a_norm() const { return A_BLOCK0 + AB_COUNT * d.depth; }
     int a_head() const { return a_norm() + 1; }
     int widx(int blk_i, int k) const { return 1 + WB_COUNT * blk_i + k; }
-    // the observer / qparams update of activation quantizer ai: its own single-wave launch right behind the producer of its statistics
-    void qparams_after(int ai, bool produced_stats) const {
-        if (produced_stats) qparams_act(ai);
+    // ---- late qparams (qv_kernels.h QpLate, QATVIT_QP_LATE=0 switches it off): the quantizers whose consumer kernel resolves the observer / qparams update
+    // itself - the LayerNorm outputs (k_ln_apply_quant), the proj / fc2 outputs (k_resid_fq_lnstats) of every block always, the qkv / fc1 outputs where the
+    // strip kernel's code pass is their consumer (decided by the caller: late_strip) - need no k_qparams launch behind the producer of their statistics
+    static bool late_on() {
+        static const int on = getenv("QATVIT_QP_LATE") ? atoi(getenv("QATVIT_QP_LATE")) : 1;
+        return on != 0;
     }
-    // launch_resid_fq_lnstats with the LayerNorm-output quantizer ai_stats updated behind it
-    int resid_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, const float* cls, const float* pos, float* x_new, float* mean,
+    bool late_kind(int ai) const {
+        if (!late_on() || d.n_act > kMaxActFq || ai < A_BLOCK0 || ai >= A_BLOCK0 + AB_COUNT * d.depth) return false;
+        const int k = (ai - A_BLOCK0) % AB_COUNT;
+        return k == AB_N1 || k == AB_N2 || k == AB_PROJ || k == AB_FC2;
+    }
+    QpLate late(int ai) const {
+        const qatvit_fq& f = act[ai];
+        return QpLate{act_stats(ai), f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const, c.act_qmin, c.act_qmax,
+                      act_qp(ai), at<float>(p.qp_staged) + (int64_t)ai * kQpStagedWords};
+    }
+    // the staged states into the modules' buffers: once at the end of every forward call
+    int commit_late() const {
+        if (!late_on() || d.n_act > kMaxActFq) return 0;
+        QpCommitTab t{};
+        t.n = d.n_act; t.staged = at<float>(p.qp_staged); t.stats = at<uint32_t>(p.stats);
+        for (int ai = 0; ai < d.n_act; ++ai) { t.rmin[ai] = act[ai].min_val; t.rmax[ai] = act[ai].max_val; t.scale[ai] = act[ai].scale; t.zp[ai] = act[ai].zero_point; }
+        return launch_qp_commit(t, st);
+    }
+    // the observer / qparams update of activation quantizer ai: its own single-wave launch right behind the producer of its statistics - unless its consumer
+    // resolves it (late_kind; `deferred`: the caller knows that the strip kernel's code pass will)
+    void qparams_after(int ai, bool produced_stats, bool deferred = false) const {
+        if (produced_stats && !deferred && !late_kind(ai)) qparams_act(ai);
+    }
+    // launch_resid_fq_lnstats (Y = the output of quantizer ai_Y, -1: none) with the LayerNorm-output quantizer ai_stats updated behind it
+    int resid_lnstats(int mode, const float* x_prev, const float* Y, int ai_Y, const float* cls, const float* pos, float* x_new, float* mean,
                       float* rstd, const float* gamma, const float* beta, int ai_stats, void* maskbits = nullptr) const {
-        if (launch_resid_fq_lnstats(mode, x_prev, Y, qpY, c.act_qmin, c.act_qmax, cls, pos, x_new, mean, rstd, gamma, beta, c.ln_eps, act_stats(ai_stats),
-                                    kStatSlots, d.M, d.D, d.T, st, maskbits))
+        const bool lt = ai_Y >= 0 && late_kind(ai_Y);
+        const QpLate L = lt ? late(ai_Y) : QpLate{};
+        if (launch_resid_fq_lnstats(mode, x_prev, Y, act_qp(ai_Y >= 0 ? ai_Y : 0), c.act_qmin, c.act_qmax, cls, pos, x_new, mean, rstd, gamma, beta, c.ln_eps,
+                                    act_stats(ai_stats), kStatSlots, d.M, d.D, d.T, st, maskbits, lt ? &L : nullptr))
             return 1;
         qparams_after(ai_stats, true);
         return 0;
+    }
+    // launch_ln_apply_quant for the LayerNorm-output quantizer ai
+    int ln_apply(const float* xrow, const float* mean, const float* rstd, const float* gamma, const float* beta, int ai, void* out16, void* out8) const {
+        const bool lt = late_kind(ai);
+        const QpLate L = lt ? late(ai) : QpLate{};
+        return launch_ln_apply_quant(xrow, mean, rstd, gamma, beta, act_qp(ai), c.act_qmin, c.act_qmax, out16, d.M, d.D, st, use_i8() ? out8 : nullptr, center(),
+                                     (flags & QATVIT_FWD_X16) != 0, lt ? &L : nullptr);
     }
     void qparams_act(int ai) const {
         const qatvit_fq& f = act[ai];
@@ -376,21 +413,31 @@ struct Ctx {
     int center() const { return (c.act_qmin + c.act_qmax + 1) / 2; }
     // the same forward product with int8 operands: A8 = q - center written next to the bf16 grid by its producer, weight integers + row sums
     // from k_w_quant_all.  Falls back to the bf16 form for shapes the int8 tile does not cover.
+    // late_strip: the output quantizer's qparams are resolved by the strip kernel's code pass (the caller checked strip_consumes): the statistics pass
+    // (post mode 3) then launches no k_qparams, the code pass gets the QpLate record
     int linear_fwd_grid(const void* A16, const void* A8, int M, int wi, const float* a_qp, const float* bias, float* C, int ai_out,
-                        const NTPost* post = nullptr, bool with_stats = true) const {
+                        const NTPost* post = nullptr, bool with_stats = true, bool late_strip = false) const {
         int N, K; wshape(d, wi, &N, &K);
         if (!use_i8() || N % 384 != 0 || K % 64 != 0) return linear_fwd(A16, nullptr, M, wi, a_qp, bias, C, ai_out, post, with_stats);
         const qatvit_fq& f = wfq[wi];
         {
             ProfScope ps(prof, !post ? 2 : post->mode == 3 ? 7 : post->mode == 4 ? 8 : post->mode == 7 ? 9 : 2, (post && post->mode == 3) ? 0.0 : 2.0 * M * N * K, st);
+            const bool code_pass = late_strip && post && post->mode != 3;
+            const QpLate L = code_pass ? late(ai_out) : QpLate{};
             if (launch_gemm_nt_i8(A8, at<void>(p.w8_off[wi]), at<int32_t>(p.wsum_off[wi]), a_qp, center(), C, M, N, K, K, K, N, a_qp,
                                   c.w_per_channel ? nullptr : f.scale, c.w_per_channel ? f.scale : nullptr, bias,
                                   with_stats ? act_stats(ai_out) : nullptr, kStatSlots, st, post,
-                                  (w_batched(d) && p.w8f_off[wi] >= 0) ? at<void>(p.w8f_off[wi]) : nullptr))
+                                  (w_batched(d) && p.w8f_off[wi] >= 0) ? at<void>(p.w8f_off[wi]) : nullptr, code_pass ? &L : nullptr))
                 return 1;
         }
-        qparams_after(ai_out, with_stats);
+        qparams_after(ai_out, with_stats, late_strip);
         return 0;
+    }
+    // will the strip kernel's code pass (post2) be the consumer of quantizer-of-layer-wi's statistics?  (then it resolves the qparams itself)
+    bool strip_consumes(int M, int wi, const NTPost* post2) const {
+        int N, K; wshape(d, wi, &N, &K);
+        return late_on() && d.n_act <= kMaxActFq && use_i8() && N % 384 == 0 && K % 64 == 0 && w_batched(d) && p.w8f_off[wi] >= 0 &&
+               i8_strip_covers(at<void>(p.w8f_off[wi]), M, N, K, K, N, post2);
     }
     // the per-channel weight scale of layer wi, which its dY producer folds in (nullptr for per-tensor)
     const float* dy_colscale(int wi) const { return c.w_per_channel ? wfq[wi].scale : nullptr; }
@@ -443,18 +490,19 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         float* xin = x.blk<float>(p.x_in, i);
         float* xmid = x.blk<float>(p.x_mid, i);
         if (parts & 1) {   // ---- part 0: norm1 -> qkv   (every quantizer's observer / qparams update runs behind the producer of its statistics)
-        launch_ln_apply_quant(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.act_qp(x.aidx(i, AB_N1)),
-                              qa, qb, x.blk<void>(p.h1q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h1q8, i) : nullptr, x.center(), (x.flags & QATVIT_FWD_X16) != 0);
+        x.ln_apply(xin, x.blk<float>(p.mean1, i), x.blk<float>(p.rstd1, i), x.bprm(i, B_N1W), x.bprm(i, B_N1B), x.aidx(i, AB_N1), x.blk<void>(p.h1q, i),
+                   x.blk<void>(p.h1q8, i));
         if (qkv_2pass(c)) {
-            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
-            if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
-                                  x.aidx(i, AB_QKV), &p1))
-                return 1;
             NTPost p2{};
             p2.mode = 7; p2.qp = x.act_qp(x.aidx(i, AB_QKV)); p2.qmin = qa; p2.qmax = qb;
             p2.out8 = x.blk<void>(p.qkv8, i); p2.out8_mask = x.blk<void>(p.qkvm, i); p2.code_T = (int)d.T; p2.code_hd = (int)(d.D / d.H);
+            const bool lt = x.strip_consumes(M, x.widx(i, WB_QKV), &p2);   // the code pass resolves the qkv quantizer's qparams itself: no k_qparams launch between the passes
+            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
             if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
-                                  x.aidx(i, AB_QKV), &p2, false))
+                                  x.aidx(i, AB_QKV), &p1, true, lt))
+                return 1;
+            if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB), nullptr,
+                                  x.aidx(i, AB_QKV), &p2, false, lt))
                 return 1;
         } else if (x.linear_fwd_grid(x.blk<void>(p.h1q, i), x.blk<void>(p.h1q8, i), M, x.widx(i, WB_QKV), x.act_qp(x.aidx(i, AB_N1)), x.bprm(i, B_QKVB),
                                      x.blk<float>(p.qkv, i), x.aidx(i, AB_QKV)))
@@ -478,31 +526,31 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         } else if (x.linear_fwd(x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), M, x.widx(i, WB_PROJ), nullptr, x.bprm(i, B_PROJB),
                                 x.blk<float>(p.Yproj, i), x.aidx(i, AB_PROJ)))
             return 1;
-        if (x.resid_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.act_qp(x.aidx(i, AB_PROJ)), nullptr, nullptr, xmid, x.blk<float>(p.mean2, i),
+        if (x.resid_lnstats(1, xin, x.blk<float>(p.Yproj, i), x.aidx(i, AB_PROJ), nullptr, nullptr, xmid, x.blk<float>(p.mean2, i),
                             x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B), x.aidx(i, AB_N2), x.blk<void>(p.mproj, i)))
             return 1;
         }
         if (parts & 4) {   // ---- part 2: norm2 -> fc1 (both passes) -> GELU
-        launch_ln_apply_quant(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B),
-                              x.act_qp(x.aidx(i, AB_N2)), qa, qb, x.blk<void>(p.h2q, i), d.M, d.D, st, use_i8() ? x.blk<void>(p.h2q8, i) : nullptr,
-                              x.center(), (x.flags & QATVIT_FWD_X16) != 0);
+        x.ln_apply(xmid, x.blk<float>(p.mean2, i), x.blk<float>(p.rstd2, i), x.bprm(i, B_N2W), x.bprm(i, B_N2B), x.aidx(i, AB_N2), x.blk<void>(p.h2q, i),
+                   x.blk<void>(p.h2q8, i));
         {
             // fc1 is a K = D GEMM whose [M, 4D] fp32 output would be written once and read twice: run it TWICE instead.  Pass 1 only
             // feeds the observer (min/max, nothing stored); pass 2 - the same kernel on the same operands, so the same bits - quantises
             // with the fresh qparams and stores gelu(fq(.)) as the (hi, lo) pair fc2 reads plus a uint16 code (grid index | in-range
             // bit) for the backward.  The fp32 pre-FQ tensor and the separate fq+gelu pass (620 MB per block) disappear.
-            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
-            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
-                             x.aidx(i, AB_FC1), &p1))
-                return 1;
             NTPost p2{nullptr, x.act_qp(x.aidx(i, AB_FC1)), qa, qb, nullptr, x.blk<void>(p.G_hi, i), x.blk<void>(p.G_lo, i), 4,
                       x.blk<void>(p.Y1, i)};
             if (fc2_c) { p2.out8 = x.blk<void>(p.G8, i); p2.lut_out = x.blk<uint32_t>(p.glut, i); p2.out16_scale = scal16 + 1; }
             if (fc1_b) { p2.code = nullptr; p2.out8_mask = x.blk<void>(p.Y1m, i); }
             if (fc1_b && fc2w_code_form(x, i)) { p2.out_hi = p2.out_lo = nullptr; p2.lutq_out = x.blk<uint32_t>(p.glutq, i); }   // no 4-byte plane of gelu(fq(fc1)) at all
             else if (fc2_16) { p2.out16_hi = x.at<void>(p.G16_hi); p2.out16_lo = x.at<void>(p.G16_lo); p2.out16_scale = scal16 + 1; }
+            const bool lt = x.strip_consumes(M, x.widx(i, WB_FC1), &p2);   // (as for qkv: the code pass resolves the fc1 quantizer's qparams)
+            const NTPost p1{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 3, nullptr};
             if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
-                             x.aidx(i, AB_FC1), &p2, false))
+                             x.aidx(i, AB_FC1), &p1, true, lt))
+                return 1;
+            if (x.linear_fwd_grid(x.blk<void>(p.h2q, i), x.blk<void>(p.h2q8, i), M, x.widx(i, WB_FC1), x.act_qp(x.aidx(i, AB_N2)), x.bprm(i, B_FC1B), nullptr,
+                             x.aidx(i, AB_FC1), &p2, false, lt))
                 return 1;
         }
         }
@@ -524,7 +572,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
         const float* bt = last ? x.prm(P_BLOCK0 + B_COUNT * d.depth + 1) : x.bprm(i + 1, B_N1B);
         float* mean = last ? x.at<float>(p.meanF) : x.blk<float>(p.mean1, i + 1);
         float* rstd = last ? x.at<float>(p.rstdF) : x.blk<float>(p.rstd1, i + 1);
-        if (x.resid_lnstats(1, xmid, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), nullptr, nullptr, x.blk<float>(p.x_in, i + 1), mean, rstd, g, bt,
+        if (x.resid_lnstats(1, xmid, x.blk<float>(p.Y2, i), x.aidx(i, AB_FC2), nullptr, nullptr, x.blk<float>(p.x_in, i + 1), mean, rstd, g, bt,
                             last ? x.a_norm() : x.aidx(i + 1, AB_N1), x.blk<void>(p.m2, i)))
             return 1;
         }
@@ -537,7 +585,7 @@ static int fwd_block(const Ctx& x, int i, int parts, bool qkv_injected = false) 
 // and the min/max of the LayerNorm output that the consumer's first fake-quant observes.
 static int inject_ln_stats_of(const Ctx& x, const float* tensor, const float* g, const float* bt, float* mean, float* rstd, int ai) {
     launch_ws_init(x.act_stats(ai), kStatSlots * kStatStride / 2, x.st);   // whatever an earlier, unconsumed producer accumulated is stale
-    return x.resid_lnstats(2, tensor, nullptr, x.act_qp(0), nullptr, nullptr, nullptr, mean, rstd, g, bt, ai);
+    return x.resid_lnstats(2, tensor, nullptr, -1, nullptr, nullptr, nullptr, mean, rstd, g, bt, ai);
 }
 static int inject_ln_stats(const Ctx& x, int i) {
     const Dims& d = x.d;
@@ -582,6 +630,9 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
     const int qa = c.act_qmin, qb = c.act_qmax;
     if (inject && s_from >= 1 && inject_ln_stats(x, s_from - 1)) return 1;
     if (s_from == 0) {
+    // a forward from the start observes from empty accumulators: statistics a partial call (a stage range) produced for a consumer that never ran do not leak
+    // into this step (the late-resolved quantizers' accumulators are re-armed by their consumer's commit, not behind their producer)
+    if (Ctx::late_on()) launch_ws_init(x.at<uint32_t>(p.stats), (int64_t)d.n_act * kStatSlots * kStatStride / 2, st);
     // ---- weights: observe, qparams, integer operands (row-major and transposed) - all 50 tensors in three launches
     if (w_batched(d)) {
         WObsTab to{};
@@ -632,7 +683,7 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
                            use_i8() ? x.at<void>(p.imgq8) : nullptr, x.center()))
         return 1;
     if (x.linear_fwd_grid(x.at<void>(p.imgq), x.at<void>(p.imgq8), d.B * d.np, 0, x.act_qp(A_IN), x.prm(P_PE_B), x.at<float>(p.Y0), A_PE)) return 1;
-    if (x.resid_lnstats(0, nullptr, x.at<float>(p.Y0), x.act_qp(A_PE), x.prm(P_CLS), x.prm(P_POS), x.blk<float>(p.x_in, 0), x.blk<float>(p.mean1, 0),
+    if (x.resid_lnstats(0, nullptr, x.at<float>(p.Y0), A_PE, x.prm(P_CLS), x.prm(P_POS), x.blk<float>(p.x_in, 0), x.blk<float>(p.mean1, 0),
                         x.blk<float>(p.rstd1, 0), x.bprm(0, B_N1W), x.bprm(0, B_N1B), x.aidx(0, AB_N1)))
         return 1;
     }   // stage 0
@@ -905,8 +956,9 @@ int qatvit_student_init(const qatvit_cfg* cfg, void* workspace, void* stream) {
         g_profs.erase(workspace);
     }
     launch_ws_init(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + p.stats), p.stats_words / 2, (hipStream_t)stream);
-    // the one-plane backward's scale history starts empty (the first backward on a workspace calibrates)
+    // the one-plane backward's scale history starts empty (the first backward on a workspace calibrates); no late-resolved quantizer state is pending
     launch_zero_i32(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + p.dy16), dy16_state_bytes(DS_COUNT * cfg->depth) / 4, (hipStream_t)stream);
+    launch_zero_i32(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + p.qp_staged), (int64_t)dims_of(*cfg).n_act * kQpStagedWords, (hipStream_t)stream);
     QV_CHECK_LAUNCH("qatvit_student_init");
     return 0;
 }
@@ -924,6 +976,7 @@ static int run_forward(const qatvit_cfg* cfg, void* const* params, const qatvit_
     x.flags = flags & QATVIT_FWD_X16;
     QV_CHECK_ARG(!x.flags || dy16_supported(x), "%s: QATVIT_FWD_X16 needs a configuration the one-plane backward covers (qatvit_student_dy16_supported)", who);
     if (fwd(x, images, logits, stage_from, stage_to, (flags & QATVIT_STAGE_INJECT) != 0)) return 1;
+    if (x.commit_late()) return 1;
     QV_CHECK_LAUNCH(who);
     return 0;
 }
@@ -951,6 +1004,7 @@ int qatvit_student_forward_part(const qatvit_cfg* cfg, void* const* params, cons
     x.flags = flags & QATVIT_FWD_X16;
     QV_CHECK_ARG(!x.flags || dy16_supported(x), "qatvit_student_forward_part: QATVIT_FWD_X16 needs a configuration the one-plane backward covers");
     if (fwd_part(x, block, part, (flags & QATVIT_STAGE_INJECT) != 0)) return 1;
+    if (x.commit_late()) return 1;
     QV_CHECK_LAUNCH("qatvit_student_forward_part");
     return 0;
 }

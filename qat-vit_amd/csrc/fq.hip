@@ -114,6 +114,24 @@ __global__ __launch_bounds__(64) void k_w_qparams_all(const WQpTab t) {
                  t.per_channel ? t.N[wi] : 1, 1, t.qp[wi], 1, t.per_channel ? 1 : t.nslots, blk);
 }
 
+// the staged states of the late-resolved quantizers (qv_qparams.h, QpLate) into the modules' buffers, their accumulators re-armed: one thread per quantizer
+__global__ __launch_bounds__(128) void k_qp_commit(const QpCommitTab t) {
+    const int ai = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ai >= t.n) return;
+    float* sg = t.staged + (int64_t)ai * kQpStagedWords;
+    const uint32_t fl = reinterpret_cast<uint32_t*>(sg)[4];
+    if (!(fl & 4u)) return;
+    if (fl & 1u) { *t.rmin[ai] = sg[0]; *t.rmax[ai] = sg[1]; }
+    if (fl & 2u) { *t.scale[ai] = sg[2]; *t.zp[ai] = reinterpret_cast<int32_t*>(sg)[3]; }
+    uint32_t* ws = t.stats + (int64_t)ai * kStatSlots * kStatStride;
+    for (int l = 0; l < kStatSlots; ++l) { ws[l * kStatStride] = kOrdPosInf; ws[l * kStatStride + 1] = kOrdNegInf; }
+    reinterpret_cast<uint32_t*>(sg)[4] = 0u;
+}
+int launch_qp_commit(const QpCommitTab& t, hipStream_t st) {
+    k_qp_commit<<<cdiv(t.n, 128), 128, 0, st>>>(t);
+    return 0;
+}
+
 // ------------------------------------------------------------------ phase 3: quantize
 // 8 consecutive elements per lane -> one mask byte per lane, 64 contiguous bytes per wave.
 __device__ inline void fq8(const float* __restrict__ px, float* __restrict__ py, uint8_t* __restrict__ pm, float s, float inv, float fzp,

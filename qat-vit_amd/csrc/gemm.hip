@@ -1316,7 +1316,7 @@ int launch_gemm_nt_codes(const void* A8, const uint32_t* lut, const void* B16, f
 // bit for bit (both accumulate the same integers exactly).  Tall 208 x 384 tiles only: N % 384 == 0, K % 64 == 0.
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
-                      hipStream_t st, const NTPost* post, const void* B8f) {
+                      hipStream_t st, const NTPost* post, const void* B8f, const QpLate* late) {
     if (M < 1 || N % 384 != 0 || K % 64 != 0 || lda % 16 != 0 || ldb % 16 != 0 || ldc % 4 != 0 || !wsum || !a_qp) {
         set_error("gemm_nt_i8: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d (need N%%384==0, K%%64==0, ld%%16==0)", M, N, K, lda, ldb);
         return 1;
@@ -1350,7 +1350,8 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
     }
     // the K = 384 two-pass GEMMs (qkv, fc1: statistics pass, code passes) on the A-stationary strip kernel (i8strip.hip) when the weight came in
     // fragment order too; everything else (plain fp32 output, K != 384, the inference epilogues) on the general tall tile below
-    if (post && launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, K, lda, ldc, s1, s2, col_scale, bias, stats, stat_slots, st, post)) return 0;
+    if (post && launch_i8_strip(A8, B8f, wsum, a_qp, center, M, N, K, lda, ldc, s1, s2, col_scale, bias, stats, stat_slots, st, post, false, late)) return 0;
+    if (late) { set_error("gemm_nt_i8: late qparams exist in the strip kernel only (i8_strip_covers)"); return 1; }
     nt_launch<1, 3, 1, 13, 1, 8, 3, 32, true>(a, cdiv(M, 208) * (N / 384), (size_t)3 * (208 + 384) * 64, st);
     return 0;
 }

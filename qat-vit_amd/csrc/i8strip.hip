@@ -65,6 +65,7 @@ struct I8StripArgs {
     uint32_t* lutq_out;
     float* out16_scale;
     unsigned long long* dbg;   // experiments only: s_memtime stamps of workgroups 0 and 100 ([2][8 waves][32])
+    QpLate late;               // code passes: late.stats set -> the output quantizer's qparams are resolved in the prologue (qv_qparams.h) instead of read from qp
 };
 
 // LDS image of one [208][64 B] k-tile of A: two 64-B tile rows share one 128-B LDS row; chunk ((row & 1) * 4 + k-chunk) XOR (LDS row & 7)
@@ -165,16 +166,29 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
         return Consts{*reinterpret_cast<const float4*>(sCa + c), *reinterpret_cast<const float4*>(sCb + c)};
     };
 
+    // code passes: {scale, 1 / scale, zp} of the OUTPUT's quantizer - ready in p.qp, or resolved here from the statistics pass' accumulators (QpLate)
+    float* sQp = reinterpret_cast<float*>(sStage + (MODE == 3 ? 512 : NWV * WSTG));
+    if constexpr (MODE != 3) {
+        if (p.late.stats) qp_late_compute(p.late, sQp);
+        else if (tid == 0) { sQp[0] = p.qp[0]; sQp[1] = p.qp[1]; sQp[2] = p.qp[2]; }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's A pieces have landed, its constants are written ...
+    QV_STAMP();   // own DMA landed
+    __builtin_amdgcn_s_barrier();                        // ... and everybody else's: the ONLY workgroup barrier of the code passes
+    asm volatile("" ::: "memory");
+    QV_STAMP();   // strip complete
+    const float qp_s = MODE != 3 ? sQp[0] : 0.f, qp_inv = MODE != 3 ? sQp[1] : 0.f, qp_zp = MODE != 3 ? sQp[2] : 0.f;
     if constexpr (MODE == 4) {   // the two 256-entry tables of gelu(grid value) and the fp16 pair's scale: data-independent, one workgroup writes them
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 256) {
-            const float ga = fabsf(((float)p.qmin - p.qp[2]) * p.qp[0]), gb = fabsf(((float)p.qmax - p.qp[2]) * p.qp[0]);
+            const float ga = fabsf(((float)p.qmin - qp_zp) * qp_s), gb = fabsf(((float)p.qmax - qp_zp) * qp_s);
             int ex;
             (void)frexpf(fmaxf(ga, gb), &ex);
             const float gs = ldexpf(1.0f, 14 - ex);
             if (p.out16_scale && tid == 0) *p.out16_scale = ldexpf(1.0f, ex - 14);
             uint32_t wq = 0u, wh = 0u;
             if (tid <= p.qmax - p.qmin) {
-                const float gv = gelu_fwd(((float)(tid + p.qmin) - p.qp[2]) * p.qp[0]);
+                const float gv = gelu_fwd(((float)(tid + p.qmin) - qp_zp) * qp_s);
                 const __bf16 gh = (__bf16)gv;
                 const __bf16 gl = (__bf16)(gv - (float)gh);
                 wq = (uint32_t)__builtin_bit_cast(uint16_t, gh) | ((uint32_t)__builtin_bit_cast(uint16_t, gl) << 16);
@@ -187,12 +201,6 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
             if (p.lutq_out) p.lutq_out[tid] = wq;
         }
     }
-
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's A pieces have landed, its constants are written ...
-    QV_STAMP();   // own DMA landed
-    __builtin_amdgcn_s_barrier();                        // ... and everybody else's: the ONLY workgroup barrier of the code passes
-    asm volatile("" ::: "memory");
-    QV_STAMP();   // strip complete
 
     float mn = INFINITY, mx = -INFINITY;                 // MODE 3
     const bool ragged = m0 + BM > p.M;                   // (uniform) the last strip holds rows past M: they read as zero and must not be observed / stored
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
             // code = clamp(u, 0, qmax - qmin).  In range <=> 0 <= u <= range <=> the BIT PATTERN of u, as an unsigned integer, is <= that of range:
             // non-negative floats order like their bits, a negative u has the sign bit set (u is never -0: rint(.) + zoff with zoff >= +0), a NaN
             // is above every finite pattern - one integer compare, no clamp needed for the test
-            const float qinv = p.qp[1], zoff = p.qp[2] - (float)p.qmin, frange = (float)(p.qmax - p.qmin);
+            const float qinv = qp_inv, zoff = qp_zp - (float)p.qmin, frange = (float)(p.qmax - p.qmin);
             const uint32_t range_bits = __builtin_bit_cast(uint32_t, frange);
             const int tilebase = nbase + nt * BN;
             // (lane-derived values are re-derived from an opaque copy of the thread id: kept live across the k-loop they are spilled, and every
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
 
 template <int MODE, int NTL, int NWV, bool R255, int TM, int KT>
 static void strip_launch_r(const I8StripArgs& a, hipStream_t st) {
-    constexpr int kLds = KT * 16 * TM * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : NWV * (64 * (384 / NWV) + 64 * 16));
+    constexpr int kLds = KT * 16 * TM * 64 + 3 * NTL * 384 * 4 + (MODE == 3 ? 512 : NWV * (64 * (384 / NWV) + 64 * 16)) + 16;   // (+ the output quantizer's {scale, 1 / scale, zp})
     static_assert(kLds <= 160 * 1024, "strip + constants + staging patches exceed the LDS");
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_i8_strip<MODE, NTL, NWV, R255, TM, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
     (void)once;
@@ -409,13 +417,27 @@ static void strip_launch(const I8StripArgs& a0, hipStream_t st) {
 }
 
 // true when the strip kernel covers the request (the caller then launched it); false -> the general tall kernel
+static int strip_ntl(int N, int K) {   // K = 384: 3 or 4 column tiles per workgroup (qkv 1152 / fc1 1536 of ViT-S); K = 768: all 6 or 8 of them (qkv 2304 / fc1 3072 of ViT-B)
+    return K == 384 ? (N % (4 * 384) == 0 ? 4 : N % (3 * 384) == 0 ? 3 : 0) : (N == 6 * 384 ? 6 : N == 8 * 384 ? 8 : 0);
+}
+static bool strip_on() {
+    static const int on = getenv("QATVIT_I8_STRIP") ? atoi(getenv("QATVIT_I8_STRIP")) : 1;   // 0: the general tall kernel (A/B arm of the bit-identity test)
+    return on != 0;
+}
+bool i8_strip_covers(const void* B8f, int M, int N, int K, int lda, int ldc, const NTPost* post) {
+    if (!strip_on() || !B8f || !post || (K != 384 && K != 768) || lda % 16 != 0 || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24) || !strip_ntl(N, K)) return false;
+    if (post->mode == 3) return true;
+    if (!post->out8 || !post->out8_mask || post->qmax - post->qmin >= 256) return false;
+    if (post->mode == 7) return post->code_hd == 64 && (N / 3) % 384 == 0 && post->code_T >= 1 && post->code_T < 1024;
+    if (post->mode == 4) return !(post->out_hi || post->out_lo || post->code || post->out16_hi || post->out16_lo || !post->lut_out || !post->lutq_out || ldc % 128 != 0);
+    return false;
+}
+
 bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                     const NTPost* post, bool force) {
-    static const int on = getenv("QATVIT_I8_STRIP") ? atoi(getenv("QATVIT_I8_STRIP")) : 1;   // 0: the general tall kernel (A/B arm of the bit-identity test)
-    if ((!on && !force) || !B8f || !post || (K != 384 && K != 768) || lda % 16 != 0 || !s1 || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24)) return false;
-    // K = 384: 3 or 4 column tiles per workgroup (qkv 1152 / fc1 1536 of ViT-S); K = 768: all 6 or 8 of them (qkv 2304 / fc1 3072 of ViT-B)
-    const int ntl = K == 384 ? (N % (4 * 384) == 0 ? 4 : N % (3 * 384) == 0 ? 3 : 0) : (N == 6 * 384 ? 6 : N == 8 * 384 ? 8 : 0);
+                     const NTPost* post, bool force, const QpLate* late) {
+    if ((!strip_on() && !force) || !B8f || !post || (K != 384 && K != 768) || lda % 16 != 0 || !s1 || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24)) return false;
+    const int ntl = strip_ntl(N, K);
     if (!ntl) return false;
     const bool wide = K == 768;
     I8StripArgs a{};
@@ -429,8 +451,9 @@ bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const
         return true;
     }
     a.qp = post->qp; a.qmin = post->qmin; a.qmax = post->qmax;
+    if (late) a.late = *late;
     a.out8 = reinterpret_cast<uint8_t*>(post->out8); a.out8_mask = reinterpret_cast<uint8_t*>(post->out8_mask);
-    if (!a.qp || !a.out8 || !a.out8_mask || a.qmax - a.qmin >= 256) return false;
+    if ((!a.qp && !a.late.stats) || !a.out8 || !a.out8_mask || a.qmax - a.qmin >= 256) return false;
     if (post->mode == 7) {
         const int D = N / 3;
         if (post->code_hd != 64 || D % 384 != 0 || post->code_T < 1 || post->code_T >= 1024) return false;

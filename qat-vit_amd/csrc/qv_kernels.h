@@ -25,6 +25,22 @@ int launch_qparams(uint32_t* ws, float* running_min, float* running_max, float* 
                    const int64_t* fake_quant_on, float c, int qmin, int qmax, int64_t channels, int symmetric, float* qp_out, int reset_ws,
                    int nslots, hipStream_t st);
 
+// the late-resolved quantizers' staged states -> module buffers (qv_qparams.h QpLate; fq.hip k_qp_commit): per activation quantizer the four buffers; the
+// staging records and the accumulators are workspace arrays indexed by the quantizer
+constexpr int kMaxActFq = 96;   // 2 + 6 per block (depth <= 12) + 2, with slack
+struct QpCommitTab { float* rmin[kMaxActFq]; float* rmax[kMaxActFq]; float* scale[kMaxActFq]; int32_t* zp[kMaxActFq]; float* staged; uint32_t* stats; int n; };
+int launch_qp_commit(const QpCommitTab& t, hipStream_t st);
+// how a consumer kernel obtains the qparams of the quantizer it applies (device side: qv_qparams.h qp_late_resolve)
+struct QpLate {
+    const uint32_t* stats;     // kStatSlots accumulator pairs; nullptr: not late - the consumer reads the ready values (k_qparams ran)
+    const float* rmin; const float* rmax; const float* scale; const int32_t* zp;   // the module's buffers: READ ONLY in the consumer
+    const int64_t* obs_on; const int64_t* fq_on;
+    float c; int qmin, qmax;
+    float* qp_out;             // {scale, 1 / scale, zp, on}: what k_qparams publishes
+    float* staged;             // kQpStagedWords words: new min, new max, new scale, new zp (int bits), flags (1: min / max moved, 2: scale / zp moved, 4: pending)
+};
+constexpr int kQpStagedWords = 8;
+
 // fused consumers of an NT GEMM's accumulators (epilogue modes)
 struct NTPost {
     // mode 1 (Y != nullptr): store (hi, lo) of C * gelu'(fq(Y)) * mask(Y) * colscale   (fc2 dgrad -> GELU backward)
@@ -94,7 +110,8 @@ int launch_gemm_nt(const void* A_hi, const void* A_lo, const void* B, float* C, 
 int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const float* a_qp, int center, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots,
                       hipStream_t st, const NTPost* post = nullptr,
-                      const void* B8f = nullptr);   // B8f: the same weight integers in fragment order (launch_w8_fragment_order): enables the strip kernel
+                      const void* B8f = nullptr,   // B8f: the same weight integers in fragment order (launch_w8_fragment_order): enables the strip kernel
+                      const QpLate* late = nullptr);
 // The one-plane backward ("dY as one fp16 plane"): the dgrad C[M,N] = A16[M,K] . B16[N,K]^T * (*s1) * (*s2) with the gradient
 // operand A16 as ONE fp16 plane pre-scaled by a power of two (its inverse arrives in *s2) and the transposed weight integers B16 as fp16 (exact):
 // one v_mfma_f32_16x16x32_f16 pass, 2 B per gradient element.  post: nullptr (plain fp32 output: proj dgrad), mode 8 (fused LayerNorm backward)
@@ -105,7 +122,9 @@ int launch_gemm_nt_dy16(const void* A16, const void* B16, float* C, int M, int N
 // ---- i8strip.hip: the K = 384 two-pass forward GEMMs (qkv, fc1), A-stationary; returns true when it covered (and launched) the request
 bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
-                     const NTPost* post, bool force = false);
+                     const NTPost* post, bool force = false, const QpLate* late = nullptr);   // late (code passes): the output quantizer's qparams are resolved inside
+// would launch_i8_strip take this request?  (the engine decides on it BEFORE the statistics pass whether a k_qparams launch has to follow it)
+bool i8_strip_covers(const void* B8f, int M, int N, int K, int lda, int ldc, const NTPost* post);
 // byte offset of element (n, k) of an [N, K] int8 weight in fragment order: [48-column group][64-deep k-step][16-column fragment][lane = 16 (k % 64 / 16) + n % 16][k % 16]
 __host__ __device__ inline int64_t w8f_offset(int n, int k, int K) {
     const int cg = n / 48, cr = n % 48, j = cr / 16, r = cr % 16, kt = k / 64, kk = k % 64;
@@ -137,14 +156,15 @@ int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qm
                        void* out8 = nullptr, int center = 0);
 int launch_resid_fq_lnstats(int mode, const float* x_prev, const float* Y, const float* qpY, int qmin, int qmax, const float* cls, const float* pos,
                             float* x_new, float* mean, float* rstd, const float* gamma, const float* beta, float eps, uint32_t* stats, int stat_slots,
-                            int64_t M, int D, int T, hipStream_t st, void* maskbits = nullptr);
+                            int64_t M, int D, int T, hipStream_t st, void* maskbits = nullptr, const QpLate* late = nullptr);   // late: Y's qparams are resolved inside (QpLate)
 // STE mask of an [M, D] tensor as wave ballots: ceil(D / 256) * 4 64-bit words per row (written by launch_resid_fq_lnstats mode 1)
 inline int64_t ln_maskbits_bytes(int64_t M, int D) { return M * ((D + 255) / 256) * 32; }
 // optional second output of launch_ln_bwd_fq: split(dx_out * mask * colscale) for the next branch's GEMMs
 struct LnBwdNext { const void* maskbits; const float* colscale; void* out_hi; void* out_lo; const float* o16_mul = nullptr; uint32_t* o16_amax = nullptr; };   // o16_*: out_hi is ONE fp16 plane (dy16.hip)
 int launch_ln_apply_quant(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* qp, int qmin,
                           int qmax, void* out_bf16, int64_t M, int D, hipStream_t st, void* out8 = nullptr, int center = 0,
-                          bool out_f16 = false);   // out_f16: the integers as fp16 bit patterns (X operand of the one-plane weight gradient)
+                          bool out_f16 = false,   // out_f16: the integers as fp16 bit patterns (X operand of the one-plane weight gradient)
+                          const QpLate* late = nullptr);
 // inference: LayerNorm + quantise (frozen qparams) in one pass -> int8 (q - center); out8 == nullptr: row statistics only; row_stride > 1: every
 // row_stride-th row (cls tokens)
 int launch_ln_quant8(const float* x, const float* gamma, const float* beta, float eps, const float* qp, int qmin, int qmax, int center, void* out8,

@@ -120,4 +120,47 @@ __device__ inline void qparams_body(uint32_t* ws, float* running_min, float* run
     }
 }
 
+// ------------------------------------------------------------------ the same update inside the CONSUMER of the qparams
+// A quantizer whose consumer kernel is known (LayerNorm outputs -> k_ln_apply_quant, proj / fc2 outputs -> k_resid_fq_lnstats, qkv / fc1 outputs -> the strip
+// kernel's code pass) needs no k_qparams launch between the producer of its statistics and that consumer: every workgroup of the consumer folds the
+// accumulator pairs and runs the arithmetic above for itself (one wave, a few hundred instructions behind loads that hit L2), nobody writes the module's
+// buffers while they are being read.  Workgroup 0 leaves the new state in a staging record and publishes {scale, 1 / scale, zp, on} for the kernels that
+// follow; ONE k_qp_commit launch at the end of the forward call moves the staged states into the module's buffers and re-arms the accumulators.
+// (struct QpLate: qv_kernels.h)
+// The first wave of the workgroup computes {scale, 1 / scale, zp, on} into sh[0..3] (LDS); the caller publishes it with a workgroup barrier.
+__device__ inline void qp_late_compute(const QpLate& L, float* sh) {
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        uint32_t omn = l < kStatSlots ? L.stats[l * kStatStride] : kOrdPosInf;
+        uint32_t omx = l < kStatSlots ? L.stats[l * kStatStride + 1] : kOrdNegInf;
+        float mn = *L.rmin, mx = *L.rmax, s = *L.scale;
+        int32_t z = *L.zp;
+        const bool obs_on = *L.obs_on != 0, fq_on = *L.fq_on != 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            omn = min(omn, (uint32_t)__shfl_xor((int)omn, o, 64));
+            omx = max(omx, (uint32_t)__shfl_xor((int)omx, o, 64));
+        }
+        if (l == 0) {
+            if (obs_on) { mn = ema(mn, ord2f(omn), L.c); mx = ema(mx, ord2f(omx), L.c); }
+            const bool moved = fq_on && mn <= mx;
+            if (moved) choose_qparams(mn, mx, L.qmin, L.qmax, false, &s, &z);
+            const float inv = __fdiv_rn(1.0f, s);
+            sh[0] = s; sh[1] = inv; sh[2] = (float)z; sh[3] = fq_on ? 1.f : 0.f;
+            if (blockIdx.x == 0 && blockIdx.y == 0) {
+                L.qp_out[0] = s; L.qp_out[1] = inv; L.qp_out[2] = (float)z; L.qp_out[3] = fq_on ? 1.f : 0.f;
+                L.staged[0] = mn; L.staged[1] = mx; L.staged[2] = s;
+                reinterpret_cast<int32_t*>(L.staged)[3] = z;
+                reinterpret_cast<uint32_t*>(L.staged)[4] = 4u | (obs_on ? 1u : 0u) | (moved ? 2u : 0u);
+            }
+        }
+    }
+}
+// Call with ALL threads of the workgroup (blockDim.x >= 64; contains one __syncthreads()); sh: 4 floats of LDS; returns {scale, 1 / scale, zp, on}.
+__device__ inline float4 qp_late_resolve(const QpLate& L, float* sh) {
+    qp_late_compute(L, sh);
+    __syncthreads();
+    return make_float4(sh[0], sh[1], sh[2], sh[3]);
+}
+
 }  // namespace qv

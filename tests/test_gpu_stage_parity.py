@@ -20,9 +20,9 @@ four parts per block (x_in -> norm1 -> qkv | qkv -> attention -> proj -> residua
       gradient and every parameter gradient of the stage (backward: one stage per block on the teacher-forced forward state).
 
 A second table repeats the forward with ONE injection per block next to the same experiment on the stock torch tree - on this GPU and on the
-host CPU with the reduction order of every Linear layer permuted (three permutations): independent fp32 evaluations, the live floor DISTRIBUTION of that coarser granularity; asserted per row against ITS OWN
-block's samples (2x the largest sample + 1e-4 + the part that the measured differences of the block's quantizer SCALES from the oracle's explain; block
-outputs 4x; median ratio <= 1.25; the stock samples' own leave-one-out ratios - the null distribution - and every scale difference are written next to it).
+host CPU with the reduction order of every Linear layer permuted (three permutations): independent fp32 evaluations, the live floor DISTRIBUTION of that coarser granularity; twice: free-running (every
+quantizer observes for itself; reported with every scale difference and the stock samples' own leave-one-out ratios, asserted in the median) and with the
+block's quantizers on the oracle's scales on both sides (asserted per row: within twice the largest sample of ITS OWN block + 1e-4).
 
 Reference call sites: forward ``ddp_model(images)`` qat_trainer.py:341, loss :343-349, ``loss.backward()`` :359.
 Tables are written to gpurun_out/ (committed copies: profiles/round3_stage_flip_table_*.txt)."""
@@ -279,37 +279,68 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
     # ---- (informational) ONE injection per block, next to the same experiment on the stock torch tree on this GPU: the live floor of
     # that granularity (in-block amplification: a flipped key perturbs a whole head; a flipped norm2 element ~5 % of its row's fc1 codes)
     coarse = Table()
-    coarse_rows = []
+    forced = Table()
+    coarse_rows, forced_rows = [], []
     n_cmp = n_within = 0
     perm_seeds = (101, 102, 103)
     CHAIN = ["norm1", "attn.qkv", "attn.proj", "norm2", "mlp.fc1", "mlp.fc2"]
 
-    def floor_sample(i, device, perm_seed=None):
+    def force_oracle_qparams(mods, pre, on):
+        """The six activation quantizers of a block (mods: name -> module) set to the ORACLE's state after its step, observers off (on=True) / observers back on."""
+        for nm in CHAIN:
+            m, o = mods[nm], tr.fq[f"{pre}.{nm}.{A}"]
+            if on:
+                with torch.no_grad():
+                    m.activation_post_process.min_val.copy_(o.activation_post_process.min_val)
+                    m.activation_post_process.max_val.copy_(o.activation_post_process.max_val)
+                    m.scale.copy_(o.scale)
+                    m.zero_point.copy_(o.zero_point)
+            m.observer_enabled[0] = 0 if on else 1
+
+    def floor_sample(i, device, perm_seed=None, forced=False):
         """One independent fp32 evaluation of block i on the oracle's block input by the STOCK torch tree (fresh observers): per tensor the fraction of
         codes (relative L2 for the block output) that differ from the oracle - the deviation between two correct evaluations at this granularity.
-        perm_seed (CPU): the reduction dimension of the block's four Linear layers is permuted (weight columns and input features alike) - the same
-        mathematical function, every dot product summed in another order.  (The host CPU at 1 .. 16 threads is NOT an independent evaluation: oneDNN
+        perm_seed (CPU): the block is evaluated in a permuted feature basis - the same mathematical function, every LayerNorm statistic and every dot
+        product summed in another order.  (The host CPU at 1 .. 16 threads is NOT an independent evaluation: oneDNN
         splits the rows, every thread count gave the oracle's bits - measured, round 4.)"""
         pre = f"model.blocks.{i}"
         blk = copy.deepcopy(po0.model.blocks[i]).to(device)
+        xin, inv = tr.block_in[i], None
         if perm_seed is not None:
+            # the same function in a permuted feature basis: the residual stream's D features by pi (LayerNorm affine parameters, the K columns of qkv / fc1,
+            # the output rows of proj / fc2 follow), the K dimensions of proj / fc2 by permutations of their own - every sum of the block (LayerNorm mean /
+            # variance, every dot product) runs in another order; outputs are brought back by the inverse permutation
             gp = torch.Generator().manual_seed(perm_seed + i)
-            for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
-                perm = torch.randperm(lin.weight.shape[1], generator=gp)
-                with torch.no_grad():
-                    lin.weight.copy_(lin.weight[:, perm].clone())
-                lin.register_forward_pre_hook(lambda mod, inp, perm=perm: (inp[0][..., perm],))
+            pi = torch.randperm(blk.norm1.weight.numel(), generator=gp)
+            sig = torch.randperm(blk.attn.proj.weight.shape[1], generator=gp)
+            tau = torch.randperm(blk.mlp.fc2.weight.shape[1], generator=gp)
+            inv = torch.argsort(pi)
+            with torch.no_grad():
+                for ln in (blk.norm1, blk.norm2):
+                    ln.weight.copy_(ln.weight[pi].clone()); ln.bias.copy_(ln.bias[pi].clone())
+                blk.attn.qkv.weight.copy_(blk.attn.qkv.weight[:, pi].clone())
+                blk.mlp.fc1.weight.copy_(blk.mlp.fc1.weight[:, pi].clone())
+                blk.attn.proj.weight.copy_(blk.attn.proj.weight[pi][:, sig].clone()); blk.attn.proj.bias.copy_(blk.attn.proj.bias[pi].clone())
+                blk.mlp.fc2.weight.copy_(blk.mlp.fc2.weight[pi][:, tau].clone()); blk.mlp.fc2.bias.copy_(blk.mlp.fc2.bias[pi].clone())
+            blk.attn.proj.register_forward_pre_hook(lambda mod, inp, sig=sig: (inp[0][..., sig],))
+            blk.mlp.fc2.register_forward_pre_hook(lambda mod, inp, tau=tau: (inp[0][..., tau],))
+            xin = xin[..., pi]
+        if forced:
+            force_oracle_qparams({nm: dict(blk.named_modules())[f"{nm}.{A}"] for nm in CHAIN}, pre, True)
         caps = capture_fq_io(blk)
         with torch.no_grad():
-            bo = blk(tr.block_in[i].to(device))
+            bo = blk(xin.to(device))
         fl = {}
         for nm in ("norm1", "attn.qkv", "attn.proj", "norm2", "mlp.fc1", "mlp.fc2"):
             fm = dict(blk.named_modules())[f"{nm}.{A}"]
-            cg = torch.round(caps[f"{nm}.{A}"][1] / fm.scale).cpu().reshape(-1)
-            fl[nm] = (cg != tr.codes(f"{pre}.{nm}.{A}").reshape(-1)).float().mean().item()
+            cg = torch.round(caps[f"{nm}.{A}"][1] / fm.scale).cpu()
+            if inv is not None and nm in ("norm1", "attn.proj", "norm2", "mlp.fc2"):
+                cg = cg[..., inv]
+            fl[nm] = (cg.reshape(-1) != tr.codes(f"{pre}.{nm}.{A}").reshape(-1)).float().mean().item()
             so = tr.fq[f"{pre}.{nm}.{A}"].scale
             fl["ds " + nm] = ((fm.scale.cpu() - so).abs() / so).item()      # relative difference of this quantizer's scale from the oracle's
-        fl[f"x_in[{i + 1}] (block output)"] = rel_l2(bo.cpu().numpy(), tr.block_in[i + 1].numpy())
+        bo = bo.cpu() if inv is None else bo.cpu()[..., inv]
+        fl[f"x_in[{i + 1}] (block output)"] = rel_l2(bo.numpy(), tr.block_in[i + 1].numpy())
         return fl
 
     for i in blocks:
@@ -342,24 +373,43 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
                     dsum = sum(((fqm[f"{pre}.{q}.{A}"].scale.cpu() - tr.fq[f"{pre}.{q}.{A}"].scale).abs() / tr.fq[f"{pre}.{q}.{A}"].scale).item() for q in chain)
                     allow = 2.0 * tr.codes(f"{pre}.{r[1]}.{A}").abs().mean().item() * dsum
                 coarse_rows.append((st, r[1], r[4], vals, ds_ours, ds_vals, allow))
-    # Every row against ITS OWN block's floor distribution.  ratio = native deviation / largest of the block's independent stock evaluations.  The same
-    # ratio for every stock sample against the OTHER evaluations of its block (leave one out, the native one included) is the null distribution: what
-    # "one of five interchangeable fp32 evaluations" looks like.  It is heavy-tailed through ONE mechanism, visible in the scale columns of the samples
-    # table: a flipped code in the row that holds a tensor's extreme element moves that quantizer's SCALE by 1e-5 .. 2e-3, which re-rounds mean|q| times
-    # that fraction of ALL its codes and of everything downstream (it happens to the oracle itself: C3 block 5, where the three permuted CPU evaluations
-    # and the native one agree with each other on fc1's scale and differ from the oracle by the same 2.3e-4).  Every quantizer's scale is asserted to
-    # 2e-5 of the oracle's in the teacher-forced run above, where its input is the oracle's; here the part of a row that the measured scale differences
-    # explain is allowed for explicitly:
-    #   (a) quantizer rows: deviation <= 2x the largest stock sample + 1e-4 + 2 mean|q - zp| (sum of the block's scale differences up to this quantizer);
-    #   (b) block outputs: <= 4x the largest stock sample + 1e-4;   (c) the median ratio over all rows <= 1.25 (a systematic excess everywhere).
-    # Rows beyond the plain 2x bound are counted and reported.
-    coarse_bad = [(st, name, v, max(vals), al) for st, name, v, vals, _, _, al in coarse_rows
-                  if v > (4 if name.startswith("x_in[") else 2) * max(vals) + 1e-4 + al]
+        # ---- the ASSERTED coarse run: the same block, one injection, with every quantizer of the block on the ORACLE's scale / zero point (observers off) -
+        # in the native tree and in the stock samples alike.  What remains is what chaining the block's stages does to VALUES (codes that sit on a rounding
+        # tie, amplified through attention and the MLP); the scale mechanism above is taken out on both sides.
+        mods = {nm: fqm[f"{pre}.{nm}.{A}"] for nm in CHAIN}
+        force_oracle_qparams(mods, pre, True)
+        eng.tensor("x_in", i, (M, D)).copy_(tr.block_in[i].reshape(M, D).cuda())
+        eng.forward_stages(None, i + 1, i + 1, inject=True)
+        n1 = len(forced.rows)
+        for part in range(3):
+            cmp_part(forced, st, i, part, lim=1.0, tol=1.0, split_fc2=False)
+        force_oracle_qparams(mods, pre, False)
+        fsamples = [floor_sample(i, "cuda", forced=True)] + [floor_sample(i, "cpu", n, forced=True) for n in perm_seeds]
+        for k in range(n1, len(forced.rows)):
+            r = forced.rows[k]
+            if r[1] in fsamples[0]:
+                vals = [fl[r[1]] for fl in fsamples]
+                forced.rows[k] = r + (max(vals),)
+                forced_rows.append((st, r[1], r[4], vals))
+    # The free-running table (every quantizer observes for itself) is heavy-tailed through ONE mechanism, visible in its scale columns: a flipped code in
+    # the row that holds a tensor's extreme element moves that quantizer's SCALE by 1e-5 .. 2e-3, which re-rounds mean|q| times that fraction of ALL its
+    # codes and of everything downstream (it happens to the oracle itself: C3 block 5, where the three permuted CPU evaluations and the native one agree
+    # on fc1's scale and differ from the oracle's by the same 2.3e-4).  Every quantizer's scale is asserted to 2e-5 of the oracle's in the teacher-forced
+    # run, where its input is the oracle's.  That table is reported with the null distribution (each stock sample against the other evaluations of its
+    # block) and asserted only in the median (a systematic excess everywhere); the per-row assertion is on the forced-scale run: every native row within
+    # twice the largest of ITS OWN block's four independent stock evaluations (+ 1e-4).
     plain2 = [(st, name) for st, name, v, vals, _, _, _ in coarse_rows if v > 2 * max(vals) + 1e-4]
     sig = [(v, vals) for _, _, v, vals, _, _, _ in coarse_rows if max(vals + [v]) > 1e-4]          # rows with a measurable deviation
     ratios = sorted(v / (max(vals) + 1e-12) for v, vals in sig)
     null = sorted(vals[k] / (max(vals[:k] + vals[k + 1:] + [v]) + 1e-12) for v, vals in sig for k in range(len(vals)))
     med = ratios[len(ratios) // 2] if ratios else 0.0
+    forced_bad = [(st, name, v, max(vals)) for st, name, v, vals in forced_rows if v > 2 * max(vals) + 1e-4]
+    fr = sorted(v / (max(vals) + 1e-12) for _, _, v, vals in forced_rows if max(vals + [v]) > 1e-4)
+    forced.write(os.path.join(ROOT, "gpurun_out", f"round4_block_level_forced_scales_{golden_tag}.txt"),
+                 f"# ONE injection per block with every quantizer of the block on the oracle's scale / zero point (observers off), native and stock alike: native block on "
+                 f"the oracle's block input vs the oracle; last column = the largest deviation of {1 + len(perm_seeds)} independent stock-torch evaluations (this GPU; host CPU "
+                 f"with {len(perm_seeds)} permutations of every Linear layer's reduction order); {arch} batch {B}, {backend}; {len(forced_rows) - len(forced_bad)} of "
+                 f"{len(forced_rows)} rows within 2x that + 1e-4; ratio native / largest stock sample: median {(fr[len(fr) // 2] if fr else 0):.2f}, max {(fr[-1] if fr else 0):.2f}")
     coarse.write(os.path.join(ROOT, "gpurun_out", f"round4_block_level_vs_floor_{golden_tag}.txt"),
                  f"# ONE injection per block (coarse): native block on the oracle's block input vs the oracle; last column = the largest deviation of {1 + len(perm_seeds)} "
                  f"independent stock-torch evaluations of the same block on the same input (this GPU; host CPU with {len(perm_seeds)} permutations of every Linear layer's reduction order) from the oracle; "
@@ -497,8 +547,7 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
                     f"(torch {torch.__version__} CPU eager QAT); produced by tests/test_gpu_stage_parity.py")
     tab.check()
     tab16.check()
-    assert not coarse_bad, ("one injection per block: rows beyond 2x (block output: 4x) the largest of that block's stock deviations + what its scale differences explain",
-                            coarse_bad[:8], n_within, n_cmp)
+    assert not forced_bad, ("one injection per block, oracle's scales: rows beyond 2x the largest of that block's independent stock deviations", forced_bad[:8])
     assert med <= 1.25, ("one injection per block: the native deviation is systematically above the stock evaluations'", med)
     return tab
 
