@@ -25,7 +25,7 @@ quantizer observes for itself; reported with every scale difference and the stoc
 block's quantizers on the oracle's scales on both sides (asserted per row: within twice the largest sample of ITS OWN block + 1e-4).
 
 Reference call sites: forward ``ddp_model(images)`` qat_trainer.py:341, loss :343-349, ``loss.backward()`` :359.
-Tables are written to gpurun_out/ (committed copies: profiles/round3_stage_flip_table_*.txt)."""
+Tables are written to gpurun_out/ (committed copies: profiles/round4_stage_flip_table_*.txt)."""
 import copy
 import os
 
@@ -542,7 +542,7 @@ def _run(backend, seed, teacher, golden_tag, arch="vit_small_patch16_224", B=8, 
             for st, n, k, ne, val, _ in tab16.rows:
                 f.write(f"{st:<14}{n:<34}{k:<8}{ne:>12}{val:>14.3e}\n")
             f.write(f"\nworst rel L2 {max(r[4] for r in tab16.rows):.2e} (pair form, same stages: {max(r[4] for r in tab.rows if r[0].startswith('bwd block')):.2e})\n")
-    path = os.path.join(ROOT, "gpurun_out", f"round3_stage_flip_table_{golden_tag}.txt")
+    path = os.path.join(ROOT, "gpurun_out", f"round4_stage_flip_table_{golden_tag}.txt")
     tab.write(path, f"# teacher-forced stage parity, {arch} batch {B}, {backend} qconfig, {'KD' if teacher else 'CE only'}; native stage on the oracle's input vs the oracle "
                     f"(torch {torch.__version__} CPU eager QAT); produced by tests/test_gpu_stage_parity.py")
     tab.check()
