@@ -359,7 +359,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_i8_strip(const I8StripArg
                     } else {
                         // attention layout [b][h][q|k|v][t][d], head_dim 64: a 16-B piece lies inside one head's row
                         const int cm = cm0 + 16 * c, hh = cm >> 6, d = cm & 63;
-                        const int bb_ = (int)(((float)row + 0.5f) * invT), tt = row - (int)__umul24((uint32_t)bb_, (uint32_t)p.code_T);   // (exact for row < 2^22: checked by the launcher)
+                        const int bb_ = (int)(((float)row + 0.5f) * invT), tt = row - (int)__umul24((uint32_t)bb_, (uint32_t)p.code_T);   // (exact for row < 2^20, T < 2^10: checked by the launcher)
                         // (every factor below 2^24 and the element offset below 2^32 - checked by the launcher: 24-bit multiplies, 32-bit offset)
                         const uint32_t eo = ((__umul24(__umul24((uint32_t)(bb_ * Hh + hh), 3u) + (uint32_t)which, (uint32_t)p.code_T) + (uint32_t)tt) << 6) + (uint32_t)d;
                         if (ok) {
@@ -424,8 +424,16 @@ static bool strip_on() {
     static const int on = getenv("QATVIT_I8_STRIP") ? atoi(getenv("QATVIT_I8_STRIP")) : 1;   // 0: the general tall kernel (A/B arm of the bit-identity test)
     return on != 0;
 }
+// the kernel's 32-bit / 24-bit address arithmetic: the A-strip DMA offset (m0 + row) * lda + .. is a uint32; mode 4 forms __umul24(row, ldc) + column as a
+// uint32; mode 7 floors (row + 0.5) * (1 / T) in fp32 (exact with margin for row < 2^20, T < 2^10)
+static bool strip_addressable(int M, int N, int lda, int ldc, int mode) {
+    if ((int64_t)M * lda >= (1ll << 32) || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24)) return false;
+    if (mode == 4 && (ldc >= (1 << 24) || (int64_t)M * ldc >= (1ll << 32))) return false;
+    if (mode == 7 && M >= (1 << 20)) return false;
+    return true;
+}
 bool i8_strip_covers(const void* B8f, int M, int N, int K, int lda, int ldc, const NTPost* post) {
-    if (!strip_on() || !B8f || !post || (K != 384 && K != 768) || lda % 16 != 0 || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24) || !strip_ntl(N, K)) return false;
+    if (!strip_on() || !B8f || !post || (K != 384 && K != 768) || lda % 16 != 0 || !strip_addressable(M, N, lda, ldc, post->mode) || !strip_ntl(N, K)) return false;
     if (post->mode == 3) return true;
     if (!post->out8 || !post->out8_mask || post->qmax - post->qmin >= 256) return false;
     if (post->mode == 7) return post->code_hd == 64 && (N / 3) % 384 == 0 && post->code_T >= 1 && post->code_T < 1024;
@@ -436,7 +444,7 @@ bool i8_strip_covers(const void* B8f, int M, int N, int K, int lda, int ldc, con
 bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
                      const NTPost* post, bool force, const QpLate* late) {
-    if ((!strip_on() && !force) || !B8f || !post || (K != 384 && K != 768) || lda % 16 != 0 || !s1 || M >= (1 << 22) || (int64_t)M * N >= (1ll << 32) || N >= (1 << 24)) return false;
+    if ((!strip_on() && !force) || !B8f || !post || (K != 384 && K != 768) || lda % 16 != 0 || !s1 || !strip_addressable(M, N, lda, ldc, post->mode)) return false;
     const int ntl = strip_ntl(N, K);
     if (!ntl) return false;
     const bool wide = K == 768;

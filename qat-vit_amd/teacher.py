@@ -54,6 +54,11 @@ class TeacherEngine:
             raise RuntimeError(f"QATVIT_TEACHER_PASSES={self.passes}: 1, 2 or 3")
         if self.passes < 3 and (model.embed_dim % 384 or blocks[0].mlp.fc1.weight.shape[0] % 384):
             self.passes = 3   # the fp16 forms run on the tall 208 x 384 tile only
+        if self.passes < 3 and not self._fp16_range_ok(model, blocks):
+            import warnings
+            warnings.warn("qat-vit_amd: a teacher activation could leave fp16's range with these weights (bound from the LayerNorm / Linear parameters); "
+                          "the frozen teacher runs in the three-pass bf16-pair form instead of the fp16 form", RuntimeWarning)
+            self.passes = 3
         self._split_weights()
         nbytes = self.lib.qatvit_teacher_workspace_bytes(ctypes.byref(self.cfg))
         if nbytes <= 0:
@@ -61,6 +66,29 @@ class TeacherEngine:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._ptr_params = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
         self._key = tuple(p.data_ptr() for p in ps)
+
+    @staticmethod
+    @torch.no_grad()
+    def _fp16_range_ok(model, blocks, limit: float = 0.25 * 65504.0) -> bool:
+        """The fp16 forms cast every GEMM INPUT to fp16 (LayerNorm outputs, attention outputs, GELU outputs, patches) without a run-time check.  A bound that
+        needs no data: |LayerNorm(x)| <= |gamma| sqrt(D) + |beta|; a Linear output is at most the largest row 1-norm of its weight times the bound of its
+        input plus |bias|; softmax-weighted sums and GELU do not grow their input.  Everything a GEMM reads must stay below a quarter of fp16's largest number;
+        otherwise (outlier channels, huge LayerNorm gains of some pretrained checkpoints) the engine keeps the bf16-pair form, which has fp32's range."""
+        d = float(model.embed_dim) ** 0.5
+
+        def ln_bound(ln):
+            return float(ln.weight.abs().max()) * d + float(ln.bias.abs().max())
+
+        def lin_bound(lin, xin):
+            return float(lin.weight.abs().sum(1).max()) * xin + (float(lin.bias.abs().max()) if lin.bias is not None else 0.0)
+
+        worst = 0.0
+        for b in blocks:
+            h1, h2 = ln_bound(b.norm1), ln_bound(b.norm2)
+            v = lin_bound(b.attn.qkv, h1)            # attention output: a convex combination of value rows
+            g = lin_bound(b.mlp.fc1, h2)             # |gelu(x)| <= |x|
+            worst = max(worst, h1, h2, v, g)
+        return worst < limit
 
     @torch.no_grad()
     def _split_weights(self):

@@ -339,7 +339,12 @@ def test_engine_data_parallel_path_single_rank(native_lib):
 #   2: fp16 pair x weights rounded to fp16 (the default): observed 4.2e-4 .. 6.3e-4 over six seeds, worst single image 8.2e-4
 #   1: fp16 x fp16: observed 6.1e-4 .. 8.4e-4 over six seeds - inside 1e-3 as a batch, single images up to 1.3e-3 (opt-in for that reason)
 # (profiles/round3_teacher_precision.txt)
-TEACHER_TOL = {3: (2e-4, 5e-4), 2: (1e-3, 1e-3), 1: (1e-3, 2e-3)}
+# The teacher enters the student's step only through the KD term of the loss (qat_trainer.py:343-349): what has to stay inside the 1e-3 bar per image is
+# the KD gradient w.r.t. the student's logits, alpha T (softmax(s / T) - softmax(t / T)) / B - measured 1.8e-4 .. 2.7e-4 (form 2), 3.0e-4 .. 3.4e-4 (form 1) as a
+# batch; asserted per image in test_native_teacher_forward_at_b256_vs_fp64.  The per-image LOGIT bound is looser than the observed worst case on purpose
+# (8.2e-4 for form 2: a bar AT the observation would flake).
+TEACHER_TOL = {3: (2e-4, 5e-4), 2: (1e-3, 1.5e-3), 1: (1e-3, 2e-3)}
+TEACHER_KD_TOL = {3: 5e-5, 2: 1e-3, 1: 1e-3}
 
 
 @pytest.mark.parametrize("passes", [3, 2, 1])
@@ -412,5 +417,15 @@ def test_native_teacher_forward_at_b256_vs_fp64(native_lib, monkeypatch, passes)
     with torch.no_grad():
         ref = m64.head(m64.forward_features(x[idx].double())[:, 0])
     assert rel_l2(out[idx].cpu(), ref.cpu()) < tol
-    for k, i in enumerate(idx):   # per image too: one wrong row tile must not hide in the average
+    # per image too (one wrong row tile must not hide in the average): logits, and the KD gradient a random student would receive from this teacher
+    T, alpha = 4.0, 0.5
+    s = torch.randn(len(idx), 10, device="cuda", dtype=torch.float64)
+    kd = lambda t: alpha * T * (torch.softmax(s / T, 1) - torch.softmax(t / T, 1)) / B   # noqa: E731
+    g_ref, g_out = kd(ref), kd(out[idx].double())
+    worst_kd = 0.0
+    for k, i in enumerate(idx):
         assert rel_l2(out[i].cpu(), ref[k].cpu()) < tol_img, i
+        e = rel_l2(g_out[k].cpu(), g_ref[k].cpu())
+        worst_kd = max(worst_kd, e)
+        assert e < TEACHER_KD_TOL[passes], (i, e)
+    print(f"teacher form {passes}: worst per-image KD-gradient rel L2 {worst_kd:.2e}")
