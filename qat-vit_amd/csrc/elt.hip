@@ -621,7 +621,8 @@ __global__ __launch_bounds__(64) void k_embed_bwd(const float* __restrict__ dx0,
 __device__ inline void wquant_body(const float* __restrict__ W, const float* __restrict__ qp, int per_channel, int qmin, int qmax,
                                    __bf16* __restrict__ wq, __bf16* __restrict__ wqT, int N, int K, int bx, int by,
                                    int8_t* __restrict__ w8 = nullptr, int32_t* __restrict__ wsum = nullptr, _Float16* __restrict__ w16 = nullptr,
-                                   int8_t* __restrict__ w8f = nullptr, int64_t wT16_gap = 0) {   // wT16_gap: byte distance from wqT to its fp16 twin (0: none)
+                                   int8_t* __restrict__ w8f = nullptr, int64_t wT16_gap = 0,   // wT16_gap: byte distance from wqT to its fp16 twin (0: none)
+                                   bool wT16_frag = false) {   // ... followed, another gap further, by the same fp16 integers in MFMA fragment order (f16strip.hip's B operand)
     // 32x32 tile transpose through LDS
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -649,12 +650,15 @@ __device__ inline void wquant_body(const float* __restrict__ W, const float* __r
     }
     if (wqT) {
         _Float16* const wT16 = wT16_gap ? reinterpret_cast<_Float16*>(reinterpret_cast<char*>(wqT) + wT16_gap) : nullptr;
+        char* const wT16f = (wT16_gap && wT16_frag) ? reinterpret_cast<char*>(wqT) + 2 * wT16_gap : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + ty + 8 * i, n = n0 + tx;
             if (n < N && k < K) {
                 wqT[(int64_t)k * N + n] = (__bf16)tile[tx][ty + 8 * i];
                 if (wT16) wT16[(int64_t)k * N + n] = (_Float16)tile[tx][ty + 8 * i];   // the transposed integers as fp16: the one-plane dgrad's B operand
+                // (fragment order of the [K rows][N fp16] matrix: w8f_offset on its 2 N-byte rows; element n of row k starts at byte 2 n)
+                if (wT16f) *reinterpret_cast<_Float16*>(wT16f + w8f_offset(k, 2 * n, 2 * N)) = (_Float16)tile[tx][ty + 8 * i];
             }
         }
     }
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(256) void k_w_quant_all(const WQuantTab t) {
     const int b = blockIdx.x - t.blk0[wi], kt = (t.K[wi] + 31) / 32;
     wquant_body(t.W[wi], t.qp[wi], t.per_channel, t.qmin, t.qmax, reinterpret_cast<__bf16*>(t.wq[wi]), reinterpret_cast<__bf16*>(t.wqT[wi]), t.N[wi],
                 t.K[wi], b % kt, b / kt, reinterpret_cast<int8_t*>(t.w8[wi]), t.wsum[wi], reinterpret_cast<_Float16*>(t.w16[wi]),
-                reinterpret_cast<int8_t*>(t.w8f[wi]), t.wT16 ? wT16_gap_bytes(t.N[wi], t.K[wi]) : 0);
+                reinterpret_cast<int8_t*>(t.w8f[wi]), t.wT16 ? wT16_gap_bytes(t.N[wi], t.K[wi]) : 0, ((t.wT16f_mask >> wi) & 1ull) != 0);
 }
 static_assert(sizeof(WQuantTab) <= 4096, "WQuantTab travels as a kernel argument");
 // row-major int8 [N, K] -> fragment order (kernel-level tests / callers that hold a row-major weight)

@@ -142,6 +142,7 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
         p->w_off[wi] = take((int64_t)N * K * 2);
         p->wT_off[wi] = take((int64_t)N * K * 2);
         (void)take((int64_t)N * K * 2);   // the same transposed integers as fp16, wT16_gap_bytes(N, K) behind (the one-plane dgrad's B operand)
+        (void)take((int64_t)N * K * 2);   // ... and once more in MFMA fragment order (written for fc2 where f16strip.hip takes the fc2 dgrad)
         p->w8_off[wi] = take((int64_t)N * K);
         const int kind = (wi == 0 || wi == d.n_w - 1) ? -1 : (wi - 1) % WB_COUNT;
         p->w16_off[wi] = (kind == WB_PROJ || kind == WB_FC2) ? take((int64_t)N * K * 2) : -1;
@@ -300,6 +301,12 @@ struct Ctx {
     const float* dy_mul(int i, int k) const { return reinterpret_cast<const float*>(dy_slot(i, k) + 1); }
     const float* dy_inv(int i, int k) const { return reinterpret_cast<const float*>(dy_slot(i, k) + 2); }
     void* wT16(int wi) const { int N, K; wshape(d, wi, &N, &K); return ws + p.wT_off[wi] + wT16_gap_bytes(N, K); }
+    void* wT16f(int wi) const { int N, K; wshape(d, wi, &N, &K); return ws + p.wT_off[wi] + 2 * wT16_gap_bytes(N, K); }
+    // fc2's transposed weight in fragment order exists where the strip form of its dgrad applies (ViT-S: N = 384 columns of 2 bytes = 768-byte rows, K = 1536)
+    bool wT16f_ok(int wi) const {
+        int N, K; wshape(d, wi, &N, &K);
+        return wi >= 1 && wi < d.n_w - 1 && (wi - 1) % WB_COUNT == WB_FC2 && N == 384 && K == 1536;
+    }
     template <typename T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
     template <typename T> T* blk(int64_t off, int i) const { return reinterpret_cast<T*>(ws + off + p.blk_stride * i); }
     const float* prm(int i) const { return reinterpret_cast<const float*>(params[i]); }
@@ -640,6 +647,8 @@ static int fwd(const Ctx& x, const float* images, float* logits, int s_from, int
         WQuantTab tw{};
         to.n = tq.n = tw.n = d.n_w;
         tw.wT16 = 1;
+        for (int wi = 0; wi < d.n_w && wi < 64; ++wi)
+            if (x.wT16f_ok(wi)) tw.wT16f_mask |= 1ull << wi;
         to.per_channel = tq.per_channel = tw.per_channel = c.w_per_channel;
         to.nslots = tq.nslots = kStatSlots;
         tq.qmin = tw.qmin = c.w_qmin; tq.qmax = tw.qmax = c.w_qmax; tq.c = c.averaging_const;
@@ -795,7 +804,12 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 post.mode = 9; post.qp = x.act_qp(x.aidx(i, AB_FC1)); post.qmin = qa; post.qmax = qb; post.colscale = x.dy_colscale(w_fc1);
                 post.out_hi = dY1_16; post.code8 = x.blk<void>(p.G8, i); post.code_mask = x.blk<void>(p.Y1m, i);
                 post.o16_mul = x.dy_mul(i, DS_FC1); post.o16_amax = x.dy_slot(i, DS_FC1);
-                if (dgrad16(dY16, DS_FC2, w_fc2, nullptr, &post)) return 1;
+                bool strip = false;
+                if (x.wT16f_ok(w_fc2) && f16_strip_enabled()) {   // the A-stationary strip form (f16strip.hip): the gradient plane fetched once for all four column tiles
+                    ProfScope ps(x.prof, 5, 2.0 * M * d.D * d.Hd, st);
+                    strip = launch_f16_strip_gelu_bwd(dY16, x.wT16f(w_fc2), nullptr, M, d.Hd, d.D, d.D, d.Hd, wscale1(w_fc2), x.dy_inv(i, DS_FC2), st, &post);
+                }
+                if (!strip && dgrad16(dY16, DS_FC2, w_fc2, nullptr, &post)) return 1;
             }
             if (wgrad16(dY1_16, DS_FC1, w_fc1, x.blk<void>(p.h2q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N2)), BG(i, B_FC1W), BG(i, B_FC1B))) return 1;
             const bool lnb = lnb_fuse() && d.D == 384;

@@ -119,6 +119,11 @@ int launch_gemm_nt_i8(const void* A8, const void* B8, const int32_t* wsum, const
 // N % 384 == 0, K % 32 == 0.
 int launch_gemm_nt_dy16(const void* A16, const void* B16, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* s1, const float* s2,
                         hipStream_t st, const NTPost* post = nullptr);
+// ---- f16strip.hip: the fc2 dgrad + GELU backward of the one-plane backward, A-stationary (K = 384, N = 1536); B16f = the transposed weight integers as fp16 in
+// fragment order (w8f_offset on their 768-byte rows).  true when it took the request; false -> launch_gemm_nt_dy16 with epilogue mode 9
+bool f16_strip_enabled();   // QATVIT_F16_STRIP != 0
+bool launch_f16_strip_gelu_bwd(const void* A16, const void* B16f, float* unused, int M, int N, int K, int lda, int ldc, const float* s1, const float* s2, hipStream_t st,
+                               const NTPost* post);
 // ---- i8strip.hip: the K = 384 two-pass forward GEMMs (qkv, fc1), A-stationary; returns true when it covered (and launched) the request
 bool launch_i8_strip(const void* A8, const void* B8f, const int32_t* wsum, const float* a_qp, int center, int M, int N, int K, int lda, int ldc,
                      const float* s1, const float* s2, const float* col_scale, const float* bias, uint32_t* stats, int stat_slots, hipStream_t st,
@@ -197,6 +202,7 @@ struct WQuantTab {
     void* w8f[kMaxW];   // optional: the int8 integers once more in fragment order (w8f_offset: B operand of the strip kernel; N % 48 == 0, K % 64 == 0)
     int N[kMaxW], K[kMaxW], blk0[kMaxW + 1]; int n, per_channel, qmin, qmax;
     int wT16;           // nonzero: every wqT[i] is followed, wT16_gap_bytes(N, K) further on, by the same transposed integers as fp16 (the table itself is at the 4-KiB kernel-argument limit)
+    unsigned long long wT16f_mask;   // bit i: ... and, another gap further, by those fp16 integers in MFMA fragment order (fc2 of ViT-S: the B operand of f16strip.hip; K % 48 == 0, 2 N % 64 == 0)
 };
 __host__ __device__ inline int64_t wT16_gap_bytes(int N, int K) { return ((int64_t)N * K * 2 + 255) & ~(int64_t)255; }
 int launch_w_observe_all(WObsTab& t, hipStream_t st);      // fills blk0
