@@ -222,36 +222,6 @@ struct ProfScope {
     }
 };
 
-// ---- a second stream for the weight gradients of the one-plane backward (QATVIT_BWD_STREAMS=0: everything on the caller's stream).  The dgrad chain of a
-// block (fc2 dgrad -> fc1 dgrad + LayerNorm backward -> proj dgrad -> attention backward -> qkv dgrad) is what the next block waits for; the four weight gradients
-// only have to be done when the stage range ends.  Every kernel of the step fills the chip in ONE round of workgroups that take a whole CU's LDS, so two kernels in
-// flight do not share CUs - but a CU whose dgrad workgroup has finished takes a weight-gradient workgroup instead of idling until the launch boundary, and the
-// boundaries themselves (387 per step, ~2.3 us each) overlap.  Fork / join by events on the caller's stream (a hipGraph capture follows them); keyed by the
-// engine's workspace like the profiler session.
-struct Side {
-    hipStream_t s = nullptr;
-    std::vector<hipEvent_t> ev;
-    size_t next = 0;
-    bool ok = false;
-    hipEvent_t event() { hipEvent_t e = ev[next]; next = (next + 1) % ev.size(); return e; }
-};
-static std::mutex g_side_mu;
-static std::unordered_map<const void*, std::shared_ptr<Side>> g_sides;
-static Side* side_of(const void* workspace) {
-    static const int on = getenv("QATVIT_BWD_STREAMS") ? atoi(getenv("QATVIT_BWD_STREAMS")) : 1;
-    if (!on) return nullptr;
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    auto it = g_sides.find(workspace);
-    if (it == g_sides.end()) {
-        auto sd = std::make_shared<Side>();
-        sd->ok = hipStreamCreateWithFlags(&sd->s, hipStreamNonBlocking) == hipSuccess;
-        sd->ev.assign(64, nullptr);
-        for (auto& e : sd->ev) sd->ok = sd->ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        it = g_sides.emplace(workspace, sd).first;
-    }
-    return it->second->ok ? it->second.get() : nullptr;
-}
-
 // QATVIT_I8=0: the grid x grid forward GEMMs (patch-embed, qkv, fc1) on bf16 MFMA instead of int8 MFMA (bit-identical results)
 static bool use_i8() {
     static const int on = getenv("QATVIT_I8") ? atoi(getenv("QATVIT_I8")) : 1;
@@ -783,8 +753,6 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
     if ((dy || cal) && (stage_from == 0 || inject)) launch_dy16_begin(dystate, nslots, stage_from == 0 ? dlogits : nullptr, d.B * d.C, st);
     // calibration: the maximum of a tensor the pair form just wrote (its hi plane) into the tensor's slot
     auto calib = [&](const void* hi, int64_t n, int blk_i, int k) { if (cal && blk_i >= 0) launch_absmax_bf16(hi, n, x.dy_slot(blk_i, k), st); };
-    Side* const side = dy ? side_of(x.ws) : nullptr;
-    hipEvent_t rdA = nullptr, rd1 = nullptr, rdB = nullptr, rdQ = nullptr;   // where the side stream stood after the last reader of planes A / fc1-gradient / B / qkv-gradient
     for (int s = stage_from; s <= stage_to; ++s) {
         if (s == 0) {
             const int base = P_BLOCK0 + B_COUNT * d.depth;
@@ -802,32 +770,24 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
         } else if (s <= d.depth && dy) {
             // ---- one block, one-plane form.  Same dataflow as the pair form below; every dY is one fp16 plane in the hi buffer of the pair.
             const int i = d.depth - s;
-            void* dY16 = x.at<void>(p.dYs_hi);     // the masked residual gradient entering fc2 (plane "A": the hi buffer of the pair form)
-            void* dYp16 = x.at<void>(p.dYs_lo);    // ... entering proj (plane "B": the pair form's lo buffer - two planes, so that a weight gradient may still read one
-                                                   //     while the dgrad chain already writes the other)
+            void* dY16 = x.at<void>(p.dYs_hi);
             void* dY1_16 = x.at<void>(p.dY1_hi);
             void* dqkv16 = x.at<void>(p.dqkv_hi);
             const int w_fc2 = x.widx(i, WB_FC2), w_fc1 = x.widx(i, WB_FC1), w_proj = x.widx(i, WB_PROJ), w_qkv = x.widx(i, WB_QKV);
             float* const scal16 = x.blk<float>(p.scal16, i);
-            hipStream_t const wst = side ? side->s : st;   // the weight gradients' stream
-            // fork: the side stream may start once everything enqueued on the caller's stream so far is done (the producer of the plane it reads)
-            auto fork = [&]() { if (side) { hipEvent_t e = side->event(); (void)hipEventRecord(e, st); (void)hipStreamWaitEvent(wst, e, 0); } };
-            // a weight gradient was enqueued: remember where the side stream stands, for whoever overwrites the plane it reads
-            auto mark = [&](hipEvent_t& slot) { if (side) { slot = side->event(); (void)hipEventRecord(slot, wst); } };
-            auto wait_reader = [&](hipEvent_t& slot) { if (side && slot) { (void)hipStreamWaitEvent(st, slot, 0); slot = nullptr; } };
             auto wscale1 = [&](int wi) { return c.w_per_channel ? nullptr : x.wfq[wi].scale; };
             // wgrad of layer wi from the plane P16 (slot k): X as fp16 integers (X_lo == nullptr), an fp16 pair, or codes + a table of fp16 pairs
             auto wgrad16 = [&](const void* P16, int k, int wi, const void* X_hi, const void* X_lo, const void* Xc, const uint32_t* lut, const float* s_x, float* dW,
                                float* db) -> int {
                 int N, K; wshape(d, wi, &N, &K);
                 const qatvit_fq& f = x.wfq[wi];
-                ProfScope ps(x.prof, (wi == w_proj || Xc) ? 6 : 3, 2.0 * M * N * K, wst);
+                ProfScope ps(x.prof, (wi == w_proj || Xc) ? 6 : 3, 2.0 * M * N * K, st);
                 const float* rdiv = c.w_per_channel ? f.scale : nullptr;
                 if (Xc)
                     return launch_gemm_tn_codes_dy16(P16, Xc, lut, dW, M, N, K, N, K, K, s_x, x.dy_inv(i, k), x.prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
-                                                     c.w_qmin, c.w_qmax, db, rdiv, wst, x.at<float>(p.tn_scratch), kTnScratchBytes);
+                                                     c.w_qmin, c.w_qmax, db, rdiv, st, x.at<float>(p.tn_scratch), kTnScratchBytes);
                 return launch_gemm_tn_dy16(P16, X_hi, X_lo, dW, M, N, K, N, K, K, s_x, x.dy_inv(i, k), x.prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
-                                           c.w_qmin, c.w_qmax, db, rdiv, wst, x.at<float>(p.tn_scratch), kTnScratchBytes);
+                                           c.w_qmin, c.w_qmax, db, rdiv, st, x.at<float>(p.tn_scratch), kTnScratchBytes);
             };
             auto dgrad16 = [&](const void* P16, int k, int wi, float* dX, const NTPost* post) -> int {
                 int N, K; wshape(d, wi, &N, &K);
@@ -838,10 +798,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             if (inject && s == stage_from)
                 launch_mask_bwd(0, dxA, x.blk<float>(p.Y2, i), x.act_qp(x.aidx(i, AB_FC2)), qa, qb, x.dy_colscale(w_fc2), d.D, dY16, nullptr, d.M * d.D, st,
                                 x.dy_mul(i, DS_FC2), x.dy_slot(i, DS_FC2));
-            fork();
             if (wgrad16(dY16, DS_FC2, w_fc2, nullptr, nullptr, x.blk<void>(p.G8, i), x.blk<uint32_t>(p.glut, i), scal16 + 1, BG(i, B_FC2W), BG(i, B_FC2B))) return 1;
-            mark(rdA);
-            wait_reader(rd1);   // (the previous block's fc1 weight gradient has read the fc1-gradient plane this dgrad overwrites)
             {   // fc2 dgrad + GELU backward + fc1's STE mask -> the fc1 output gradient, one plane
                 NTPost post{};
                 post.mode = 9; post.qp = x.act_qp(x.aidx(i, AB_FC1)); post.qmin = qa; post.qmax = qb; post.colscale = x.dy_colscale(w_fc1);
@@ -854,18 +811,15 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 }
                 if (!strip && dgrad16(dY16, DS_FC2, w_fc2, nullptr, &post)) return 1;
             }
-            fork();
             if (wgrad16(dY1_16, DS_FC1, w_fc1, x.blk<void>(p.h2q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N2)), BG(i, B_FC1W), BG(i, B_FC1B))) return 1;
-            mark(rd1);
-            wait_reader(rdB);   // (the previous block's proj weight gradient has read plane B)
             const bool lnb = lnb_fuse() && d.D == 384;
-            LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dYp16, nullptr, x.dy_mul(i, DS_PROJ), x.dy_slot(i, DS_PROJ)};
+            LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dY16, nullptr, x.dy_mul(i, DS_PROJ), x.dy_slot(i, DS_PROJ)};
             if (lnb) {
                 NTPost post{};
                 post.mode = 8; post.qp = x.act_qp(x.aidx(i, AB_N2)); post.qmin = qa; post.qmax = qb;
                 post.lnb_x = x.blk<float>(p.x_mid, i); post.lnb_mean = x.blk<float>(p.mean2, i); post.lnb_rstd = x.blk<float>(p.rstd2, i);
                 post.lnb_gamma = x.bprm(i, B_N2W); post.lnb_beta = x.bprm(i, B_N2B); post.lnb_dx_in = dxA; post.lnb_dgamma = BG(i, B_N2W); post.lnb_dbeta = BG(i, B_N2B);
-                post.lnb_nmask = nx_proj.maskbits; post.colscale = nx_proj.colscale; post.out_hi = dYp16;
+                post.lnb_nmask = nx_proj.maskbits; post.colscale = nx_proj.colscale; post.out_hi = dY16;
                 post.o16_mul = nx_proj.o16_mul; post.o16_amax = nx_proj.o16_amax;
                 if (dgrad16(dY1_16, DS_FC1, w_fc1, dxB, &post)) return 1;
             } else {
@@ -878,19 +832,13 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             // (the float X operands - attention output, gelu output - enter the one-plane weight gradients rounded to fp16 like dY itself: one pass;
             //  QATVIT_DY16_XPAIR=1 keeps them as fp16 (hi, lo) pairs, two passes)
             static const bool xpair = getenv("QATVIT_DY16_XPAIR") && atoi(getenv("QATVIT_DY16_XPAIR")) != 0;
-            fork();
-            if (wgrad16(dYp16, DS_PROJ, w_proj, x.blk<void>(p.O16_hi, i), xpair ? x.blk<void>(p.O16_lo, i) : nullptr, nullptr, nullptr, scal16, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
-            mark(rdB);
-            if (dgrad16(dYp16, DS_PROJ, w_proj, x.at<float>(p.dO), nullptr)) return 1;
-            wait_reader(rdQ);   // (the previous block's qkv weight gradient has read the qkv-gradient plane the attention backward overwrites)
+            if (wgrad16(dY16, DS_PROJ, w_proj, x.blk<void>(p.O16_hi, i), xpair ? x.blk<void>(p.O16_lo, i) : nullptr, nullptr, nullptr, scal16, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
+            if (dgrad16(dY16, DS_PROJ, w_proj, x.at<float>(p.dO), nullptr)) return 1;
             if (launch_attn_bwd(nullptr, x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i),
                                 x.at<float>(p.delta), x.at<float>(p.dO), dqkv16, nullptr, x.dy_colscale(w_qkv), st, x.blk<void>(p.qkv8, i), x.blk<void>(p.qkvm, i),
                                 x.dy_mul(i, DS_QKV), x.dy_slot(i, DS_QKV)))
                 return 1;
-            fork();
             if (wgrad16(dqkv16, DS_QKV, w_qkv, x.blk<void>(p.h1q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N1)), BG(i, B_QKVW), BG(i, B_QKVB))) return 1;
-            mark(rdQ);
-            wait_reader(rdA);   // (this block's fc2 weight gradient has read plane A, which the qkv dgrad's epilogue overwrites with the next block's)
             LnBwdNext nx_fc2{i > 0 ? x.blk<void>(p.m2, i - 1) : nullptr, i > 0 ? x.dy_colscale(x.widx(i - 1, WB_FC2)) : nullptr, dY16, nullptr,
                              i > 0 ? x.dy_mul(i - 1, DS_FC2) : nullptr, i > 0 ? x.dy_slot(i - 1, DS_FC2) : nullptr};
             if (lnb) {
@@ -988,11 +936,6 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                                G(P_PE_B), false))
                 return 1;
         }
-    }
-    if (side) {   // join: the caller's stream continues (all-reduce of the bucket, the optimizer) behind the last weight gradient
-        hipEvent_t e = side->event();
-        (void)hipEventRecord(e, side->s);
-        (void)hipStreamWaitEvent(st, e, 0);
     }
     if (dy || cal) launch_dy16_end(dystate, nslots, dy ? 1 : 0, st);
     return 0;
