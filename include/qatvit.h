@@ -186,6 +186,11 @@ int qatvit_gemm_tn_dy16(const void* P16, const void* Q_hi, const void* Q_lo, con
                         int32_t ldp, int32_t ldq, int32_t ldc, const float* s1, const float* s2, const float* W, const float* w_scale, const int32_t* w_zp,
                         int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes,
                         void* stream);
+/* tn with the grid X operand as ONE byte per element (what the forward's int8 GEMM reads): Q8[m, Kw] = q - center as int8 (ldq in bytes, % 16 == 0),
+ * a_qp = that activation's {scale, 1/scale, zero_point, enabled}: X = Q8 + center - zero_point, *s1 of the form above = a_qp[0].  Kw % 384 == 0. */
+int qatvit_gemm_tn_q8_dy16(const void* P16, const void* Q8, const float* a_qp, int32_t center, float* C, int32_t M, int32_t N, int32_t Kw, int32_t ldp, int32_t ldq,
+                           int32_t ldc, const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin,
+                           int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes, void* stream);
 
 /* Attention core between attn.qkv and attn.proj (timm Attention; no fake-quant inside).
  *  qkv: PRE-fake-quant fp32 [B*T, 3*D]; qp: {scale, 1/scale, zero_point, enabled} of the qkv activation FQ

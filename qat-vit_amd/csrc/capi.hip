@@ -188,6 +188,18 @@ int qatvit_gemm_tn_dy16(const void* P16, const void* Q_hi, const void* Q_lo, con
     return 0;
 }
 
+int qatvit_gemm_tn_q8_dy16(const void* P16, const void* Q8, const float* a_qp, int32_t center, float* C, int32_t M, int32_t N, int32_t Kw, int32_t ldp, int32_t ldq,
+                           int32_t ldc, const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin,
+                           int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes, void* stream) {
+    QV_CHECK_ARG(P16 && Q8 && a_qp && C, "qatvit_gemm_tn_q8_dy16: null pointer argument");
+    QV_CHECK_ARG(!W || (w_scale && w_zp), "qatvit_gemm_tn_q8_dy16: weight mask needs w_scale and w_zp");
+    if (launch_gemm_tn_q8_dy16(P16, Q8, a_qp, center, C, M, N, Kw, ldp, ldq, ldc, s2, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div,
+                               (hipStream_t)stream, scratch, scratch_bytes))
+        return 1;
+    QV_CHECK_LAUNCH("qatvit_gemm_tn_q8_dy16");
+    return 0;
+}
+
 int qatvit_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int32_t M, int32_t N, int32_t Kw, int32_t ldp,
                          int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel,
                          int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes, void* stream) {

@@ -777,12 +777,16 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             float* const scal16 = x.blk<float>(p.scal16, i);
             auto wscale1 = [&](int wi) { return c.w_per_channel ? nullptr : x.wfq[wi].scale; };
             // wgrad of layer wi from the plane P16 (slot k): X as fp16 integers (X_lo == nullptr), an fp16 pair, or codes + a table of fp16 pairs
+            // (X8: the same grid integers as q - center, one byte each - the forward's int8 operand; taken instead of the fp16 plane where k_gemm_tn_q8 applies)
             auto wgrad16 = [&](const void* P16, int k, int wi, const void* X_hi, const void* X_lo, const void* Xc, const uint32_t* lut, const float* s_x, float* dW,
-                               float* db) -> int {
+                               float* db, const void* X8 = nullptr) -> int {
                 int N, K; wshape(d, wi, &N, &K);
                 const qatvit_fq& f = x.wfq[wi];
                 ProfScope ps(x.prof, (wi == w_proj || Xc) ? 6 : 3, 2.0 * M * N * K, st);
                 const float* rdiv = c.w_per_channel ? f.scale : nullptr;
+                if (X8 && tn_q8_enabled() && K % 384 == 0)
+                    return launch_gemm_tn_q8_dy16(P16, X8, s_x, x.center(), dW, M, N, K, N, K, K, x.dy_inv(i, k), x.prm(wparam(d, wi)), f.scale, f.zero_point,
+                                                  c.w_per_channel, c.w_qmin, c.w_qmax, db, rdiv, st, x.at<float>(p.tn_scratch), kTnScratchBytes);
                 if (Xc)
                     return launch_gemm_tn_codes_dy16(P16, Xc, lut, dW, M, N, K, N, K, K, s_x, x.dy_inv(i, k), x.prm(wparam(d, wi)), f.scale, f.zero_point, c.w_per_channel,
                                                      c.w_qmin, c.w_qmax, db, rdiv, st, x.at<float>(p.tn_scratch), kTnScratchBytes);
@@ -811,7 +815,9 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 }
                 if (!strip && dgrad16(dY16, DS_FC2, w_fc2, nullptr, &post)) return 1;
             }
-            if (wgrad16(dY1_16, DS_FC1, w_fc1, x.blk<void>(p.h2q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N2)), BG(i, B_FC1W), BG(i, B_FC1B))) return 1;
+            if (wgrad16(dY1_16, DS_FC1, w_fc1, x.blk<void>(p.h2q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N2)), BG(i, B_FC1W), BG(i, B_FC1B),
+                        x.blk<void>(p.h2q8, i)))
+                return 1;
             const bool lnb = lnb_fuse() && d.D == 384;
             LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dY16, nullptr, x.dy_mul(i, DS_PROJ), x.dy_slot(i, DS_PROJ)};
             if (lnb) {
@@ -838,7 +844,9 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                                 x.at<float>(p.delta), x.at<float>(p.dO), dqkv16, nullptr, x.dy_colscale(w_qkv), st, x.blk<void>(p.qkv8, i), x.blk<void>(p.qkvm, i),
                                 x.dy_mul(i, DS_QKV), x.dy_slot(i, DS_QKV)))
                 return 1;
-            if (wgrad16(dqkv16, DS_QKV, w_qkv, x.blk<void>(p.h1q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N1)), BG(i, B_QKVW), BG(i, B_QKVB))) return 1;
+            if (wgrad16(dqkv16, DS_QKV, w_qkv, x.blk<void>(p.h1q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N1)), BG(i, B_QKVW), BG(i, B_QKVB),
+                        x.blk<void>(p.h1q8, i)))
+                return 1;
             LnBwdNext nx_fc2{i > 0 ? x.blk<void>(p.m2, i - 1) : nullptr, i > 0 ? x.dy_colscale(x.widx(i - 1, WB_FC2)) : nullptr, dY16, nullptr,
                              i > 0 ? x.dy_mul(i - 1, DS_FC2) : nullptr, i > 0 ? x.dy_slot(i - 1, DS_FC2) : nullptr};
             if (lnb) {

@@ -1386,6 +1386,7 @@ struct TNArgs {
     const uint8_t* Qc;    // [M, ldq] uint8 table indices (ldq in bytes)
     const uint32_t* lutQ;
     const float* s2;      // optional second device scalar: multiplies alpha AND the bias gradient (the one-plane form: P = dY * 2^e, *s2 = 2^-e)
+    int q8_center;        // k_gemm_tn_q8, grid form: Qc holds q - q8_center as int8, s1 the activation's {scale, 1/scale, zero point, ..}: X = Qc + q8_center - s1[2]
 };
 
 template <int ROWB>  // ROWB: bytes per LDS row of the image (256 for a 128-column tile, 768 for a 384-column tile)
@@ -1768,6 +1769,223 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, i
         if (nbase + e < p.N) p.C[(int64_t)(nbase + e) * p.ldc + kw] = outv[e];
 }
 
+// ---------------------------------------------------------------------------- TN, one fp16 P plane x a BYTE Q operand (the one-plane backward)
+// The weight-gradient kernels are bound by the L2 -> LDS fill of their workgroup (a 128 x 384 tile takes 256 B of P and 768 B of fp16 Q per token:
+// 2.4 MB per workgroup, ~42 GB/s per CU, against 24 us of MFMA).  Both X operands of the big weight gradients exist as ONE byte per element:
+//   MODE 0: LayerNorm output on its grid, q - center as int8 (the forward's int8-MFMA operand): X = q8 + (center - zp), exact in fp16;
+//   MODE 1: gelu(fq(fc1 output)) as uint8 codes + a 256-entry table (fp16 hi halves), as fc2's forward reads it.
+// The byte tile lands by LDS-DMA as it lies in memory ([64 tokens][384 B], 16-B chunks XOR-swizzled), `ds_read_b64_tr_b8` hands every lane the 8
+// consecutive TOKENS of its column (the MFMA's k index), and the bytes become the fp16 operand IN REGISTERS: MODE 0 by the 0x6400 | u trick (u = q8 ^
+// 0x80: 1024 + u as fp16, minus 1152 - (center - zp), two packed adds per four elements), MODE 1 by eight gathers from a table replicated over the
+// 32 banks (entry e for lane l at dword e * 32 + (l & 31): conflict-free whatever the codes are).  No expansion pass through LDS, no second barrier,
+// 640 B per token instead of 1024.  64-token stages; WM x WNK waves as in k_gemm_tn (accumulator layout shared with k_tn_reduce).
+__device__ inline int tn8_sw(int row) { return (row >> 1) & 7; }   // 384-B rows: rows r, r + 1 differ by 8 chunks mod 16 already; the XOR spreads the 8 row pairs of a 16-row half
+__device__ inline uint2 tr8_frag(const char* img, int row0, int chunk, int lane) {
+    // block of 8 rows x 16 byte columns per 16-lane group: lane 2q + p supplies the address of row q, bytes 8p .. 8p + 7; lane i receives column i, row q in byte q
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 1, pp = idx & 1;
+    const int row = row0 + 8 * g + q;
+    typedef int v2i32_ __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2i32_ lds_v2i32;
+    const v2i32_ v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i32*)(img + row * 384 + ((chunk ^ tn8_sw(row)) << 4) + pp * 8));
+    return make_uint2((uint32_t)v[0], (uint32_t)v[1]);
+}
+
+template <int MODE, int NSTAGE, int WM>
+__global__ __launch_bounds__(512) void k_gemm_tn_q8(const TNArgs p) {
+    constexpr int BN = 128, BKW = 384, BK = 64, NW = 8, WNK = NW / WM;
+    constexpr int TM = BN / WM / 16, TNT = BKW / WNK / 16;
+    static_assert(TM == WNK, "bias: row fragment i of a wave row is summed by the wave with wn == i");
+    constexpr int IMGP = BK * 256, IMGQ = BK * BKW, STAGE = IMGP + IMGQ;
+    constexpr int PP = IMGP / 1024 / NW, PQ = IMGQ / 1024 / NW, NDMA = PP + PQ;   // 2 + 3 one-KiB DMA pieces per wave per stage
+    constexpr int TAB = NSTAGE * STAGE;                                           // MODE 1: [256 entries][32 banks] dwords
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNK, wn = wave % WNK;
+    const int tilesK = p.Kw / BKW;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = vb % p.tiles, split = vb / p.tiles;
+    const int n0 = (tile / tilesK) * BN, k0 = (tile % tilesK) * BKW;
+    const int total_steps = (p.M + BK - 1) / BK;
+    const int s_begin = split * p.steps_per_split;
+    const int nsteps = min(total_steps, s_begin + p.steps_per_split) - s_begin;
+    const v4i32 rP = make_rsrc_v(p.P0, (int64_t)p.M * p.ldp * 2);
+    const v4i32 rQ = make_rsrc_v(p.Qc, (int64_t)p.M * p.ldq);     // rows past M read as zero bytes: P is zero there too
+    auto issue = [&](int s) {
+        char* st = smem + (s % NSTAGE) * STAGE;
+        const int mrow0 = (s_begin + s) * BK;
+#pragma unroll
+        for (int c = 0; c < PP; ++c) {
+            const int piece = wave * PP + c, row = piece * 4 + (lane >> 4);
+            dma16_asm(rP, st + piece * 1024, (uint32_t)(((int64_t)(mrow0 + row) * p.ldp + n0 + (((lane & 15) ^ tn_sw(row)) << 3)) * 2));
+        }
+#pragma unroll
+        for (int c = 0; c < PQ; ++c) {
+            const int piece = wave * PQ + c, L = piece * 64 + lane, row = L / 24, cp = L % 24;
+            dma16_asm(rQ, st + IMGP + piece * 1024, (uint32_t)((int64_t)(mrow0 + row) * p.ldq + k0 + ((cp ^ tn8_sw(row)) << 4)));
+        }
+    };
+    f32x4 acc[TM][TNT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient: row fragment wn of this wave's rows, one more MFMA per 32 tokens against a fragment of ones - in EVERY workgroup (no branch inside the
+    // loop); only the first Kw tile's workgroups add their sums
+    const bool do_bias = p.dbias != nullptr && (tile % tilesK) == 0;
+    f32x4 accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
+
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nsteps) issue(s);
+    qv_f16x2 cadd;
+    if constexpr (MODE == 0) {
+        const float c = (float)p.q8_center - p.s1[2] - 1152.0f;     // X = (1024 + u) + c, u = q8 + 128: an integer of magnitude < 2048, exact
+        cadd[0] = (_Float16)c; cadd[1] = (_Float16)c;
+    } else {
+        uint32_t* tab = reinterpret_cast<uint32_t*>(smem + TAB);
+        for (int i = tid; i < 256 * 32; i += 512) tab[i] = p.lutQ[i >> 5] & 0xffffu;
+    }
+    const uint32_t tab_lane = (uint32_t)(TAB + (lane & 31) * 4);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // One 32-token substep's operands in registers: TM P fragments + the bias fragment + TNT raw byte fragments (Ops), expanded to fp16 by x1 / x2.
+    // The loop is software-pipelined by hand over two register sets: the LDS reads of substep t + 1 are issued in front of the MFMAs of substep t, the table
+    // gathers (MODE 1) in the middle of them - the hipcc schedule of the plain loop kept ONE fragment in flight (2 reads per 3 MFMAs, every fragment a stall).
+    struct Ops { f16x8 pf[TM]; f16x8 pb; uint2 qb[TNT]; uint32_t v[MODE == 1 ? TNT * 8 : 1]; f16x8 qf[TNT]; };
+    // (two groups of LDS reads - 13 and 8: the lgkm counter holds 15, a 16th outstanding read makes hipcc insert a wait for the oldest ones)
+    auto load1 = [&](Ops& o, const char* st, int kk) {
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) o.qb[j] = tr8_frag(st + IMGP, 32 * kk, wn * TNT + j, lane);
+#pragma unroll
+        for (int i = 0; i < TM / 2; ++i) o.pf[i] = __builtin_bit_cast(f16x8, tr_frag<256>(st, 32 * kk, wm * (16 * TM) + 16 * i, lane));
+        o.pb = __builtin_bit_cast(f16x8, tr_frag<256>(st, 32 * kk, wm * (16 * TM) + 16 * wn, lane));
+    };
+    auto load2 = [&](Ops& o, const char* st, int kk) {
+#pragma unroll
+        for (int i = TM / 2; i < TM; ++i) o.pf[i] = __builtin_bit_cast(f16x8, tr_frag<256>(st, 32 * kk, wm * (16 * TM) + 16 * i, lane));
+    };
+    auto x1 = [&](Ops& o) {     // MODE 1: the table gathers of the codes
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < TNT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o.v[8 * j + q] = *reinterpret_cast<const uint32_t*>(smem + tab_lane + (((o.qb[j].x >> (8 * q)) & 0xffu) << 7));
+                    o.v[8 * j + 4 + q] = *reinterpret_cast<const uint32_t*>(smem + tab_lane + (((o.qb[j].y >> (8 * q)) & 0xffu) << 7));
+                }
+        }
+    };
+    auto x2 = [&](Ops& o) {
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) {
+            uint32_t h[4];
+            if constexpr (MODE == 0) {
+                const uint32_t x0 = o.qb[j].x ^ 0x80808080u, x1_ = o.qb[j].y ^ 0x80808080u;
+                const uint32_t e[4] = {__builtin_amdgcn_perm(0x64646464u, x0, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, x0, 0x04030402u),
+                                       __builtin_amdgcn_perm(0x64646464u, x1_, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, x1_, 0x04030402u)};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[q] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(qv_f16x2, e[q]) + cadd);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[q] = o.v[8 * j + 2 * q] | (o.v[8 * j + 2 * q + 1] << 16);
+            }
+            o.qf[j] = __builtin_bit_cast(f16x8, (u32x4){h[0], h[1], h[2], h[3]});
+        }
+    };
+    auto mm = [&](const Ops& o, int lo, int hi) {
+        if (lo == 0) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.pb, ones, accb, 0, 0, 0);
+#pragma unroll
+        for (int i = lo; i < hi; ++i)
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.pf[i], o.qf[j], acc[i][j], 0, 0, 0);
+    };
+    Ops A, B;
+    {   // set B starts as zeros: the first pass of the loop runs "the substep before the first" on it
+        const f16x8 z = __builtin_bit_cast(f16x8, (u32x4){0u, 0u, 0u, 0u});
+#pragma unroll
+        for (int i = 0; i < TM; ++i) B.pf[i] = z;
+        B.pb = z;
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) B.qf[j] = z;
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        if (NSTAGE >= 3 && s + NSTAGE - 2 < nsteps) wait_vmcnt<(NSTAGE - 2) * NDMA>();
+        else wait_vmcnt<0>();
+        // (every LDS read of the stage this step's DMA overwrites has returned: they were issued a substep of MFMAs ago.  MODE 1: the first barrier publishes the table)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + NSTAGE - 1 < nsteps) issue(s + NSTAGE - 1);
+        const char* st = smem + (s % NSTAGE) * STAGE;
+        load1(A, st, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(B, 0, TM / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        load2(A, st, 0);
+        x1(A);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(B, TM / 2, TM);
+        __builtin_amdgcn_sched_barrier(0);
+        x2(A);
+        load1(B, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(A, 0, TM / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        load2(B, st, 1);
+        x1(B);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(A, TM / 2, TM);
+        __builtin_amdgcn_sched_barrier(0);
+        x2(B);
+    }
+    mm(B, 0, TM);
+    // ---- epilogue (k_gemm_tn's: raw accumulators to the split scratch, or scale / STE mask / atomics)
+    const float bscale = p.s2 ? *p.s2 : 1.f;
+    const float alpha = (p.s1 ? *p.s1 : 1.f) * bscale;
+    const int r = lane & 15, g = lane >> 4;
+    if (do_bias && r == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wm * (16 * TM) + 16 * wn + 4 * g + e;
+            if (n < p.N) atomicAdd(&p.dbias[n], accb[e] * bscale * (p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f));
+        }
+    }
+    if (p.partial) {
+        float4* dst = reinterpret_cast<float4*>(p.partial) + ((int64_t)vb * NW + wave) * (TM * TNT * 64);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) dst[(i * TNT + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wm * (16 * TM) + 16 * i + 4 * g + e;
+            if (n >= p.N) continue;
+            const float rdiv = p.row_div ? __fdiv_rn(1.0f, p.row_div[n]) : 1.0f;
+            float inv = 0.f, fzp = 0.f;
+            if (p.W) {
+                const int ci = p.w_per_channel ? n : 0;
+                inv = __fdiv_rn(1.0f, p.w_scale[ci]);
+                fzp = (float)p.w_zp[ci];
+            }
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) {
+                const int kw = k0 + wn * (16 * TNT) + 16 * j + r;
+                float v = acc[i][j][e] * (alpha * rdiv);
+                if (p.W) {
+                    const float q = rintf(p.W[(int64_t)n * p.ldc + kw] * inv) + fzp;
+                    if (!(q >= (float)p.w_qmin && q <= (float)p.w_qmax)) v = 0.f;
+                }
+                atomicAdd(&p.C[(int64_t)n * p.ldc + kw], v);
+            }
+        }
+    }
+}
+
 // token-split plan shared by the weight-gradient launchers: one round of <= 256 long-running workgroups (the 128 - 160 KiB stage ring admits ONE
 // workgroup per CU, so one round beats two rounds of short ones: same MFMA time, half the prologues and half the partial tiles), >= 256 tokens per split
 static int tn_plan(TNArgs& a, int M, int bk, int tiles) {
@@ -1855,6 +2073,46 @@ int launch_gemm_tn_dy16(const void* P16, const void* Q_hi, const void* Q_lo, flo
                               partial, partial_bytes);
 }
 
+// The byte-Q forms of the one-plane weight gradient (k_gemm_tn_q8).  QATVIT_TN_Q8=0: the fp16-plane / expand-through-LDS kernels instead.
+bool tn_q8_enabled() {
+    static const bool on = !(getenv("QATVIT_TN_Q8") && atoi(getenv("QATVIT_TN_Q8")) == 0);
+    return on;
+}
+template <int MODE>
+static int gemm_tn_q8_impl(const void* P16, const void* Q8, const uint32_t* lutQ16, int center, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc,
+                           const float* s1, const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax,
+                           float* dbias, const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
+    if (M < 1 || N % 128 != 0 || Kw % 384 != 0 || ldp % 8 != 0 || ldq % 16 != 0 || !P16 || !Q8 || !C || !s1 || (MODE == 1 && !lutQ16)) {
+        set_error("gemm_tn_q8: unsupported arguments M=%d N=%d Kw=%d ldp=%d ldq=%d (need N%%128==0, Kw%%384==0, ldp%%8==0, ldq%%16==0, s1)", M, N, Kw, ldp, ldq);
+        return 1;
+    }
+    TNArgs a = tn_args(P16, P16, nullptr, nullptr, C, M, N, Kw, ldp, ldq, ldc, s1, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div);
+    a.Qc = reinterpret_cast<const uint8_t*>(Q8); a.lutQ = lutQ16; a.s2 = s2; a.q8_center = center;
+    const int tiles = (N / 128) * (Kw / 384);
+    const int splits = tn_plan(a, M, 64, tiles);
+    const int grid = tiles * splits;
+    // one wave row of eight waves (128 x 48 per wave): every Q fragment is expanded by exactly one wave
+    constexpr int WM = 1, WNK = 8, TM = 8, TNT = 3;
+    constexpr int NS = MODE == 0 ? 4 : 3;
+    constexpr size_t lds = (size_t)NS * (64 * 256 + 64 * 384) + (MODE == 1 ? 256 * 32 * 4 : 0);   // 160 KiB / 152 KiB
+    static_assert(lds <= 160 * 1024, "LDS");
+    const int64_t tile_f4 = (int64_t)WM * WNK * TM * TNT * 64;
+    const bool two_phase = partial && splits > 1 && (int64_t)grid * tile_f4 * 16 <= partial_bytes;
+    a.partial = two_phase ? partial : nullptr;
+    static bool once = (allow_lds(k_gemm_tn_q8<MODE, NS, WM>, lds), true);
+    (void)once;
+    k_gemm_tn_q8<MODE, NS, WM><<<grid, 512, lds, st>>>(a);
+    if (two_phase) k_tn_reduce<<<(int)cdiv((int64_t)tiles * tile_f4, 256), 256, 0, st>>>(a, splits, WM, WNK, TM, TNT);
+    return 0;
+}
+// grid X operand of the one-plane weight gradient as int8: Q8[m][k] = q - center, a_qp = the activation's {scale, 1/scale, zero point, enabled}
+int launch_gemm_tn_q8_dy16(const void* P16, const void* Q8, const float* a_qp, int center, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s2,
+                           const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias, const float* row_div,
+                           hipStream_t st, float* partial, int64_t partial_bytes) {
+    return gemm_tn_q8_impl<0>(P16, Q8, nullptr, center, C, M, N, Kw, ldp, ldq, ldc, a_qp, s2, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div, st,
+                              partial, partial_bytes);
+}
+
 // Weight gradient with the Q operand as uint8 table indices + a 256-entry table of bf16 (hi | lo << 16) pairs (fc2: Q = gelu(fq(fc1 output))): the
 // 128 x 384 tile of launch_gemm_tn's split-Q form, the same MFMAs in the same order - bit-identical to it on the expanded planes.
 template <bool DY16, int TQ = 2>   // TQ = 1 (one-plane form only): the hi half of every table entry alone - X rounded to fp16, one MFMA pass
@@ -1893,6 +2151,9 @@ int launch_gemm_tn_codes_dy16(const void* P16, const void* Qc, const uint32_t* l
                               const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
                               const float* row_div, hipStream_t st, float* partial, int64_t partial_bytes) {
     static const int xpair = getenv("QATVIT_DY16_XPAIR") ? atoi(getenv("QATVIT_DY16_XPAIR")) : 0;   // QATVIT_DY16_XPAIR=1: the float X operands as fp16 (hi, lo) pairs
+    if (!xpair && tn_q8_enabled() && ldq % 16 == 0 && Kw % 384 == 0)
+        return gemm_tn_q8_impl<1>(P16, Qc, lutQ16, 0, C, M, N, Kw, ldp, ldq, ldc, s1, s2, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias, row_div, st, partial,
+                                  partial_bytes);
     if (!xpair)
         return gemm_tn_codes_impl<true, 1>(P16, nullptr, Qc, lutQ16, C, M, N, Kw, ldp, ldq, ldc, s1, s2, W, w_scale, w_zp, w_per_channel, w_qmin, w_qmax, dbias,
                                            row_div, st, partial, partial_bytes);

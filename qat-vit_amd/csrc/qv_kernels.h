@@ -156,6 +156,12 @@ int launch_gemm_tn_dy16(const void* P16, const void* Q_hi, const void* Q_lo, flo
 int launch_gemm_tn_codes_dy16(const void* P16, const void* Qc, const uint32_t* lutQ16, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s1,
                               const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias,
                               const float* row_div, hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
+// ... with the grid X operand as ONE byte per element: Q8 = q - center as int8 (the forward's int8-MFMA operand), a_qp = that activation's {scale, 1/scale,
+// zero point, enabled}: X = Q8 + center - zero point, expanded to fp16 in registers (k_gemm_tn_q8).  Kw % 384 == 0, ldq % 16 == 0 (bytes).
+int launch_gemm_tn_q8_dy16(const void* P16, const void* Q8, const float* a_qp, int center, float* C, int M, int N, int Kw, int ldp, int ldq, int ldc, const float* s2,
+                           const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias, const float* row_div,
+                           hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
+bool tn_q8_enabled();   // QATVIT_TN_Q8 (default on)
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st,
                        void* out8 = nullptr, int center = 0);

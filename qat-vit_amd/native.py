@@ -41,6 +41,7 @@ SIGNATURES = {
     "qatvit_gemm_tn_codes": (c_int, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
     "qatvit_gemm_nt_dy16": (c_int, [c_void_p] * 3 + [c_int32] * 6 + [c_void_p] * 3),
     "qatvit_gemm_tn_dy16": (c_int, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p] * 5 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
+    "qatvit_gemm_tn_q8_dy16": (c_int, [c_void_p] * 3 + [c_int32, c_void_p] + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
     "qatvit_attn_padded_tokens": (c_int32, [c_int32]),
     "qatvit_attn_forward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 4),
     "qatvit_attn_forward_f16": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 9),

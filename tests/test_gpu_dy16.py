@@ -93,6 +93,35 @@ def test_wgrad_one_plane_vs_fp64(native_lib, M, N, Kw, kind):
     assert rel_l2(db.cpu().numpy(), (plane.double().sum(0) * 2.0 ** -e).cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,Kw,center,zp", [(1576, 1152, 384, 128, 131), (50432, 1536, 384, 128, 0), (50432, 1152, 384, 64, 127), (999, 384, 768, 128, 255)])
+def test_wgrad_one_plane_byte_grid_vs_fp64(native_lib, M, N, Kw, center, zp):
+    """The grid X operand as one byte per element (the forward's int8 operand, q - center): X = Q8 + center - zero_point, expanded to fp16 in registers
+    after a transposed byte read (k_gemm_tn_q8).  Exact integers either way: the result must match the fp16-plane form's reference to fp32 rounding."""
+    g = torch.Generator(device="cuda").manual_seed(N + Kw + zp)
+    dy = torch.randn(M, N, generator=g, device="cuda") * 2e-6 * torch.exp(torch.randn(M, N, generator=g, device="cuda"))
+    e = 8 - int(np.floor(np.log2(dy.abs().max().item())) + 1)
+    plane = (dy * 2.0 ** e).to(torch.float16)
+    qlo, qhi = (0, 255) if center == 128 else (0, 127)
+    q = torch.randint(qlo, qhi + 1, (M, Kw), generator=g, device="cuda")
+    q8 = (q - center).to(torch.int8)
+    sx = 0.0371
+    a_qp = torch.tensor([sx, 1.0 / sx, float(zp), 1.0], dtype=torch.float32, device="cuda")
+    dW = torch.zeros(N, Kw, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    scratch = torch.empty(native_lib.qatvit_gemm_tn_scratch_bytes(), dtype=torch.uint8, device="cuda")
+    s2 = _scalar(2.0 ** -e)
+    native.check(native_lib.qatvit_gemm_tn_q8_dy16(_ptr(plane), _ptr(q8), _ptr(a_qp), center, _ptr(dW), M, N, Kw, N, Kw, Kw, _ptr(s2), None, None, None, 0, -128, 127,
+                                                   _ptr(db), None, _ptr(scratch), scratch.numel(), P(native.stream_ptr())), "tn_q8_dy16")
+    ref = (plane.double().T @ (q - zp).double()) * (sx * 2.0 ** -e)
+    assert rel_l2(dW.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+    assert rel_l2(db.cpu().numpy(), (plane.double().sum(0) * 2.0 ** -e).cpu().numpy()) < 2e-5
+    # ... and without the split scratch (atomic accumulation), on top of a non-zero dW
+    dW2 = torch.full((N, Kw), 1e-4, device="cuda")
+    native.check(native_lib.qatvit_gemm_tn_q8_dy16(_ptr(plane), _ptr(q8), _ptr(a_qp), center, _ptr(dW2), M, N, Kw, N, Kw, Kw, _ptr(s2), None, None, None, 0, -128, 127,
+                                                   None, None, None, 0, P(native.stream_ptr())), "tn_q8_dy16")
+    assert rel_l2((dW2.double() - 1e-4).cpu().numpy(), ref.cpu().numpy()) < 1e-4      # (fp32 atomics onto 1e-4: ~1e-5)
+
+
 def _pair(seed=0, backend="qnnpack", **kw):
     torch.manual_seed(seed)
     stu = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True, **kw)
