@@ -287,6 +287,7 @@ struct AttnArgs {
     // the one-plane backward (k_attn_bwd_fused<NKT, true>): dqkv_hi is ONE fp16 plane of value * (*o16_mul), max |value| goes to o16_amax (dy16.hip)
     const float* o16_mul;
     uint32_t* o16_amax;
+    int exp;   // EXPERIMENT
 };
 
 // stage one [T][HD] slice (q, k or v of head h) into an LDS image; `which`: 0 q, 1 k, 2 v
@@ -1042,6 +1043,8 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
     float4 ckq = make_float4(1.f, 1.f, 1.f, 1.f);
     if (p.col_scale) ckq = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 16 * jd + 4 * g);
     __syncthreads();
+    if (p.exp & 4) return;
+    const int nqs_exp = (p.exp & 1) ? 0 : NKT / 2;
     const float c = q.s * q.s * p.softmax_scale, c2 = c * kLog2e;
     f32x4 dk[U][ND], dv[U][ND];
 #pragma unroll
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
 #pragma unroll
         for (int id = 0; id < ND; ++id) dk[u][id] = dv[u][id] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int qs = 0; qs < NKT / 2; ++qs) {
+    for (int qs = 0; qs < nqs_exp; ++qs) {
         const int qme = 16 * (2 * qs + vq) + r;
         const uint32_t mqb = reinterpret_cast<const uint8_t*>(sM)[min(qme, T - 1) * 8 + 2 * jd + (g >> 1)];
         // phase 1: S and dP of every owned key tile (the query-row fragments are dead afterwards: 48 registers)
@@ -1167,6 +1170,7 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
             }
         }
     }
+    if (p.exp & 2) return;
     // dK / dV: accumulators hold row = feature 16id + 4g + e, col = key 16j + r -> 8-B (4 x bf16) stores along d  (as k_attn_bwd_dkv)
     float4 ckc[ND], cvc[ND];
 #pragma unroll
@@ -1318,6 +1322,7 @@ int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B
                reinterpret_cast<__bf16*>(const_cast<void*>(O_lo)), const_cast<float*>(lse), delta, dO, reinterpret_cast<__bf16*>(dqkv_hi),
                reinterpret_cast<__bf16*>(dqkv_lo), col_scale, nullptr, nullptr, nullptr,
                reinterpret_cast<uint8_t*>(const_cast<void*>(codes)), reinterpret_cast<uint8_t*>(const_cast<void*>(cmask)), o16_mul, o16_amax};
+    a.exp = getenv("QATVIT_ATTN_EXP") ? atoi(getenv("QATVIT_ATTN_EXP")) : 0;
     // one fused kernel (dK, dV and dQ from one sweep) where its shape holds: head_dim 64, 33..224 tokens, saved codes; QATVIT_ATTN_BWD_FUSED=0: the
     // two-kernel form (k_attn_bwd_dq + k_attn_bwd_dkv) everything else takes
     int nkt;

@@ -84,6 +84,19 @@ __global__ __launch_bounds__(256) void k_f16int_to_bf16int(uint4* __restrict__ p
     }
 }
 
+// plane[i] = q8[i] + center - zero point as bf16 (|.| <= 255: exact): the pair-form weight gradient's X operand rebuilt from the forward's int8 plane
+__global__ __launch_bounds__(256) void k_q8_to_bf16int(const uint2* __restrict__ q8, const float* __restrict__ qp, int center, uint4* __restrict__ out, int64_t n8) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const float off = (float)center - qp[2];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 b = q8[i];
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)((float)(int8_t)(((k < 4 ? b.x : b.y) >> (8 * (k & 3))) & 0xffu) + off);
+        out[i] = __builtin_bit_cast(uint4, o);
+    }
+}
+
 static int grid_for(int64_t n8) {
     const int64_t b = (n8 + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -100,6 +113,11 @@ int launch_dy16_end(uint32_t* state, int nslots, int check_overflow, hipStream_t
 int launch_absmax_bf16(const void* hi, int64_t n, uint32_t* amax, hipStream_t st) {
     if (n % 8 != 0) { set_error("absmax_bf16: n %% 8 != 0"); return 1; }
     k_absmax_bf16<<<grid_for(n / 8), 256, 0, st>>>(reinterpret_cast<const uint4*>(hi), n / 8, amax);
+    return 0;
+}
+int launch_q8_to_bf16int(const void* q8, const float* qp, int center, void* plane, int64_t n, hipStream_t st) {
+    if (n % 8 != 0) { set_error("q8_to_bf16int: n %% 8 != 0"); return 1; }
+    k_q8_to_bf16int<<<grid_for(n / 8), 256, 0, st>>>(reinterpret_cast<const uint2*>(q8), qp, center, reinterpret_cast<uint4*>(plane), n / 8);
     return 0;
 }
 int launch_f16int_to_bf16int(void* plane, int64_t n, hipStream_t st) {

@@ -225,8 +225,9 @@ __global__ __launch_bounds__(256) void k_ln_apply_quant(const float* __restrict_
         o[2] = (__bf16)fqi((v.z - mu) * rs * g.z + b.z, q, qmin, qmax);
         o[3] = (__bf16)fqi((v.w - mu) * rs * g.w + b.w, q, qmin, qmax);
         // out_f16 (uniform): the same integers as fp16 bit patterns - the X operand of the one-plane weight gradient (|q - zp| <= 255: exact either way)
-        if (out_f16) *reinterpret_cast<uint2*>(out + row * D + c) = make_uint2(pk_f16((float)o[0], (float)o[1]), pk_f16((float)o[2], (float)o[3]));
-        else *reinterpret_cast<bf16x4*>(out + row * D + c) = o;
+        // out == nullptr (uniform): nobody reads the 2-byte plane - the forward GEMM and the one-plane weight gradient both take out8
+        if (out && out_f16) *reinterpret_cast<uint2*>(out + row * D + c) = make_uint2(pk_f16((float)o[0], (float)o[1]), pk_f16((float)o[2], (float)o[3]));
+        else if (out) *reinterpret_cast<bf16x4*>(out + row * D + c) = o;
         if (out8) {
             const float sh = q.zp - (float)center;
             char4 o8 = make_char4((signed char)((float)o[0] + sh), (signed char)((float)o[1] + sh), (signed char)((float)o[2] + sh),

@@ -363,9 +363,13 @@ struct Ctx {
     int ln_apply(const float* xrow, const float* mean, const float* rstd, const float* gamma, const float* beta, int ai, void* out16, void* out8) const {
         const bool lt = late_kind(ai);
         const QpLate L = lt ? late(ai) : QpLate{};
-        return launch_ln_apply_quant(xrow, mean, rstd, gamma, beta, act_qp(ai), c.act_qmin, c.act_qmax, out16, d.M, d.D, st, use_i8() ? out8 : nullptr, center(),
-                                     (flags & QATVIT_FWD_X16) != 0, lt ? &L : nullptr);
+        // a QATVIT_FWD_X16 forward whose backward takes the byte plane (k_gemm_tn_q8) writes no 2-byte plane at all: the forward GEMM reads out8 too
+        const bool x16 = (flags & QATVIT_FWD_X16) != 0;
+        return launch_ln_apply_quant(xrow, mean, rstd, gamma, beta, act_qp(ai), c.act_qmin, c.act_qmax, x16 && x_plane_from_q8() ? nullptr : out16, d.M, d.D, st,
+                                     use_i8() ? out8 : nullptr, center(), x16, lt ? &L : nullptr);
     }
+    // the qkv / fc1 weight gradients of the one-plane backward read the int8 plane of the LayerNorm outputs (q - center) instead of the fp16 one
+    bool x_plane_from_q8() const { return use_i8() && tn_q8_enabled() && d.D % 384 == 0; }
     void qparams_act(int ai) const {
         const qatvit_fq& f = act[ai];
         launch_qparams(act_stats(ai), f.min_val, f.max_val, f.scale, f.zero_point, f.observer_on, f.fake_quant_on, c.averaging_const,
@@ -784,7 +788,7 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 const qatvit_fq& f = x.wfq[wi];
                 ProfScope ps(x.prof, (wi == w_proj || Xc) ? 6 : 3, 2.0 * M * N * K, st);
                 const float* rdiv = c.w_per_channel ? f.scale : nullptr;
-                if (X8 && tn_q8_enabled() && K % 384 == 0)
+                if (X8 && x.x_plane_from_q8())
                     return launch_gemm_tn_q8_dy16(P16, X8, s_x, x.center(), dW, M, N, K, N, K, K, x.dy_inv(i, k), x.prm(wparam(d, wi)), f.scale, f.zero_point,
                                                   c.w_per_channel, c.w_qmin, c.w_qmax, db, rdiv, st, x.at<float>(p.tn_scratch), kTnScratchBytes);
                 if (Xc)
@@ -1071,6 +1075,11 @@ int qatvit_student_dy16_to_pair(const qatvit_cfg* cfg, void* workspace, void* st
     Ctx x{*cfg, dims_of(*cfg), Plan(), reinterpret_cast<char*>(workspace), nullptr, nullptr, nullptr, (hipStream_t)stream, nullptr};
     if (make_plan(*cfg, &x.p)) return 1;
     for (int i = 0; i < x.d.depth; ++i) {
+        if (x.x_plane_from_q8()) {   // the X16 forward wrote the byte planes only: q - zp = q8 + center - zp as bf16 integers
+            if (launch_q8_to_bf16int(x.blk<void>(x.p.h1q8, i), x.act_qp(x.aidx(i, AB_N1)), x.center(), x.blk<void>(x.p.h1q, i), x.d.M * x.d.D, x.st)) return 1;
+            if (launch_q8_to_bf16int(x.blk<void>(x.p.h2q8, i), x.act_qp(x.aidx(i, AB_N2)), x.center(), x.blk<void>(x.p.h2q, i), x.d.M * x.d.D, x.st)) return 1;
+            continue;
+        }
         if (launch_f16int_to_bf16int(x.blk<void>(x.p.h1q, i), x.d.M * x.d.D, x.st)) return 1;
         if (launch_f16int_to_bf16int(x.blk<void>(x.p.h2q, i), x.d.M * x.d.D, x.st)) return 1;
     }

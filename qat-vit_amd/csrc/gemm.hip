@@ -1846,8 +1846,11 @@ __global__ __launch_bounds__(512) void k_gemm_tn_q8(const TNArgs p) {
         const float c = (float)p.q8_center - p.s1[2] - 1152.0f;     // X = (1024 + u) + c, u = q8 + 128: an integer of magnitude < 2048, exact
         cadd[0] = (_Float16)c; cadd[1] = (_Float16)c;
     } else {
+        // (one table load per thread, sixteen LDS stores: entry tid & 255 into banks 16 (tid >> 8) .. + 15 - not sixteen dependent round trips)
         uint32_t* tab = reinterpret_cast<uint32_t*>(smem + TAB);
-        for (int i = tid; i < 256 * 32; i += 512) tab[i] = p.lutQ[i >> 5] & 0xffffu;
+        const uint32_t ent = p.lutQ[tid & 255] & 0xffffu;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tab[(tid & 255) * 32 + 16 * (tid >> 8) + k] = ent;
     }
     const uint32_t tab_lane = (uint32_t)(TAB + (lane & 31) * 4);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

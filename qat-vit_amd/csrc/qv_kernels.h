@@ -228,6 +228,7 @@ inline int64_t dy16_state_bytes(int nslots) { return 4ll * (kDyHdrWords + (int64
 int launch_dy16_begin(uint32_t* state, int nslots, const float* dlogits, int n_dlogits, hipStream_t st);   // dlogits == nullptr: no rescaling
 int launch_dy16_end(uint32_t* state, int nslots, int check_overflow, hipStream_t st);
 int launch_absmax_bf16(const void* hi, int64_t n, uint32_t* amax, hipStream_t st);      // calibration: max |hi part| of a bf16 (hi, lo) pair, n % 8 == 0
+int launch_q8_to_bf16int(const void* q8, const float* qp, int center, void* plane, int64_t n, hipStream_t st);
 int launch_f16int_to_bf16int(void* plane, int64_t n, hipStream_t st);                  // fallback: grid integers stored as fp16 -> bf16, in place, n % 8 == 0
 
 // ---- attn.hip
