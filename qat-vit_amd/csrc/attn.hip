@@ -287,7 +287,6 @@ struct AttnArgs {
     // the one-plane backward (k_attn_bwd_fused<NKT, true>): dqkv_hi is ONE fp16 plane of value * (*o16_mul), max |value| goes to o16_amax (dy16.hip)
     const float* o16_mul;
     uint32_t* o16_amax;
-    int exp;   // EXPERIMENT
 };
 
 // stage one [T][HD] slice (q, k or v of head h) into an LDS image; `which`: 0 q, 1 k, 2 v
@@ -905,14 +904,17 @@ __global__ __launch_bounds__(NWV * 64) void k_attn_bwd_dkv(const AttnArgs p) {
 // image and of the dS image: ds_read_b64_tr_b16, the same k-slot map on both sides), finish it over all keys and store it at once.  delta
 // (row sums of dO . O) is formed while dO is staged.  head_dim 64, eight waves, saved codes; everything else takes the two-kernel path.
 // LDS: images of Q, K (integers), dO hi / lo (4 x 28 KiB) + dS hi / lo (2 x 17.5 KiB) + the per-row softmax constants = 149 KiB, one workgroup per CU.
-// transposed fragment of the dS image ([key][32 queries] bf16, rows kSRow bytes apart: 80, not 64 - sixteen 64-byte rows would put rows r and
-// r + 4 in the same banks, a 4-way conflict on every read and write; at 80 the sixteen 32-byte pieces of one access cover every bank twice)
-constexpr int kSRow = 80;
-__device__ inline bf16x8 tr_frag_ds(const char* img, int tokA, int tokB, int col0, int lane) {
+// The dS image of a query pair: per 16-query tile vq its own [key][16 queries] bf16 plane with 32-byte rows, the four 8-byte slots of a row XORed with
+// (key >> 2) & 3.  A transposed read takes, per 32-lane half, eight consecutive rows = 256 contiguous bytes (every bank once); a wave's store - 16 keys x
+// one slot per 16-lane group - lands on 16 distinct bank pairs.  (Round 3's [key][32 queries] image with 80-byte rows: rows r and r + 3 shared four banks
+// on every transposed read, 26 % of this kernel's LDS cycles were conflict cycles.)
+constexpr int kSRow = 32;
+__device__ inline bf16x8 tr_frag_ds(const char* img_vq, int tokA, int tokB, int lane) {
     const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (tokA + 4 * g + q) * kSRow + col0 * 2 + pp * 8));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (tokB + 4 * g + q) * kSRow + col0 * 2 + pp * 8));
+    // rows tokA + 4g + q, tokA a multiple of 16: (row >> 2) & 3 == g
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img_vq + (tokA + 4 * g + q) * kSRow + ((pp ^ g) << 3)));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img_vq + (tokB + 4 * g + q) * kSRow + ((pp ^ g) << 3)));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
@@ -923,7 +925,7 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
     float mul16 = 1.f, am16 = 0.f;
     if constexpr (O16) mul16 = *p.o16_mul;
     constexpr int U = (NKT + NWV - 1) / NWV;   // key tiles per wave
-    constexpr int IMG = NKT * 16 * HD * 2, SIMG = NKT * 16 * kSRow;
+    constexpr int IMG = NKT * 16 * HD * 2, SVQ = NKT * 16 * kSRow, SIMG = 2 * SVQ;   // (SVQ: one 16-query tile's plane)
     constexpr int KK = HD / 32, ND = HD / 16;
     static_assert(2 * ND == NWV, "one dQ^T tile (16 features x 16 queries of a query pair) per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -931,11 +933,12 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
     char* sDh = smem + IMG;
     char* sDl = smem + 2 * IMG;
     char* sKt = smem + 3 * IMG;
-    char* sSh = smem + 4 * IMG;     // [key][32 queries] image of the current query pair's dS, hi / lo
+    char* sSh = smem + 4 * IMG;     // [query tile of the pair][key][16 queries] image of the current query pair's dS, hi / lo
     char* sSl = sSh + SIMG;
     float* sLse = reinterpret_cast<float*>(sSl + SIMG);
     float* sDlt = sLse + NKT * 16;
     uint2* sM = reinterpret_cast<uint2*>(sDlt + NKT * 16);   // STE mask bits of this head's q | k | v slices: [3][T] rows of HD / 8 = 8 bytes
+    float* sCs = reinterpret_cast<float*>(sM + 3 * NKT * 16);   // this head's 3 x 64 per-column scales (q | k | v), 1.0 without col_scale
     const AQP q = make_aqp(p.qp, p.qmin, p.qmax);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, D = p.D, ld = 3 * D;
@@ -992,6 +995,7 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) mrow[k] = reinterpret_cast<const uint2*>(mbase)[min((int)threadIdx.x + k * NWV * 64, 3 * T - 1)];
     if (threadIdx.x < NKT * 16) sLse[threadIdx.x] = lse_i;
+    if (threadIdx.x < 3 * HD) sCs[threadIdx.x] = p.col_scale ? p.col_scale[(threadIdx.x / HD) * D + h * HD + (threadIdx.x % HD)] : 1.f;
     for (int i = threadIdx.x; i < 2 * SIMG / 16; i += NWV * 64) reinterpret_cast<uint4*>(sSh)[i] = make_uint4(0u, 0u, 0u, 0u);   // key tiles nobody owns stay zero
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -1043,8 +1047,6 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
     float4 ckq = make_float4(1.f, 1.f, 1.f, 1.f);
     if (p.col_scale) ckq = *reinterpret_cast<const float4*>(p.col_scale + h * HD + 16 * jd + 4 * g);
     __syncthreads();
-    if (p.exp & 4) return;
-    const int nqs_exp = (p.exp & 1) ? 0 : NKT / 2;
     const float c = q.s * q.s * p.softmax_scale, c2 = c * kLog2e;
     f32x4 dk[U][ND], dv[U][ND];
 #pragma unroll
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
 #pragma unroll
         for (int id = 0; id < ND; ++id) dk[u][id] = dv[u][id] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int qs = 0; qs < nqs_exp; ++qs) {
+    for (int qs = 0; qs < NKT / 2; ++qs) {
         const int qme = 16 * (2 * qs + vq) + r;
         const uint32_t mqb = reinterpret_cast<const uint8_t*>(sM)[min(qme, T - 1) * 8 + 2 * jd + (g >> 1)];
         // phase 1: S and dP of every owned key tile (the query-row fragments are dead afterwards: 48 registers)
@@ -1127,12 +1129,11 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
             if (has[u]) {
                 // this lane: key 16 jt + r, queries 4g .. 4g+3 of tile v in elements 4v .. 4v+3 -> 8-byte runs of the [key][32 queries] image
                 const uint4 wh = __builtin_bit_cast(uint4, sh), wl = __builtin_bit_cast(uint4, sl2);
-                char* const row_h = sSh + (16 * jt[u] + r) * kSRow + 8 * g;
-                char* const row_l = sSl + (16 * jt[u] + r) * kSRow + 8 * g;
-                *reinterpret_cast<uint2*>(row_h) = make_uint2(wh.x, wh.y);
-                *reinterpret_cast<uint2*>(row_h + 32) = make_uint2(wh.z, wh.w);
-                *reinterpret_cast<uint2*>(row_l) = make_uint2(wl.x, wl.y);
-                *reinterpret_cast<uint2*>(row_l + 32) = make_uint2(wl.z, wl.w);
+                const int so = (16 * jt[u] + r) * kSRow + ((g ^ ((r >> 2) & 3)) << 3);   // slot g of the key's row, XORed with (key >> 2) & 3
+                *reinterpret_cast<uint2*>(sSh + so) = make_uint2(wh.x, wh.y);
+                *reinterpret_cast<uint2*>(sSh + SVQ + so) = make_uint2(wh.z, wh.w);
+                *reinterpret_cast<uint2*>(sSl + so) = make_uint2(wl.x, wl.y);
+                *reinterpret_cast<uint2*>(sSl + SVQ + so) = make_uint2(wl.z, wl.w);
 #pragma unroll
                 for (int id = 0; id < ND; ++id) {
                     dv[u][id] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dth[id], ph, dv[u][id], 0, 0, 0);
@@ -1148,8 +1149,8 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < NKT / 2; ++ks) {
             const bf16x8 kt = tr_frag2<HD>(sKt, 32 * ks, 32 * ks + 16, 16 * jd, lane);   // A: row = feature, k-slots = keys
-            const bf16x8 bh = tr_frag_ds(sSh, 32 * ks, 32 * ks + 16, 16 * vq, lane);     // B: col = query, the same k-slots
-            const bf16x8 bl = tr_frag_ds(sSl, 32 * ks, 32 * ks + 16, 16 * vq, lane);
+            const bf16x8 bh = tr_frag_ds(sSh + vq * SVQ, 32 * ks, 32 * ks + 16, lane);     // B: col = query, the same k-slots
+            const bf16x8 bl = tr_frag_ds(sSl + vq * SVQ, 32 * ks, 32 * ks + 16, lane);
             dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, bh, dq, 0, 0, 0);
             dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, bl, dq1, 0, 0, 0);
         }
@@ -1170,16 +1171,12 @@ __global__ __launch_bounds__(8 * 64) void k_attn_bwd_fused(const AttnArgs p) {
             }
         }
     }
-    if (p.exp & 2) return;
     // dK / dV: accumulators hold row = feature 16id + 4g + e, col = key 16j + r -> 8-B (4 x bf16) stores along d  (as k_attn_bwd_dkv)
-    float4 ckc[ND], cvc[ND];
+    float4 ckc[ND], cvc[ND];   // (from the LDS copy the prologue made: a global load here is a full round trip with nothing to hide it)
 #pragma unroll
     for (int id = 0; id < ND; ++id) {
-        ckc[id] = cvc[id] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (p.col_scale) {
-            ckc[id] = *reinterpret_cast<const float4*>(p.col_scale + D + h * HD + 16 * id + 4 * g);
-            cvc[id] = *reinterpret_cast<const float4*>(p.col_scale + 2 * D + h * HD + 16 * id + 4 * g);
-        }
+        ckc[id] = *reinterpret_cast<const float4*>(sCs + HD + 16 * id + 4 * g);
+        cvc[id] = *reinterpret_cast<const float4*>(sCs + 2 * HD + 16 * id + 4 * g);
     }
     // Through a wave-private LDS tile ([key][64 features] bf16, rows 144 B apart: 16-byte aligned, 2-way conflicts at most) so that the global
     // stores are 16 bytes per lane in whole 128-byte row segments - straight from the accumulator layout they would be 8-byte pieces, 32 bytes
@@ -1322,13 +1319,12 @@ int launch_attn_bwd(const float* qkv, const float* qp, int qmin, int qmax, int B
                reinterpret_cast<__bf16*>(const_cast<void*>(O_lo)), const_cast<float*>(lse), delta, dO, reinterpret_cast<__bf16*>(dqkv_hi),
                reinterpret_cast<__bf16*>(dqkv_lo), col_scale, nullptr, nullptr, nullptr,
                reinterpret_cast<uint8_t*>(const_cast<void*>(codes)), reinterpret_cast<uint8_t*>(const_cast<void*>(cmask)), o16_mul, o16_amax};
-    a.exp = getenv("QATVIT_ATTN_EXP") ? atoi(getenv("QATVIT_ATTN_EXP")) : 0;
     // one fused kernel (dK, dV and dQ from one sweep) where its shape holds: head_dim 64, 33..224 tokens, saved codes; QATVIT_ATTN_BWD_FUSED=0: the
     // two-kernel form (k_attn_bwd_dq + k_attn_bwd_dkv) everything else takes
     int nkt;
     if (check_shape(T, D, H, &nkt)) return 1;
     if (attn_bwd_is_fused(T, H, D, codes != nullptr)) {
-        constexpr int kLds = 4 * 14 * 16 * 64 * 2 + 2 * 14 * 16 * kSRow + 2 * 14 * 16 * 4 + 3 * 14 * 16 * 8;   // 157,696 B
+        constexpr int kLds = 4 * 14 * 16 * 64 * 2 + 2 * 2 * 14 * 16 * kSRow + 2 * 14 * 16 * 4 + 3 * 14 * 16 * 8 + 3 * 64 * 4;   // 151,296 B
         static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_fused<14>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds),
                             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_fused<14, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds), true);
         (void)once;
