@@ -337,8 +337,10 @@ def main():
              7: "k_i8_strip<3> A-stationary int8 strip kernel, statistics-only pass (qkv and fc1 first passes; csrc/i8strip.hip)",
              8: "k_i8_strip<4> A-stationary int8 strip kernel, fc1 code pass (gelu(fq(.)) as uint8 codes + STE mask bits + two 256-entry tables)",
              9: "k_i8_strip<7> A-stationary int8 strip kernel, qkv code pass (uint8 codes + STE mask bits in the attention layout)",
-             3: "k_gemm_tn<1,..> + k_tn_reduce: weight gradients with grid X (qkv / fc1 / patch-embed; dY one fp16 plane: 1 pass - or a bf16 pair: 2)",
-             6: "k_gemm_tn + k_tn_reduce: weight gradients with float X (proj: X fp16; fc2: X as codes expanded in the kernel; 1 pass - 3 bf16 passes with QATVIT_DY16=0)"}
+             3: "k_gemm_tn_q8<0> (X = the forward's int8 plane, expanded in registers; k_gemm_tn<1,..> on an fp16 plane with QATVIT_TN_Q8=0) + k_tn_reduce: weight "
+                "gradients with grid X (qkv / fc1 / patch-embed; dY one fp16 plane: 1 pass - or a bf16 pair: 2)",
+             6: "k_gemm_tn / k_gemm_tn_q8<1> + k_tn_reduce: weight gradients with float X (proj: X fp16; fc2: X as codes through a bank-replicated table; 1 pass - "
+                "3 bf16 passes with QATVIT_DY16=0)"}
     SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_plain", 7: "nt_int8_stats_pass",
              8: "nt_int8_fc1_store_pass", 9: "nt_int8_qkv_code_pass", 3: "tn_grid_x", 6: "tn_split_x"}
     prof = {}
@@ -364,6 +366,7 @@ def main():
         # weights once per launch; split-reduction partials, mask bit planes (1/32 of an fp32 plane) and re-reads are NOT counted
         dy = 2 if eng.dy16 else 4                            # bytes per element of a backward gradient operand: one fp16 plane, or a bf16 (hi, lo) pair
         xf = 2 if eng.dy16 else 4                            # ... of the float X operand of the proj weight gradient (fp16 / bf16 pair); fc2's X is codes either way
+        xg = 1 if (eng.dy16 and os.environ.get("QATVIT_TN_Q8", "1") != "0" and Dm % 384 == 0) else 2   # ... of the grid X operand of the qkv / fc1 weight gradients: int8 plane, or 16-bit integers
         lnb = 3 * Mr * Dm * 4 + Mr * Dm * dy                 # fused LayerNorm backward: x, dx_in read; dx_out and the masked gradient for the next branch written
         step_bytes = {
             1: dep * ((Mr * Dm * 4 + Dm * Dm * 2 + Mr * Dm * 4)                                  # proj forward: fp16 pair in, fp32 out
@@ -376,7 +379,7 @@ def main():
             8: dep * (Mr * Dm + Hd * Dm + Mr * Hd * (1 if codes else 4) + (Mr * Hd // 8 if bits else Mr * Hd * 2) + (0 if fc2w else Mr * Hd * 4)),   # fc1 storing pass: codes (or fp16 pair) + mask bits (or uint16 code) [+ bf16 pair]
             9: dep * (Mr * Dm + 3 * Dm * Dm + Mr * 3 * Dm * 9 // 8),                            # qkv code pass: 1 B + 1 bit per element out
             3: (Mpe * Dm * 4 + Mpe * Kpe * 2 + Dm * Kpe * 4)
-               + dep * ((Mr * 3 * Dm * dy + Mr * Dm * 2 + 3 * Dm * Dm * 4) + (Mr * Hd * dy + Mr * Dm * 2 + Hd * Dm * 4)),   # qkv, fc1 wgrad
+               + dep * ((Mr * 3 * Dm * dy + Mr * Dm * xg + 3 * Dm * Dm * 4) + (Mr * Hd * dy + Mr * Dm * xg + Hd * Dm * 4)),   # qkv, fc1 wgrad
             6: dep * ((Mr * Dm * dy + Mr * Dm * xf + Dm * Dm * 4) + (Mr * Dm * dy + Mr * Hd * (1 if fc2w else 4) + Hd * Dm * 4)),   # proj, fc2 wgrad (Q as codes)
         }
         gemms = {}

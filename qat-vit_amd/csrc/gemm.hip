@@ -170,8 +170,12 @@ __device__ const ZerosTab kZeros{};
 __device__ unsigned long long g_nt_stamps[2 * 8 * 16];   // wave; read back with qatvit_debug_nt_stamps (tools/stamp_nt.py).  The shipped library has none.
 #define QV_NT_STAMP(PM_, k_)                                                                                                    \
     do {                                                                                                                        \
-        if ((PM_) == QV_NT_EXPERIMENTS && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0)                    \
+        if ((PM_) == QV_NT_EXPERIMENTS && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0) {                  \
             g_nt_stamps[((blockIdx.x ? 1 : 0) * 8 + (threadIdx.x >> 6)) * 16 + (k_)] = __builtin_amdgcn_s_memtime();            \
+            /* the constant 100 MHz counter next to stamps 1 and 3: in-kernel clock of the k-loop = d(memtime) / d(memrealtime) x 100 MHz */ \
+            if ((k_) == 1) g_nt_stamps[((blockIdx.x ? 1 : 0) * 8 + (threadIdx.x >> 6)) * 16 + 14] = __builtin_amdgcn_s_memrealtime(); \
+            if ((k_) == 3) g_nt_stamps[((blockIdx.x ? 1 : 0) * 8 + (threadIdx.x >> 6)) * 16 + 15] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                                       \
     } while (0)
 #else
 #define QV_NT_STAMP(PM_, k_)
@@ -1920,6 +1924,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_q8(const TNArgs p) {
         // (every LDS read of the stage this step's DMA overwrites has returned: they were issued a substep of MFMAs ago.  MODE 1: the first barrier publishes the table)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (s + NSTAGE - 1 < nsteps) issue(s + NSTAGE - 1);
+        if (s == 1) QV_NT_STAMP(100 + MODE, 1);
         const char* st = smem + (s % NSTAGE) * STAGE;
         load1(A, st, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1943,6 +1948,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_q8(const TNArgs p) {
         x2(B);
     }
     mm(B, 0, TM);
+    QV_NT_STAMP(100 + MODE, 3);
     // ---- epilogue (k_gemm_tn's: raw accumulators to the split scratch, or scale / STE mask / atomics)
     const float bscale = p.s2 ? *p.s2 : 1.f;
     const float alpha = (p.s1 ? *p.s1 : 1.f) * bscale;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""s_memtime stamps of the mode-8 (dgrad + fused LayerNorm backward) or mode-9 (fc2 dgrad + GELU') NT kernel inside the real C2 step at batch 256.
-Needs a development build of the library (-DQV_NT_EXPERIMENTS=8 or 9: tools/ab_lib.sh describes how such a build is linked); the shipped library has
+"""s_memtime stamps of the mode-8 / 18 (dgrad + fused LayerNorm backward), mode-9 / 19 (fc2 dgrad + GELU') NT kernel or of k_gemm_tn_q8 (100 / 101) inside the
+real C2 step at batch 256, and the in-kernel clock of the k-loop (STAMP_STEPS=60: after a second of back-to-back steps).
+Needs a development build of the library (-DQV_NT_EXPERIMENTS=8, 9, 18, 19, 100 or 101: tools/ab_lib.sh describes how such a build is linked); the shipped library has
 no stamps.  usage: python3 tools/stamp_nt.py   (prints, for workgroups 0 and 100, ticks since entry per phase for every wave)"""
 import ctypes
 import os
@@ -10,7 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.argv = ["bench.py", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-rates", "--no-extras", "--no-kernel-legs"]
+sys.argv = ["bench.py", "--steps", os.environ.get("STAMP_STEPS", "3"), "--warmup", "2", "--no-cpu-baseline", "--no-kernel-rates", "--no-extras", "--no-kernel-legs"]
 import runpy  # noqa: E402
 
 try:
@@ -31,3 +32,6 @@ for b in range(2):
     for w in range(8):
         t = [buf[(b * 8 + w) * 16 + k] for k in range(14)]
         print(f"block {(0, 100)[b]} wave {w}: " + "  ".join(f"{n}={t[k] - t[0]}" for k, n in enumerate(names) if t[k] and k))
+        r1, r3 = buf[(b * 8 + w) * 16 + 14], buf[(b * 8 + w) * 16 + 15]
+        if r3 > r1 and t[3] > t[1]:   # the constant 100 MHz counter next to stamps 1 and 3 (MI355X_MICROARCH.md, DVFS give-back item 6)
+            print(f"    k-loop: {t[3] - t[1]} shader clocks in {(r3 - r1) * 10} ns -> in-kernel clock {(t[3] - t[1]) / (r3 - r1) * 0.1:.2f} GHz")
