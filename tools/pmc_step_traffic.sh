@@ -34,6 +34,8 @@ res = {"kernels": out}
 found = 0
 for kind, modes in (("4", (18, 8)), ("5", (19, 9, 5))):   # (18 / 19: the one-plane forms of modes 8 / 9)
     names = [k for k in out if pm_of(k) in modes]
+    if kind == "5" and any(k.startswith("qv::k_f16_strip_gelu_bwd") for k in out):   # ViT-S: the fc2 dgrad + GELU' runs in the A-stationary strip kernel (f16strip.hip)
+        names = [k for k in out if k.startswith("qv::k_f16_strip_gelu_bwd")]
     if names:
         name = max(names, key=lambda k: out[k]["launches"])
         o = out[name]
@@ -43,6 +45,12 @@ for kind, modes in (("4", (18, 8)), ("5", (19, 9, 5))):   # (18 / 19: the one-pl
                              "separate rocprofv3 --pmc passes (tools/pmc_step_traffic.sh)"}
 if not found:
     print("no k_gemm_nt launch with epilogue mode 8 / 9 found"); raise SystemExit(1)
+for kind, prefix in (("3", "qv::k_gemm_tn_q8<0"), ("6", "qv::k_gemm_tn_q8<1")):   # the byte-X weight gradients (their k_tn_reduce launches are separate rows of "kernels")
+    names = [k for k in out if k.startswith(prefix)]
+    if names:
+        o = out[names[0]]
+        res[kind] = {"bytes_per_launch": (o["fetch_MB"] + o["write_MB"]) * 1e6, "fetch_MB": o["fetch_MB"], "write_MB": o["write_MB"],
+                     "note": f"mean FETCH_SIZE (x2) + WRITE_SIZE per launch of {names[0]} over {o['launches']} launches (the partial tiles included, k_tn_reduce not)"}
 json.dump(res, open("gpurun_out/pmc_step/summary.json", "w"), indent=1)
 for k, o in sorted(out.items(), key=lambda kv: -(kv[1]["fetch_MB"] + kv[1]["write_MB"]) * kv[1]["launches"])[:24]:
     print(f'{o["launches"]:5d} x  fetch {o["fetch_MB"]:8.1f} MB  write {o["write_MB"]:8.1f} MB   {k[:100]}')
