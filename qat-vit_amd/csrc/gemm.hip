@@ -1774,8 +1774,8 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, i
 }
 
 // ---------------------------------------------------------------------------- TN, one fp16 P plane x a BYTE Q operand (the one-plane backward)
-// The weight-gradient kernels are bound by the L2 -> LDS fill of their workgroup (a 128 x 384 tile takes 256 B of P and 768 B of fp16 Q per token:
-// 2.4 MB per workgroup, ~42 GB/s per CU, against 24 us of MFMA).  Both X operands of the big weight gradients exist as ONE byte per element:
+// A 128 x 384 tile takes 256 B of P and 768 B of fp16 Q per token through the L2 -> LDS fill of its workgroup, and the table form of round 3 expanded its
+// codes through an fp16 LDS image behind a second barrier per step.  Both X operands of the big weight gradients exist as ONE byte per element:
 //   MODE 0: LayerNorm output on its grid, q - center as int8 (the forward's int8-MFMA operand): X = q8 + (center - zp), exact in fp16;
 //   MODE 1: gelu(fq(fc1 output)) as uint8 codes + a 256-entry table (fp16 hi halves), as fc2's forward reads it.
 // The byte tile lands by LDS-DMA as it lies in memory ([64 tokens][384 B], 16-B chunks XOR-swizzled), `ds_read_b64_tr_b8` hands every lane the 8
@@ -1783,6 +1783,7 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TNArgs p, int splits, i
 // 0x80: 1024 + u as fp16, minus 1152 - (center - zp), two packed adds per four elements), MODE 1 by eight gathers from a table replicated over the
 // 32 banks (entry e for lane l at dword e * 32 + (l & 31): conflict-free whatever the codes are).  No expansion pass through LDS, no second barrier,
 // 640 B per token instead of 1024.  64-token stages; WM x WNK waves as in k_gemm_tn (accumulator layout shared with k_tn_reduce).
+// What paces the loop (stamps): MFMA issue - 74 % utilisation at a measured 2.24 GHz; 84 % of the launch remains with no global traffic at all.
 __device__ inline int tn8_sw(int row) { return (row >> 1) & 7; }   // 384-B rows: rows r, r + 1 differ by 8 chunks mod 16 already; the XOR spreads the 8 row pairs of a 16-row half
 __device__ inline uint2 tr8_frag(const char* img, int row0, int chunk, int lane) {
     // block of 8 rows x 16 byte columns per 16-lane group: lane 2q + p supplies the address of row q, bytes 8p .. 8p + 7; lane i receives column i, row q in byte q
