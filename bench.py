@@ -337,10 +337,10 @@ def main():
              7: "k_i8_strip<3> A-stationary int8 strip kernel, statistics-only pass (qkv and fc1 first passes; csrc/i8strip.hip)",
              8: "k_i8_strip<4> A-stationary int8 strip kernel, fc1 code pass (gelu(fq(.)) as uint8 codes + STE mask bits + two 256-entry tables)",
              9: "k_i8_strip<7> A-stationary int8 strip kernel, qkv code pass (uint8 codes + STE mask bits in the attention layout)",
-             3: "k_gemm_tn_q8<0> (X = the forward's int8 plane, expanded in registers; k_gemm_tn<1,..> on an fp16 plane with QATVIT_TN_Q8=0) + k_tn_reduce: weight "
-                "gradients with grid X (qkv / fc1 / patch-embed; dY one fp16 plane: 1 pass - or a bf16 pair: 2)",
-             6: "k_gemm_tn / k_gemm_tn_q8<1> + k_tn_reduce: weight gradients with float X (proj: X fp16; fc2: X as codes through a bank-replicated table; 1 pass - "
-                "3 bf16 passes with QATVIT_DY16=0)"}
+             3: "k_tn_stream<0> + fix-up: ALL qkv / fc1 weight gradients of the backward call in one persistent stream-K launch (X = the forward's int8 plane, expanded in "
+                "registers; QATVIT_TN_STREAM=0: k_gemm_tn_q8<0> + k_tn_reduce per GEMM), + the patch-embedding weight gradient (k_gemm_tn, bf16 pair)",
+             6: "k_tn_stream<1> / <2> + fix-ups: all fc2 (X = codes through a bank-replicated table) / proj (X fp16) weight gradients of the backward call, one persistent "
+                "stream-K launch each (QATVIT_TN_STREAM=0: one launch + k_tn_reduce per GEMM; QATVIT_DY16=0: 3 bf16 passes)"}
     SHORT = {1: "nt_split_plain", 4: "nt_split_dgrad_fused_layernorm_bwd", 5: "nt_split_dgrad_fused_gelu_bwd", 2: "nt_int8_plain", 7: "nt_int8_stats_pass",
              8: "nt_int8_fc1_store_pass", 9: "nt_int8_qkv_code_pass", 3: "tn_grid_x", 6: "tn_split_x"}
     prof = {}
@@ -404,7 +404,7 @@ def main():
             gemms[7]["note"] = "fc1 and qkv run twice (statistics-only pass + storing pass): the statistics passes count as time, not as algorithmic work"
         for k in (3, 6):
             if k in gemms:
-                gemms[k]["note"] = "the bracket holds k_gemm_tn and its k_tn_reduce (ordered second-phase reduction of the split partials)"
+                gemms[k]["note"] = "the bracket holds the GEMM launch and its fix-up / reduction launch (ordered summation of the split tiles)"
         dom = max(gemms, key=lambda k: gemms[k]["ms_per_step"])          # the dominant kernel of the step = the GEMM class with the largest time
         g = gemms[dom]
         hbm_bound = g.get("roofline_bound") == "hbm"

@@ -192,6 +192,20 @@ int qatvit_gemm_tn_q8_dy16(const void* P16, const void* Q8, const float* a_qp, i
                            int32_t ldc, const float* s2, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel, int32_t w_qmin,
                            int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes, void* stream);
 
+/* The weight gradients of a whole backward call as ONE persistent launch per X form ("stream-K" over the 64-token steps of all 128 x 384 output tiles: about one tile per
+ * CU in a full backward, so accumulators stay in registers over the whole token range and only the tiles a span boundary cuts go through scratch; a fix-up launch sums
+ * those in a fixed order - bit-reproducible).  All items are one-plane weight gradients (qatvit_gemm_tn_dy16's arithmetic) over the same M token rows:
+ * mode 0: Q = int8 grid plane q - center, s1 = the activation's {scale, 1/scale, zero_point, enabled};  mode 1: Q = uint8 codes, lut = 256 fp16 (hi | lo << 16) entries
+ * (hi used), s1 = X's scale;  mode 2: Q = fp16 plane (ldq in elements), s1 = X's scale.  C[N, ldc] += ... under the weight STE mask (W NULL: none); dbias, row_div optional.
+ * n <= 24 items per call, N % 128 == 0, Kw % 384 == 0; scratch >= qatvit_gemm_tn_stream_scratch_bytes(). */
+struct qatvit_tn_item {
+    const void* P; const void* Q; const uint32_t* lut; const float* s1; const float* s2; float* C; const float* W; const float* w_scale; const int32_t* w_zp; float* dbias;
+    const float* row_div; int32_t N, Kw, ldp, ldq, ldc;
+};
+int64_t qatvit_gemm_tn_stream_scratch_bytes(void);
+int qatvit_gemm_tn_stream_dy16(int32_t mode, const struct qatvit_tn_item* items, int32_t n, int32_t M, int32_t center, int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax,
+                               float* scratch, int64_t scratch_bytes, void* stream);
+
 /* Attention core between attn.qkv and attn.proj (timm Attention; no fake-quant inside).
  *  qkv: PRE-fake-quant fp32 [B*T, 3*D]; qp: {scale, 1/scale, zero_point, enabled} of the qkv activation FQ
  *  (quantize-on-load).  O = O_hi + O_lo, bf16 [B*T, D] each; lse fp32 [B*H, qatvit_attn_padded_tokens(T)].

@@ -200,6 +200,16 @@ int qatvit_gemm_tn_q8_dy16(const void* P16, const void* Q8, const float* a_qp, i
     return 0;
 }
 
+int64_t qatvit_gemm_tn_stream_scratch_bytes(void) { return tn_stream_scratch_bytes(); }
+int qatvit_gemm_tn_stream_dy16(int32_t mode, const struct qatvit_tn_item* items, int32_t n, int32_t M, int32_t center, int32_t w_per_channel, int32_t w_qmin, int32_t w_qmax,
+                               float* scratch, int64_t scratch_bytes, void* stream) {
+    QV_CHECK_ARG(items && scratch && n >= 1, "qatvit_gemm_tn_stream_dy16: null / empty argument");
+    static_assert(sizeof(qatvit_tn_item) == sizeof(TNStreamGemm), "qatvit_tn_item mirrors TNStreamGemm");
+    if (launch_tn_stream(mode, reinterpret_cast<const TNStreamGemm*>(items), n, M, center, w_per_channel, w_qmin, w_qmax, scratch, scratch_bytes, (hipStream_t)stream)) return 1;
+    QV_CHECK_LAUNCH("qatvit_gemm_tn_stream_dy16");
+    return 0;
+}
+
 int qatvit_gemm_tn_codes(const void* P_hi, const void* P_lo, const void* Qc, const uint32_t* lutQ, float* C, int32_t M, int32_t N, int32_t Kw, int32_t ldp,
                          int32_t ldq, int32_t ldc, const float* s1, const float* W, const float* w_scale, const int32_t* w_zp, int32_t w_per_channel,
                          int32_t w_qmin, int32_t w_qmax, float* dbias, const float* row_div, float* scratch, int64_t scratch_bytes, void* stream) {

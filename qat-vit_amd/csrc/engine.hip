@@ -75,6 +75,9 @@ struct Plan {
     int64_t w8f_off[64 * 4 + 8];   // the int8 weight once more in fragment order (qkv, fc1 with K == 384 / 768: the strip kernel's B operand), -1 otherwise
     int64_t w16_off[64 * 4 + 8], O16_hi, O16_lo, G16_hi, G16_lo, scal16;   // fp16 operands of the forward float x grid GEMMs (proj, fc2): O16 / scal16 per block, G16 shared
     int64_t dxA, dxB, dYs_hi, dYs_lo, dG, dY1_hi, dY1_lo, dH, dO, dqkv_hi, dqkv_lo, delta, dh, dY0_hi, dY0_lo, tn_scratch;
+    // the one-plane backward's gradient planes of EVERY block (its weight gradients run at the end of the call, k_tn_stream): per block [fc2-in | proj-in | fc1-out | qkv-out],
+    // stride dyp_stride; 0 bytes where the deferred form does not apply.  tn_stream: the stream-K scratch
+    int64_t dyp, dyp_stride, dyp_p, dyp_h, dyp_q, tn_stream;
     int64_t qp_staged;   // staging records of the late-resolved quantizers (qv_kernels.h QpLate): kQpStagedWords words per activation quantizer
     int64_t dy16;   // scale state of the one-plane backward (dy16.hip): 4 slots per block - the gradients entering fc2, fc1, proj, qkv
     int64_t total, stats_words;
@@ -83,6 +86,16 @@ struct Plan {
 enum { DS_FC2 = 0, DS_FC1, DS_PROJ, DS_QKV, DS_COUNT };
 
 static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+// QATVIT_TN_STREAM (default on): the one-plane backward keeps every block's gradient planes and runs the weight gradients of a whole backward call as one persistent
+// stream-K launch per X form (gemm.hip k_tn_stream).  The planes are part of the workspace where the shapes allow the form (dy16_supported decides at run time).
+static bool tn_stream_on() {
+    static const bool on = !(getenv("QATVIT_TN_STREAM") && atoi(getenv("QATVIT_TN_STREAM")) == 0);
+    return on;
+}
+static bool tn_stream_planes(const qatvit_cfg& c) {
+    return tn_stream_on() && c.embed_dim % 384 == 0 && c.mlp_hidden % 384 == 0 && c.depth * 2 <= 24 * 8;
+}
 
 static int make_plan(const qatvit_cfg& c, Plan* p) {
     const Dims d = dims_of(c);
@@ -167,6 +180,13 @@ static int make_plan(const qatvit_cfg& c, Plan* p) {
     p->dh = take((int64_t)d.B * D * 4);
     p->dY0_hi = take((int64_t)d.B * d.np * D * 2); p->dY0_lo = take((int64_t)d.B * d.np * D * 2);
     p->tn_scratch = take(kTnScratchBytes);   // split partials of the weight-gradient GEMMs (two-phase, non-atomic reduction)
+    p->dyp = p->tn_stream = -1; p->dyp_stride = 0;
+    if (tn_stream_planes(c)) {
+        p->dyp_p = al(M * D * 2); p->dyp_h = p->dyp_p + al(M * D * 2); p->dyp_q = p->dyp_h + al(M * Hd * 2);
+        p->dyp_stride = p->dyp_q + al(M * 3 * D * 2);
+        p->dyp = take(p->dyp_stride * d.depth);
+        p->tn_stream = take(tn_stream_scratch_bytes());
+    }
     p->total = o;
     return 0;
 }
@@ -747,9 +767,18 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
     // it - from the mask bits of the forward - instead of a k_mask_bwd pass re-reading dx and the fp32 pre-FQ tensor.  Stages must then
     // run in order within one backward (they already had to: dxA carries over).
     static const bool ln_fuse = !(getenv("QATVIT_LN_FUSE") && atoi(getenv("QATVIT_LN_FUSE")) == 0);
-    void* const dYh_all = x.at<void>(p.dYs_hi);
+    void* dYh_all = x.at<void>(p.dYs_hi);
     void* const dYl_all = x.at<void>(p.dYs_lo);
     const bool dy = (x.flags & QATVIT_BWD_DY16) != 0, cal = (x.flags & QATVIT_BWD_CALIBRATE) != 0;
+    // deferred weight gradients (k_tn_stream): every block's gradient planes stay in the workspace, the GEMMs are collected here and run at the end of this call
+    const bool stream = dy && p.dyp >= 0 && x.x_plane_from_q8();
+    auto plane = [&](int blk_i, int which) -> void* {   // 0 fc2-in, 1 proj-in, 2 fc1-out, 3 qkv-out
+        if (!stream) return x.at<void>(which <= 1 ? p.dYs_hi : which == 2 ? p.dY1_hi : p.dqkv_hi);
+        return x.at<char>(p.dyp) + (int64_t)blk_i * p.dyp_stride + (which == 0 ? 0 : which == 1 ? p.dyp_p : which == 2 ? p.dyp_h : p.dyp_q);
+    };
+    std::vector<TNStreamGemm> sg[3];
+    double sflops[3] = {0.0, 0.0, 0.0};
+    if (stream) dYh_all = plane(d.depth - 1, 0);
     if (dy && cal) { set_error("student backward: QATVIT_BWD_DY16 and QATVIT_BWD_CALIBRATE exclude each other"); return 1; }
     if ((dy || cal) && !dy16_supported(x)) { set_error("student backward: the one-plane form does not cover this configuration (qatvit_student_dy16_supported)"); return 1; }
     uint32_t* const dystate = x.at<uint32_t>(p.dy16);
@@ -774,9 +803,10 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
         } else if (s <= d.depth && dy) {
             // ---- one block, one-plane form.  Same dataflow as the pair form below; every dY is one fp16 plane in the hi buffer of the pair.
             const int i = d.depth - s;
-            void* dY16 = x.at<void>(p.dYs_hi);
-            void* dY1_16 = x.at<void>(p.dY1_hi);
-            void* dqkv16 = x.at<void>(p.dqkv_hi);
+            void* dY16 = plane(i, 0);      // the masked gradient entering fc2
+            void* dYp16 = plane(i, 1);     // ... entering proj (the same buffer as dY16 unless the weight gradients are deferred)
+            void* dY1_16 = plane(i, 2);
+            void* dqkv16 = plane(i, 3);
             const int w_fc2 = x.widx(i, WB_FC2), w_fc1 = x.widx(i, WB_FC1), w_proj = x.widx(i, WB_PROJ), w_qkv = x.widx(i, WB_QKV);
             float* const scal16 = x.blk<float>(p.scal16, i);
             auto wscale1 = [&](int wi) { return c.w_per_channel ? nullptr : x.wfq[wi].scale; };
@@ -786,8 +816,14 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                                float* db, const void* X8 = nullptr) -> int {
                 int N, K; wshape(d, wi, &N, &K);
                 const qatvit_fq& f = x.wfq[wi];
-                ProfScope ps(x.prof, (wi == w_proj || Xc) ? 6 : 3, 2.0 * M * N * K, st);
                 const float* rdiv = c.w_per_channel ? f.scale : nullptr;
+                if (stream && !X_lo) {   // collected: one persistent launch per X form at the end of the call
+                    const int m = X8 ? 0 : Xc ? 1 : 2;
+                    sg[m].push_back(TNStreamGemm{P16, X8 ? X8 : Xc ? Xc : X_hi, lut, s_x, x.dy_inv(i, k), dW, x.prm(wparam(d, wi)), f.scale, f.zero_point, db, rdiv, N, K, N, K, K});
+                    sflops[m] += 2.0 * M * N * K;
+                    return 0;
+                }
+                ProfScope ps(x.prof, (wi == w_proj || Xc) ? 6 : 3, 2.0 * M * N * K, st);
                 if (X8 && x.x_plane_from_q8())
                     return launch_gemm_tn_q8_dy16(P16, X8, s_x, x.center(), dW, M, N, K, N, K, K, x.dy_inv(i, k), x.prm(wparam(d, wi)), f.scale, f.zero_point,
                                                   c.w_per_channel, c.w_qmin, c.w_qmax, db, rdiv, st, x.at<float>(p.tn_scratch), kTnScratchBytes);
@@ -823,13 +859,13 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                         x.blk<void>(p.h2q8, i)))
                 return 1;
             const bool lnb = lnb_fuse() && d.D == 384;
-            LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dY16, nullptr, x.dy_mul(i, DS_PROJ), x.dy_slot(i, DS_PROJ)};
+            LnBwdNext nx_proj{x.blk<void>(p.mproj, i), x.dy_colscale(w_proj), dYp16, nullptr, x.dy_mul(i, DS_PROJ), x.dy_slot(i, DS_PROJ)};
             if (lnb) {
                 NTPost post{};
                 post.mode = 8; post.qp = x.act_qp(x.aidx(i, AB_N2)); post.qmin = qa; post.qmax = qb;
                 post.lnb_x = x.blk<float>(p.x_mid, i); post.lnb_mean = x.blk<float>(p.mean2, i); post.lnb_rstd = x.blk<float>(p.rstd2, i);
                 post.lnb_gamma = x.bprm(i, B_N2W); post.lnb_beta = x.bprm(i, B_N2B); post.lnb_dx_in = dxA; post.lnb_dgamma = BG(i, B_N2W); post.lnb_dbeta = BG(i, B_N2B);
-                post.lnb_nmask = nx_proj.maskbits; post.colscale = nx_proj.colscale; post.out_hi = dY16;
+                post.lnb_nmask = nx_proj.maskbits; post.colscale = nx_proj.colscale; post.out_hi = dYp16;
                 post.o16_mul = nx_proj.o16_mul; post.o16_amax = nx_proj.o16_amax;
                 if (dgrad16(dY1_16, DS_FC1, w_fc1, dxB, &post)) return 1;
             } else {
@@ -842,8 +878,8 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             // (the float X operands - attention output, gelu output - enter the one-plane weight gradients rounded to fp16 like dY itself: one pass;
             //  QATVIT_DY16_XPAIR=1 keeps them as fp16 (hi, lo) pairs, two passes)
             static const bool xpair = getenv("QATVIT_DY16_XPAIR") && atoi(getenv("QATVIT_DY16_XPAIR")) != 0;
-            if (wgrad16(dY16, DS_PROJ, w_proj, x.blk<void>(p.O16_hi, i), xpair ? x.blk<void>(p.O16_lo, i) : nullptr, nullptr, nullptr, scal16, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
-            if (dgrad16(dY16, DS_PROJ, w_proj, x.at<float>(p.dO), nullptr)) return 1;
+            if (wgrad16(dYp16, DS_PROJ, w_proj, x.blk<void>(p.O16_hi, i), xpair ? x.blk<void>(p.O16_lo, i) : nullptr, nullptr, nullptr, scal16, BG(i, B_PROJW), BG(i, B_PROJB))) return 1;
+            if (dgrad16(dYp16, DS_PROJ, w_proj, x.at<float>(p.dO), nullptr)) return 1;
             if (launch_attn_bwd(nullptr, x.act_qp(x.aidx(i, AB_QKV)), qa, qb, d.B, d.T, d.H, d.D, x.blk<void>(p.O_hi, i), x.blk<void>(p.O_lo, i), x.blk<float>(p.lse, i),
                                 x.at<float>(p.delta), x.at<float>(p.dO), dqkv16, nullptr, x.dy_colscale(w_qkv), st, x.blk<void>(p.qkv8, i), x.blk<void>(p.qkvm, i),
                                 x.dy_mul(i, DS_QKV), x.dy_slot(i, DS_QKV)))
@@ -851,14 +887,15 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             if (wgrad16(dqkv16, DS_QKV, w_qkv, x.blk<void>(p.h1q, i), nullptr, nullptr, nullptr, x.act_qp(x.aidx(i, AB_N1)), BG(i, B_QKVW), BG(i, B_QKVB),
                         x.blk<void>(p.h1q8, i)))
                 return 1;
-            LnBwdNext nx_fc2{i > 0 ? x.blk<void>(p.m2, i - 1) : nullptr, i > 0 ? x.dy_colscale(x.widx(i - 1, WB_FC2)) : nullptr, dY16, nullptr,
+            void* const dYnext = i > 0 ? plane(i - 1, 0) : dY16;   // the next block's fc2-in plane (its own buffer when the weight gradients are deferred)
+            LnBwdNext nx_fc2{i > 0 ? x.blk<void>(p.m2, i - 1) : nullptr, i > 0 ? x.dy_colscale(x.widx(i - 1, WB_FC2)) : nullptr, dYnext, nullptr,
                              i > 0 ? x.dy_mul(i - 1, DS_FC2) : nullptr, i > 0 ? x.dy_slot(i - 1, DS_FC2) : nullptr};
             if (lnb) {
                 NTPost post{};
                 post.mode = 8; post.qp = x.act_qp(x.aidx(i, AB_N1)); post.qmin = qa; post.qmax = qb;
                 post.lnb_x = x.blk<float>(p.x_in, i); post.lnb_mean = x.blk<float>(p.mean1, i); post.lnb_rstd = x.blk<float>(p.rstd1, i);
                 post.lnb_gamma = x.bprm(i, B_N1W); post.lnb_beta = x.bprm(i, B_N1B); post.lnb_dx_in = dxB; post.lnb_dgamma = BG(i, B_N1W); post.lnb_dbeta = BG(i, B_N1B);
-                if (i > 0) { post.lnb_nmask = nx_fc2.maskbits; post.colscale = nx_fc2.colscale; post.out_hi = dY16; }
+                if (i > 0) { post.lnb_nmask = nx_fc2.maskbits; post.colscale = nx_fc2.colscale; post.out_hi = dYnext; }
                 // (block 0 emits no next-branch gradient; the epilogue still wants a scale / maximum target: its own slot, which nothing reads afterwards)
                 post.o16_mul = i > 0 ? nx_fc2.o16_mul : x.dy_mul(0, DS_QKV); post.o16_amax = i > 0 ? nx_fc2.o16_amax : x.dy_slot(0, DS_QKV);
                 if (dgrad16(dqkv16, DS_QKV, w_qkv, dxA, &post)) return 1;
@@ -947,6 +984,13 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             if (x.linear_wgrad(x.at<void>(p.dY0_hi), x.at<void>(p.dY0_lo), d.B * d.np, 0, x.at<void>(p.imgq), nullptr, x.act_qp(A_IN), G(P_PE_W),
                                G(P_PE_B), false))
                 return 1;
+        }
+    }
+    for (int m = 0; m < 3; ++m) {   // the collected weight gradients: one persistent launch (+ its fix-up) per X form and <= 24 GEMMs
+        for (size_t o = 0; o < sg[m].size(); o += 24) {
+            const int n = (int)std::min<size_t>(24, sg[m].size() - o);
+            ProfScope ps(x.prof, m == 0 ? 3 : 6, sflops[m] * n / (double)sg[m].size(), st);
+            if (launch_tn_stream(m, sg[m].data() + o, n, M, x.center(), c.w_per_channel, c.w_qmin, c.w_qmax, x.at<float>(p.tn_stream), tn_stream_scratch_bytes(), st)) return 1;
         }
     }
     if (dy || cal) launch_dy16_end(dystate, nslots, dy ? 1 : 0, st);

@@ -168,6 +168,11 @@ __device__ const ZerosTab kZeros{};
 // needs 100 more registers than the accumulators leave and spills them)
 #ifdef QV_NT_EXPERIMENTS   // development builds only (-DQV_NT_EXPERIMENTS=<epilogue mode>): s_memtime stamps of that mode's phases, workgroups 0 and 100, every
 __device__ unsigned long long g_nt_stamps[2 * 8 * 16];   // wave; read back with qatvit_debug_nt_stamps (tools/stamp_nt.py).  The shipped library has none.
+__device__ unsigned long long g_wg_rt[2048 * 2];   // per workgroup: s_memrealtime (100 MHz, one counter for the whole device) at entry and after its last store
+#define QV_WG_RT(PM_, k_)                                                                                                       \
+    do {                                                                                                                        \
+        if ((PM_) == QV_NT_EXPERIMENTS && threadIdx.x == 0 && blockIdx.x < 2048) g_wg_rt[blockIdx.x * 2 + (k_)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #define QV_NT_STAMP(PM_, k_)                                                                                                    \
     do {                                                                                                                        \
         if ((PM_) == QV_NT_EXPERIMENTS && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0) {                  \
@@ -179,6 +184,7 @@ __device__ unsigned long long g_nt_stamps[2 * 8 * 16];   // wave; read back with
     } while (0)
 #else
 #define QV_NT_STAMP(PM_, k_)
+#define QV_WG_RT(PM_, k_)
 #endif
 template <int WM, int WN, int TM, int TNT, int SLAB = 64, int PM = 0, int RING = 0, bool I8 = false>   // SLAB: rows staged through LDS at a time; RING: LDS bytes
 __device__ inline void nt_epilogue(const NTArgs& p, std::conditional_t<I8, i32x4, f32x4> (&acc)[TM][TNT], char* smem, int m0, int n0, int tid, int lane, int wave, int wm, int wn,
@@ -842,6 +848,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void k_gemm_nt(
 
     const int nk = p.K / BK;
     QV_NT_STAMP(PM, 0);   // entry
+    QV_WG_RT(PM, 0);
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < nk) issue(s);
@@ -942,7 +949,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 256) void k_gemm_nt(
     nt_epilogue<WM, WN, TM, TNT, SLAB, PM, EPI_LDS, I8>(p, acc, smem, m0, n0, tid, lane, wave, wm, wn, r, g);
     QV_NT_STAMP(PM, 12);   // stores issued
 #ifdef QV_NT_EXPERIMENTS
-    if (PM == QV_NT_EXPERIMENTS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QV_NT_STAMP(PM, 13); }
+    if (PM == QV_NT_EXPERIMENTS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QV_NT_STAMP(PM, 13); QV_WG_RT(PM, 1); }
 #endif
 }
 
@@ -1814,6 +1821,8 @@ __global__ __launch_bounds__(512) void k_gemm_tn_q8(const TNArgs p) {
     const int total_steps = (p.M + BK - 1) / BK;
     const int s_begin = split * p.steps_per_split;
     const int nsteps = min(total_steps, s_begin + p.steps_per_split) - s_begin;
+    QV_NT_STAMP(100 + MODE, 0);   // entry
+    QV_WG_RT(100 + MODE, 0);
     const v4i32 rP = make_rsrc_v(p.P0, (int64_t)p.M * p.ldp * 2);
     const v4i32 rQ = make_rsrc_v(p.Qc, (int64_t)p.M * p.ldq);     // rows past M read as zero bytes: P is zero there too
     auto issue = [&](int s) {
@@ -1967,6 +1976,10 @@ __global__ __launch_bounds__(512) void k_gemm_tn_q8(const TNArgs p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TNT; ++j) dst[(i * TNT + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        QV_NT_STAMP(100 + MODE, 12);   // stores issued
+#ifdef QV_NT_EXPERIMENTS
+        if (100 + MODE == QV_NT_EXPERIMENTS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QV_NT_STAMP(100 + MODE, 13); QV_WG_RT(100 + MODE, 1); }
+#endif
         return;
     }
 #pragma unroll
@@ -2171,9 +2184,339 @@ int launch_gemm_tn_codes_dy16(const void* P16, const void* Qc, const uint32_t* l
                                     st, partial, partial_bytes);
 }
 
+
+// ============================================================================ weight gradients of a whole backward call in ONE persistent launch per operand form
+// The one-plane backward keeps the gradient planes of every block (348 MB per block at batch 256: 4.2 GB of the 288) and runs its weight gradients at the end of the call:
+// all GEMMs of one X form (MODE 0: int8 grid plane - qkv, fc1; MODE 1: uint8 codes + table - fc2; MODE 2: fp16 plane - proj) are ONE launch of one workgroup per CU.
+// Work unit = one 64-token step of one 128 x 384 output tile; the units of all GEMMs are laid end to end (GEMM-major, tile-major, token-minor) and cut into gridDim
+// equal spans ("stream-K"): a workgroup runs its span segment by segment, accumulators in registers across a whole tile where the span covers it - and a full backward has
+// about one tile per CU (252 / 144 / 36 tiles), so almost nothing is split: where the per-GEMM launches wrote and re-read 50 MB of raw partial tiles each (2.4 GB per step,
+// 94 launches), only the <= 2 tiles a span cuts are written raw ([2 slots per workgroup]) and summed in workgroup order by k_tn_stream_fixup - fixed order, bit-reproducible.
+// A complete tile's owner applies scale / STE mask and adds into dW itself (exclusive: no atomics).  Loop body: k_gemm_tn_q8's.
+constexpr int kTnStreamMax = 24;
+struct TNStreamItem {
+    const void* P;          // fp16 gradient plane [M, ldp]
+    const void* Q;          // MODE 0: int8 q - center [M, ldq]; MODE 1: uint8 codes [M, ldq]; MODE 2: fp16 plane [M, ldq] (ldq in elements)
+    const uint32_t* lut;    // MODE 1: 256 entries, fp16 hi half used
+    const float* s1;        // MODE 0: the activation's {scale, 1/scale, zero point, ..}; MODE 1 / 2: X's scale
+    const float* s2;        // inverse scale of the plane
+    float* C; const float* W; const float* w_scale; const int32_t* w_zp; float* dbias; const float* row_div;
+    int N, Kw, ldp, ldq, ldc, tiles, unit0;
+};
+struct TNStreamArgs {
+    TNStreamItem it[kTnStreamMax];
+    int n, M, steps, units_total, units_per_wg, center, w_per_channel, w_qmin, w_qmax;
+    float* partial;         // [2 * gridDim][8 waves][24 fragments][64 lanes] float4
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_tn_stream(const TNStreamArgs a) {
+    constexpr int BN = 128, BKW = 384, BK = 64, NW = 8, TM = 8, TNT = 3;   // one wave row of eight waves, 128 x 48 per wave
+    constexpr int QB = MODE == 2 ? 2 : 1;                       // bytes per Q element
+    constexpr int NSTAGE = MODE == 2 ? 2 : 3;
+    constexpr int IMGP = BK * 256, QROWB = BKW * QB, IMGQ = BK * QROWB, STAGE = IMGP + IMGQ;
+    constexpr int PP = IMGP / 1024 / NW, PQ = IMGQ / 1024 / NW, NDMA = PP + PQ;
+    constexpr int TAB = NSTAGE * STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave;
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int u_begin = w * a.units_per_wg, u_end = min(a.units_total, u_begin + a.units_per_wg);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    f16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
+    const uint32_t tab_lane = (uint32_t)(TAB + (lane & 31) * 4);
+    struct Ops { f16x8 pf[TM]; f16x8 pb; uint2 qb[MODE == 2 ? 1 : TNT]; uint32_t v[MODE == 1 ? TNT * 8 : 1]; f16x8 qf[TNT]; };
+    int g = 0, lut_of = -1;
+    for (int u = u_begin; u < u_end;) {
+        while (g + 1 < a.n && a.it[g + 1].unit0 <= u) ++g;
+        const TNStreamItem& it = a.it[g];
+        const int rel = u - it.unit0, tile = rel / a.steps, s_first = rel % a.steps;
+        const int nsteps = min(a.steps - s_first, u_end - u);
+        const bool complete = s_first == 0 && nsteps == a.steps;
+        const int slot = 2 * w + (u == u_begin ? 0 : 1);
+        const int tilesK = it.Kw / BKW;
+        const int n0 = (tile / tilesK) * BN, k0 = (tile % tilesK) * BKW;
+        const v4i32 rP = make_rsrc_v(it.P, (int64_t)a.M * it.ldp * 2);
+        const v4i32 rQ = make_rsrc_v(it.Q, (int64_t)a.M * it.ldq * QB);
+        const int ldp = it.ldp, ldq = it.ldq;
+        auto issue = [&](int s) {
+            char* st = smem + (s % NSTAGE) * STAGE;
+            const int mrow0 = (s_first + s) * BK;
+#pragma unroll
+            for (int c = 0; c < PP; ++c) {
+                const int piece = wave * PP + c, row = piece * 4 + (lane >> 4);
+                dma16_asm(rP, st + piece * 1024, (uint32_t)(((int64_t)(mrow0 + row) * ldp + n0 + (((lane & 15) ^ tn_sw(row)) << 3)) * 2));
+            }
+#pragma unroll
+            for (int c = 0; c < PQ; ++c) {
+                const int piece = wave * PQ + c, L = piece * 64 + lane;
+                if constexpr (MODE == 2) {
+                    const int row = L / 48, cp = L % 48;
+                    dma16_asm(rQ, st + IMGP + piece * 1024, (uint32_t)(((int64_t)(mrow0 + row) * ldq + k0 + ((cp ^ tn_sw(row)) << 3)) * 2));
+                } else {
+                    const int row = L / 24, cp = L % 24;
+                    dma16_asm(rQ, st + IMGP + piece * 1024, (uint32_t)((int64_t)(mrow0 + row) * ldq + k0 + ((cp ^ tn8_sw(row)) << 4)));
+                }
+            }
+        };
+        // every wave has left the previous segment's images (and table) before this segment's DMA / table fill overwrites them
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (s < nsteps) issue(s);
+        qv_f16x2 cadd;
+        cadd[0] = cadd[1] = (_Float16)0.f;
+        if constexpr (MODE == 0) {
+            const float c = (float)a.center - it.s1[2] - 1152.0f;
+            cadd[0] = (_Float16)c; cadd[1] = (_Float16)c;
+        }
+        if constexpr (MODE == 1) {
+            if (lut_of != g) {
+                uint32_t* tab = reinterpret_cast<uint32_t*>(smem + TAB);
+                const uint32_t ent = it.lut[tid & 255] & 0xffffu;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) tab[(tid & 255) * 32 + 16 * (tid >> 8) + k] = ent;
+                lut_of = g;
+            }
+        }
+        f32x4 acc[TM][TNT];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool do_bias = it.dbias != nullptr && (tile % tilesK) == 0;
+        f32x4 accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto load1 = [&](Ops& o, const char* st, int kk) {
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) o.qf[j] = __builtin_bit_cast(f16x8, tr_frag<QROWB>(st + IMGP, 32 * kk, wn * (16 * TNT) + 16 * j, lane));
+            } else {
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) o.qb[j] = tr8_frag(st + IMGP, 32 * kk, wn * TNT + j, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < TM / 2; ++i) o.pf[i] = __builtin_bit_cast(f16x8, tr_frag<256>(st, 32 * kk, 16 * i, lane));
+            if constexpr (MODE != 2) o.pb = __builtin_bit_cast(f16x8, tr_frag<256>(st, 32 * kk, 16 * wn, lane));
+        };
+        auto load2 = [&](Ops& o, const char* st, int kk) {
+#pragma unroll
+            for (int i = TM / 2; i < TM; ++i) o.pf[i] = __builtin_bit_cast(f16x8, tr_frag<256>(st, 32 * kk, 16 * i, lane));
+            if constexpr (MODE == 2) o.pb = __builtin_bit_cast(f16x8, tr_frag<256>(st, 32 * kk, 16 * wn, lane));
+        };
+        auto x1 = [&](Ops& o) {
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < TNT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o.v[8 * j + q] = *reinterpret_cast<const uint32_t*>(smem + tab_lane + (((o.qb[j].x >> (8 * q)) & 0xffu) << 7));
+                        o.v[8 * j + 4 + q] = *reinterpret_cast<const uint32_t*>(smem + tab_lane + (((o.qb[j].y >> (8 * q)) & 0xffu) << 7));
+                    }
+            }
+        };
+        auto x2 = [&](Ops& o) {
+            if constexpr (MODE != 2) {
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) {
+                    uint32_t h[4];
+                    if constexpr (MODE == 0) {
+                        const uint32_t x0 = o.qb[j].x ^ 0x80808080u, x1_ = o.qb[j].y ^ 0x80808080u;
+                        const uint32_t e[4] = {__builtin_amdgcn_perm(0x64646464u, x0, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, x0, 0x04030402u),
+                                               __builtin_amdgcn_perm(0x64646464u, x1_, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, x1_, 0x04030402u)};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) h[q] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(qv_f16x2, e[q]) + cadd);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) h[q] = o.v[8 * j + 2 * q] | (o.v[8 * j + 2 * q + 1] << 16);
+                    }
+                    o.qf[j] = __builtin_bit_cast(f16x8, (u32x4){h[0], h[1], h[2], h[3]});
+                }
+            }
+        };
+        auto mm = [&](const Ops& o, int lo, int hi) {
+            constexpr int BI = MODE == 2 ? TM / 2 : 0;   // the bias fragment arrives with the read group of row fragment BI
+            if (lo <= BI && BI < hi) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.pb, ones, accb, 0, 0, 0);
+#pragma unroll
+            for (int i = lo; i < hi; ++i)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.pf[i], o.qf[j], acc[i][j], 0, 0, 0);
+        };
+        Ops A, B;
+        {
+            const f16x8 z = __builtin_bit_cast(f16x8, (u32x4){0u, 0u, 0u, 0u});
+#pragma unroll
+            for (int i = 0; i < TM; ++i) B.pf[i] = z;
+            B.pb = z;
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) B.qf[j] = z;
+        }
+        for (int s = 0; s < nsteps; ++s) {
+            if (NSTAGE >= 3 && s + NSTAGE - 2 < nsteps) wait_vmcnt<(NSTAGE - 2) * NDMA>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s + NSTAGE - 1 < nsteps) issue(s + NSTAGE - 1);
+            const char* st = smem + (s % NSTAGE) * STAGE;
+            load1(A, st, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(B, 0, TM / 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load2(A, st, 0);
+            x1(A);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(B, TM / 2, TM);
+            __builtin_amdgcn_sched_barrier(0);
+            x2(A);
+            load1(B, st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(A, 0, TM / 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load2(B, st, 1);
+            x1(B);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(A, TM / 2, TM);
+            __builtin_amdgcn_sched_barrier(0);
+            x2(B);
+        }
+        mm(B, 0, TM);
+        // ---- this segment's result
+        const float bscale = it.s2 ? *it.s2 : 1.f;
+        const int r = lane & 15, gq = lane >> 4;
+        if (do_bias && r == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + 16 * wn + 4 * gq + e;
+                if (n < it.N) atomicAdd(&it.dbias[n], accb[e] * bscale * (it.row_div ? __fdiv_rn(1.0f, it.row_div[n]) : 1.0f));
+            }
+        }
+        if (!complete) {   // raw accumulators to this workgroup's slot: k_tn_stream_fixup sums the pieces of the tile in workgroup order
+            float4* dst = reinterpret_cast<float4*>(a.partial) + ((int64_t)slot * NW + wave) * (TM * TNT * 64);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) dst[(i * TNT + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        } else {           // the whole token range in registers: scale, STE mask, add into dW (this workgroup is the tile's only writer)
+            const float alpha = (it.s1 ? *it.s1 : 1.f) * bscale;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + 16 * i + 4 * gq + e;
+                    if (n >= it.N) continue;
+                    const float rdiv = it.row_div ? __fdiv_rn(1.0f, it.row_div[n]) : 1.0f;
+                    float inv = 0.f, fzp = 0.f;
+                    if (it.W) {
+                        const int ci = a.w_per_channel ? n : 0;
+                        inv = __fdiv_rn(1.0f, it.w_scale[ci]);
+                        fzp = (float)it.w_zp[ci];
+                    }
+#pragma unroll
+                    for (int j = 0; j < TNT; ++j) {
+                        const int kw = k0 + wn * (16 * TNT) + 16 * j + r;
+                        float v = acc[i][j][e] * (alpha * rdiv);
+                        if (it.W) {
+                            const float q = rintf(it.W[(int64_t)n * it.ldc + kw] * inv) + fzp;
+                            if (!(q >= (float)a.w_qmin && q <= (float)a.w_qmax)) v = 0.f;
+                        }
+                        it.C[(int64_t)n * it.ldc + kw] += v;
+                    }
+                }
+            }
+        }
+        u += nsteps;
+    }
+}
+
+// The tiles a span boundary cut: pieces summed in workgroup order, then k_tn_reduce's tail.  One thread per float4 of the accumulator layout; blocks of complete tiles return.
+__global__ __launch_bounds__(256) void k_tn_stream_fixup(const TNStreamArgs a, int total_tiles) {
+    constexpr int TM = 8, TNT = 3, NW = 8, per_wave = TM * TNT * 64, per_tile = per_wave * NW;
+    const int gt = blockIdx.x / (per_tile / 256), rem = (blockIdx.x % (per_tile / 256)) * 256 + threadIdx.x;
+    if (gt >= total_tiles) return;
+    int g = 0, t0 = 0;
+    while (g + 1 < a.n && t0 + a.it[g].tiles <= gt) { t0 += a.it[g].tiles; ++g; }
+    const TNStreamItem& it = a.it[g];
+    const int tile = gt - t0;
+    const int U0 = it.unit0 + tile * a.steps, U1 = U0 + a.steps, q = a.units_per_wg;
+    const int w0 = U0 / q, w1 = (U1 - 1) / q;
+    if (w0 == w1) return;                                   // one workgroup held the whole tile and finished it
+    const int wave = rem / per_wave, f = (rem % per_wave) / 64, lane = rem & 63;
+    const int i = f / TNT, j = f % TNT, r = lane & 15, gq = lane >> 4;
+    const int tilesK = it.Kw / 384;
+    const int n0 = (tile / tilesK) * 128, k0 = (tile % tilesK) * 384;
+    const int kw = k0 + wave * (16 * TNT) + 16 * j + r;
+    const int nbase = n0 + 16 * i + 4 * gq;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = w0; w <= w1; ++w) {
+        const int slot = 2 * w + (max(U0, w * q) == w * q ? 0 : 1);
+        const float4 b = reinterpret_cast<const float4*>(a.partial)[(int64_t)slot * per_tile + rem];
+        s4.x += b.x; s4.y += b.y; s4.z += b.z; s4.w += b.w;
+    }
+    const float av[4] = {s4.x, s4.y, s4.z, s4.w};
+    const float alpha = (it.s1 ? *it.s1 : 1.f) * (it.s2 ? *it.s2 : 1.f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = nbase + e;
+        if (n >= it.N) continue;
+        const float rdiv = it.row_div ? __fdiv_rn(1.0f, it.row_div[n]) : 1.0f;
+        float v = av[e] * (alpha * rdiv);
+        if (it.W) {
+            const int ci = a.w_per_channel ? n : 0;
+            const float qq = rintf(it.W[(int64_t)n * it.ldc + kw] * __fdiv_rn(1.0f, it.w_scale[ci])) + (float)it.w_zp[ci];
+            if (!(qq >= (float)a.w_qmin && qq <= (float)a.w_qmax)) v = 0.f;
+        }
+        it.C[(int64_t)n * it.ldc + kw] += v;
+    }
+}
+
+int64_t tn_stream_scratch_bytes() { return (int64_t)2 * 256 * 128 * 384 * 4; }   // two raw tiles per workgroup, at most 256 workgroups (one per CU of an MI355X)
+
+// items[0..n): the weight-gradient GEMMs of one X form (mode 0 / 1 / 2 as above), all over the same M token rows.  N % 128 == 0, Kw % 384 == 0.
+int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int center, int w_per_channel, int w_qmin, int w_qmax, float* partial, int64_t partial_bytes,
+                     hipStream_t st) {
+    if (n < 1 || n > kTnStreamMax || M < 1 || mode < 0 || mode > 2 || !partial) { set_error("tn_stream: bad arguments (n=%d, mode=%d)", n, mode); return 1; }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1 || cus > 256) cus = 256;
+    }
+    TNStreamArgs a{};
+    a.n = n; a.M = M; a.steps = (M + 63) / 64; a.center = center; a.w_per_channel = w_per_channel; a.w_qmin = w_qmin; a.w_qmax = w_qmax; a.partial = partial;
+    int units = 0, tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const TNStreamGemm& s = items[i];
+        const int qal = mode == 2 ? 8 : 16;
+        if (!s.P || !s.Q || !s.C || !s.s1 || (mode == 1 && !s.lut) || s.N % 128 != 0 || s.Kw % 384 != 0 || s.ldp % 8 != 0 || s.ldq % qal != 0 || (s.W && (!s.w_scale || !s.w_zp))) {
+            set_error("tn_stream: unsupported item %d (N=%d Kw=%d ldp=%d ldq=%d)", i, s.N, s.Kw, s.ldp, s.ldq);
+            return 1;
+        }
+        TNStreamItem& d = a.it[i];
+        d.P = s.P; d.Q = s.Q; d.lut = s.lut; d.s1 = s.s1; d.s2 = s.s2; d.C = s.C; d.W = s.W; d.w_scale = s.w_scale; d.w_zp = s.w_zp; d.dbias = s.dbias; d.row_div = s.row_div;
+        d.N = s.N; d.Kw = s.Kw; d.ldp = s.ldp; d.ldq = s.ldq; d.ldc = s.ldc; d.tiles = (s.N / 128) * (s.Kw / 384); d.unit0 = units;
+        units += d.tiles * a.steps;
+        tiles += d.tiles;
+    }
+    const int grid = units < cus ? units : cus;
+    a.units_total = units;
+    a.units_per_wg = (units + grid - 1) / grid;
+    if ((int64_t)2 * grid * 128 * 384 * 4 > partial_bytes) { set_error("tn_stream: scratch too small (%lld bytes)", (long long)partial_bytes); return 1; }
+    constexpr size_t lds0 = 3 * (64 * 256 + 64 * 384), lds1 = lds0 + 256 * 32 * 4, lds2 = 2 * (64 * 256 + 64 * 768);
+    static bool once = (allow_lds(k_tn_stream<0>, lds0), allow_lds(k_tn_stream<1>, lds1), allow_lds(k_tn_stream<2>, lds2), true);
+    (void)once;
+    if (mode == 0) k_tn_stream<0><<<grid, 512, lds0, st>>>(a);
+    else if (mode == 1) k_tn_stream<1><<<grid, 512, lds1, st>>>(a);
+    else k_tn_stream<2><<<grid, 512, lds2, st>>>(a);
+    k_tn_stream_fixup<<<tiles * (8 * 24 * 64 / 256), 256, 0, st>>>(a, tiles);
+    return 0;
+}
+
 }  // namespace qv
 
 #ifdef QV_NT_EXPERIMENTS
+extern "C" __attribute__((visibility("default"))) int qatvit_debug_wg_realtime(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(qv::g_wg_rt), sizeof(unsigned long long) * 2048 * 2) == hipSuccess ? 0 : 1;
+}
 extern "C" __attribute__((visibility("default"))) int qatvit_debug_nt_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(qv::g_nt_stamps), sizeof(unsigned long long) * 2 * 8 * 16) == hipSuccess ? 0 : 1;
 }

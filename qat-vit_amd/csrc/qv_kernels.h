@@ -162,6 +162,15 @@ int launch_gemm_tn_q8_dy16(const void* P16, const void* Q8, const float* a_qp, i
                            const float* W, const float* w_scale, const int32_t* w_zp, int w_per_channel, int w_qmin, int w_qmax, float* dbias, const float* row_div,
                            hipStream_t st, float* partial = nullptr, int64_t partial_bytes = 0);
 bool tn_q8_enabled();   // QATVIT_TN_Q8 (default on)
+// the weight gradients of one backward call, one persistent stream-K launch per X form (gemm.hip k_tn_stream): mode 0 = X as int8 grid plane (s1 = the activation's
+// qparams, `center`), 1 = uint8 codes + table (lut), 2 = fp16 plane.  All items share M.  partial: >= tn_stream_scratch_bytes().
+struct TNStreamGemm {
+    const void* P; const void* Q; const uint32_t* lut; const float* s1; const float* s2; float* C; const float* W; const float* w_scale; const int32_t* w_zp; float* dbias;
+    const float* row_div; int N, Kw, ldp, ldq, ldc;
+};
+int64_t tn_stream_scratch_bytes();
+int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int center, int w_per_channel, int w_qmin, int w_qmax, float* partial, int64_t partial_bytes,
+                     hipStream_t st);
 // ---- elt.hip
 int launch_img_patches(const float* img, void* out_bf16, const float* qp, int qmin, int qmax, int B, int C, int H, int W, int P, hipStream_t st,
                        void* out8 = nullptr, int center = 0);

@@ -42,6 +42,8 @@ SIGNATURES = {
     "qatvit_gemm_nt_dy16": (c_int, [c_void_p] * 3 + [c_int32] * 6 + [c_void_p] * 3),
     "qatvit_gemm_tn_dy16": (c_int, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p] * 5 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
     "qatvit_gemm_tn_q8_dy16": (c_int, [c_void_p] * 3 + [c_int32, c_void_p] + [c_int32] * 6 + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int64, c_void_p]),
+    "qatvit_gemm_tn_stream_scratch_bytes": (c_int64, []),
+    "qatvit_gemm_tn_stream_dy16": (c_int, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
     "qatvit_attn_padded_tokens": (c_int32, [c_int32]),
     "qatvit_attn_forward": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 4),
     "qatvit_attn_forward_f16": (c_int, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p] * 9),
@@ -75,6 +77,11 @@ class Cfg(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in ("batch", "img_size", "patch_size", "in_chans", "embed_dim", "depth", "num_heads", "mlp_hidden",
                                        "num_classes", "act_qmin", "act_qmax", "w_qmin", "w_qmax", "w_per_channel")] + \
                [("averaging_const", c_float), ("ln_eps", c_float)]
+
+
+class TNItem(ctypes.Structure):
+    """struct qatvit_tn_item (include/qatvit.h)."""
+    _fields_ = [(n, c_void_p) for n in ("P", "Q", "lut", "s1", "s2", "C", "W", "w_scale", "w_zp", "dbias", "row_div")] + [(n, c_int32) for n in ("N", "Kw", "ldp", "ldq", "ldc")]
 
 
 class FQ(ctypes.Structure):

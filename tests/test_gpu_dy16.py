@@ -122,6 +122,80 @@ def test_wgrad_one_plane_byte_grid_vs_fp64(native_lib, M, N, Kw, center, zp):
     assert rel_l2((dW2.double() - 1e-4).cpu().numpy(), ref.cpu().numpy()) < 1e-4      # (fp32 atomics onto 1e-4: ~1e-5)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M,shapes", [(640, [(1536, 384)] * 12 + [(1152, 384)] * 10 + [(384, 768)] * 2),      # 282 tiles of 10 steps: whole tiles in registers AND cut tiles
+                                      (6400, [(1536, 384), (1152, 384), (384, 384)]),                           # 24 tiles of 100 steps on ~256 workgroups: every tile cut ~10 times
+                                      (25216, [(384, 1536), (128, 384)])])                                      # Kw tiles; a one-tile GEMM at the end
+def test_wgrad_stream_batch_vs_fp64(native_lib, mode, M, shapes):
+    """qatvit_gemm_tn_stream_dy16: the weight gradients of a backward call as ONE persistent stream-K launch per X form - each item against fp64 on the rounded plane,
+    with and without the weight STE mask / bias gradient / per-channel division, on top of a non-zero dW; a second run gives the same bits (fixed summation order)."""
+    g = torch.Generator(device="cuda").manual_seed(100 * mode + M)
+    items = (native.TNItem * len(shapes))()
+    keep, refs = [], []
+    center, zp = 128, 131.0
+    for k, (N, Kw) in enumerate(shapes):
+        dy = torch.randn(M, N, generator=g, device="cuda") * 2e-6 * torch.exp(torch.randn(M, N, generator=g, device="cuda"))
+        e = 8 - int(np.floor(np.log2(dy.abs().max().item())) + 1)
+        plane = (dy * 2.0 ** e).to(torch.float16)
+        sx = 0.02 + 0.01 * k
+        lut = None
+        if mode == 0:
+            q = torch.randint(0, 256, (M, Kw), generator=g, device="cuda")
+            Q = (q - center).to(torch.int8)
+            xv = (q - zp).double()
+            s1 = torch.tensor([sx, 1.0 / sx, zp, 1.0], dtype=torch.float32, device="cuda")
+        elif mode == 1:
+            tab = (torch.randn(256, generator=g, device="cuda") * 400.0).to(torch.float16)
+            lut = (tab.view(torch.int16).int() & 0xffff).contiguous()
+            Q = torch.randint(0, 256, (M, Kw), generator=g, device="cuda").to(torch.uint8)
+            xv = tab.double()[Q.long()]
+            s1 = _scalar(sx)
+        else:
+            Q = (torch.randn(M, Kw, generator=g, device="cuda") * 300.0).to(torch.float16)
+            xv = Q.double()
+            s1 = _scalar(sx)
+        s2 = _scalar(2.0 ** -e)
+        C0 = torch.randn(N, Kw, generator=g, device="cuda") * 1e-5
+        C = C0.clone()
+        masked, biased, divided = k % 2 == 0, k % 3 != 1, k % 4 == 3
+        W = torch.randn(N, Kw, generator=g, device="cuda") if masked else None
+        wsc = torch.full((N,), 0.01, device="cuda") if masked else None
+        wzp = torch.zeros(N, dtype=torch.int32, device="cuda") if masked else None
+        db = torch.zeros(N, device="cuda") if biased else None
+        rdiv = (0.5 + torch.rand(N, generator=g, device="cuda")) if divided else None
+        it = items[k]
+        it.P, it.Q, it.lut, it.s1, it.s2, it.C = plane.data_ptr(), Q.data_ptr(), (lut.data_ptr() if lut is not None else None), s1.data_ptr(), s2.data_ptr(), C.data_ptr()
+        it.W, it.w_scale, it.w_zp = (W.data_ptr(), wsc.data_ptr(), wzp.data_ptr()) if masked else (None, None, None)
+        it.dbias, it.row_div = (db.data_ptr() if biased else None), (rdiv.data_ptr() if divided else None)
+        it.N, it.Kw, it.ldp, it.ldq, it.ldc = N, Kw, N, Kw, Kw
+        ref = (plane.double().T @ xv) * (sx * 2.0 ** -e)
+        if divided:
+            ref = ref / rdiv.double()[:, None]
+        if masked:   # per-channel scales 0.01, [-128, 127]: |W| > 1.27 .. 1.28 is clipped; the mask in the kernel's own fp32 arithmetic (rint(W * (1 / scale)))
+            qq = torch.round(W * (1.0 / wsc)[:, None])
+            ref = torch.where((qq >= -128) & (qq <= 127), ref, torch.zeros_like(ref))
+        bref = plane.double().sum(0) * 2.0 ** -e / (rdiv.double() if divided else 1.0)
+        keep.append((plane, Q, lut, s1, s2, C, W, wsc, wzp, db, rdiv, C0))
+        refs.append((ref, bref))
+    scratch = torch.empty(native_lib.qatvit_gemm_tn_stream_scratch_bytes(), dtype=torch.uint8, device="cuda")
+
+    def run():
+        native.check(native_lib.qatvit_gemm_tn_stream_dy16(mode, ctypes.cast(items, ctypes.c_void_p), len(shapes), M, center, 1, -128, 127, _ptr(scratch), scratch.numel(),
+                                                           P(native.stream_ptr())), "tn_stream_dy16")
+    run()
+    first = []
+    for (plane, Q, lut, s1, s2, C, W, wsc, wzp, db, rdiv, C0), (ref, bref) in zip(keep, refs):
+        got = (C.double() - C0.double())
+        assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < 3e-5
+        if db is not None:
+            assert rel_l2(db.cpu().numpy(), bref.cpu().numpy()) < 2e-5
+        first.append(C.clone())
+        C.copy_(C0)
+    run()
+    for (_, _, _, _, _, C, *_), f in zip(keep, first):
+        assert torch.equal(C, f), "the split tiles are summed in a fixed order: same bits on a second run"
+
+
 def _pair(seed=0, backend="qnnpack", **kw):
     torch.manual_seed(seed)
     stu = qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True, **kw)

@@ -28,6 +28,9 @@ KNOBS = {
     # the one-plane qkv / fc1 / fc2 weight gradients from the fp16 X plane / the expand-through-LDS kernel instead of k_gemm_tn_q8: the same products
     # (the X integers are exact either way), token splits of 64-token instead of 32-token steps - another fp32 summation order (measured 4e-8)
     "QATVIT_TN_Q8=0": (1e-9, 1e-6),
+    # the one-plane weight gradients as one launch (+ reduction) per GEMM right where the reference computes them instead of one persistent stream-K launch per X form
+    # at the end of the backward call: the same products, accumulated over the whole token range in registers instead of 21 - 85 partial tiles
+    "QATVIT_TN_STREAM=0": (1e-9, 1e-6),
     "QATVIT_LNB_FUSE=0": (1e-6, 5e-6),      # LayerNorm backward as its own kernel (another summation order for dgamma / dbeta)
     # the two-kernel attention backward (k_attn_bwd_dq + k_attn_bwd_dkv) instead of the fused one: the same forward bit for bit (logits: 0), the same
     # products in the backward with delta = rowsum(dO . O) summed in another order
