@@ -2205,7 +2205,7 @@ struct TNStreamItem {
 };
 struct TNStreamArgs {
     TNStreamItem it[kTnStreamMax];
-    int n, M, steps, units_total, units_per_wg, center, w_per_channel, w_qmin, w_qmax;
+    int n, M, steps, steps_pad, units_total, units_per_wg, center, w_per_channel, w_qmin, w_qmax;   // steps_pad: units per tile (>= steps: see launch_tn_stream)
     float* partial;         // [2 * gridDim][8 waves][24 fragments][64 lanes] float4
 };
 
@@ -2213,7 +2213,7 @@ template <int MODE>
 __global__ __launch_bounds__(512) void k_tn_stream(const TNStreamArgs a) {
     constexpr int BN = 128, BKW = 384, BK = 64, NW = 8, TM = 8, TNT = 3;   // one wave row of eight waves, 128 x 48 per wave
     constexpr int QB = MODE == 2 ? 2 : 1;                       // bytes per Q element
-    constexpr int NSTAGE = MODE == 2 ? 2 : 3;
+    constexpr int NSTAGE = MODE == 2 ? 2 : MODE == 0 ? 4 : 3;
     constexpr int IMGP = BK * 256, QROWB = BKW * QB, IMGQ = BK * QROWB, STAGE = IMGP + IMGQ;
     constexpr int PP = IMGP / 1024 / NW, PQ = IMGQ / 1024 / NW, NDMA = PP + PQ;
     constexpr int TAB = NSTAGE * STAGE;
@@ -2233,9 +2233,10 @@ __global__ __launch_bounds__(512) void k_tn_stream(const TNStreamArgs a) {
     for (int u = u_begin; u < u_end;) {
         while (g + 1 < a.n && a.it[g + 1].unit0 <= u) ++g;
         const TNStreamItem& it = a.it[g];
-        const int rel = u - it.unit0, tile = rel / a.steps, s_first = rel % a.steps;
-        const int nsteps = min(a.steps - s_first, u_end - u);
-        const bool complete = s_first == 0 && nsteps == a.steps;
+        const int rel = u - it.unit0, tile = rel / a.steps_pad, s_first = rel % a.steps_pad;
+        const int nunits = min(a.steps_pad - s_first, u_end - u);                 // this segment in units; its real token steps:
+        const int nsteps = max(0, min(a.steps - s_first, nunits));
+        const bool complete = s_first == 0 && nunits == a.steps_pad;
         const int slot = 2 * w + (u == u_begin ? 0 : 1);
         const int tilesK = it.Kw / BKW;
         const int n0 = (tile / tilesK) * BN, k0 = (tile % tilesK) * BKW;
@@ -2358,6 +2359,7 @@ __global__ __launch_bounds__(512) void k_tn_stream(const TNStreamArgs a) {
             else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (s + NSTAGE - 1 < nsteps) issue(s + NSTAGE - 1);
+            if (s == 1 && u == u_begin) QV_NT_STAMP(200 + MODE, 1);
             const char* st = smem + (s % NSTAGE) * STAGE;
             load1(A, st, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -2425,8 +2427,9 @@ __global__ __launch_bounds__(512) void k_tn_stream(const TNStreamArgs a) {
                 }
             }
         }
-        u += nsteps;
+        u += nunits;
     }
+    QV_NT_STAMP(200 + MODE, 3);
 }
 
 // The tiles a span boundary cut: pieces summed in workgroup order, then k_tn_reduce's tail.  One thread per float4 of the accumulator layout; blocks of complete tiles return.
@@ -2438,7 +2441,7 @@ __global__ __launch_bounds__(256) void k_tn_stream_fixup(const TNStreamArgs a, i
     while (g + 1 < a.n && t0 + a.it[g].tiles <= gt) { t0 += a.it[g].tiles; ++g; }
     const TNStreamItem& it = a.it[g];
     const int tile = gt - t0;
-    const int U0 = it.unit0 + tile * a.steps, U1 = U0 + a.steps, q = a.units_per_wg;
+    const int U0 = it.unit0 + tile * a.steps_pad, U1 = U0 + a.steps_pad, q = a.units_per_wg;
     const int w0 = U0 / q, w1 = (U1 - 1) / q;
     if (w0 == w1) return;                                   // one workgroup held the whole tile and finished it
     const int wave = rem / per_wave, f = (rem % per_wave) / 64, lane = rem & 63;
@@ -2470,7 +2473,7 @@ __global__ __launch_bounds__(256) void k_tn_stream_fixup(const TNStreamArgs a, i
     }
 }
 
-int64_t tn_stream_scratch_bytes() { return (int64_t)2 * 256 * 128 * 384 * 4; }   // two raw tiles per workgroup, at most 256 workgroups (one per CU of an MI355X)
+int64_t tn_stream_scratch_bytes() { return (int64_t)2 * 256 * 128 * 384 * 4 + 4096; }   // two raw tiles per workgroup, at most 256 workgroups (one per CU of an MI355X)
 
 // items[0..n): the weight-gradient GEMMs of one X form (mode 0 / 1 / 2 as above), all over the same M token rows.  N % 128 == 0, Kw % 384 == 0.
 int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int center, int w_per_channel, int w_qmin, int w_qmax, float* partial, int64_t partial_bytes,
@@ -2483,7 +2486,17 @@ int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int cent
     }
     TNStreamArgs a{};
     a.n = n; a.M = M; a.steps = (M + 63) / 64; a.center = center; a.w_per_channel = w_per_channel; a.w_qmin = w_qmin; a.w_qmax = w_qmax; a.partial = partial;
-    int units = 0, tiles = 0;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += (items[i].N / 128) * (items[i].Kw / 384);
+    // Span plan.  ALIGNED where whole tiles (x an integer number of token splits) nearly fill the chip: workgroup (tile, split) - the tiles of a GEMM then walk the token
+    // rows in lockstep and share the X rows through their XCD's L2 (with free-running stream-K spans the neighbours drift apart by the span / tile mismatch: the full
+    // backward's 252 grid-X tiles measured 1.85 us per step against 0.97).  Otherwise (144 fc2 tiles on 256 CUs) stream-K spans cut where they fall.
+    const int splits = tiles > 0 && cus / tiles > 0 ? cus / tiles : 1;
+    const bool aligned = tiles > 0 && (int64_t)tiles * splits * 10 >= (int64_t)cus * 9;
+    const int upw_al = (a.steps + splits - 1) / splits;
+    a.steps_pad = aligned ? upw_al * splits : a.steps;
+    int units = 0;
+    tiles = 0;
     for (int i = 0; i < n; ++i) {
         const TNStreamGemm& s = items[i];
         const int qal = mode == 2 ? 8 : 16;
@@ -2494,14 +2507,14 @@ int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int cent
         TNStreamItem& d = a.it[i];
         d.P = s.P; d.Q = s.Q; d.lut = s.lut; d.s1 = s.s1; d.s2 = s.s2; d.C = s.C; d.W = s.W; d.w_scale = s.w_scale; d.w_zp = s.w_zp; d.dbias = s.dbias; d.row_div = s.row_div;
         d.N = s.N; d.Kw = s.Kw; d.ldp = s.ldp; d.ldq = s.ldq; d.ldc = s.ldc; d.tiles = (s.N / 128) * (s.Kw / 384); d.unit0 = units;
-        units += d.tiles * a.steps;
+        units += d.tiles * a.steps_pad;
         tiles += d.tiles;
     }
-    const int grid = units < cus ? units : cus;
+    const int grid = aligned ? tiles * splits : (units < cus ? units : cus);
     a.units_total = units;
-    a.units_per_wg = (units + grid - 1) / grid;
-    if ((int64_t)2 * grid * 128 * 384 * 4 > partial_bytes) { set_error("tn_stream: scratch too small (%lld bytes)", (long long)partial_bytes); return 1; }
-    constexpr size_t lds0 = 3 * (64 * 256 + 64 * 384), lds1 = lds0 + 256 * 32 * 4, lds2 = 2 * (64 * 256 + 64 * 768);
+    a.units_per_wg = aligned ? upw_al : (units + grid - 1) / grid;
+    if ((int64_t)2 * grid * 128 * 384 * 4 + 4096 > partial_bytes) { set_error("tn_stream: scratch too small (%lld bytes)", (long long)partial_bytes); return 1; }
+    constexpr size_t lds0 = 4 * (64 * 256 + 64 * 384), lds1 = 3 * (64 * 256 + 64 * 384) + 256 * 32 * 4, lds2 = 2 * (64 * 256 + 64 * 768);
     static bool once = (allow_lds(k_tn_stream<0>, lds0), allow_lds(k_tn_stream<1>, lds1), allow_lds(k_tn_stream<2>, lds2), true);
     (void)once;
     if (mode == 0) k_tn_stream<0><<<grid, 512, lds0, st>>>(a);
