@@ -2473,7 +2473,7 @@ __global__ __launch_bounds__(256) void k_tn_stream_fixup(const TNStreamArgs a, i
     }
 }
 
-int64_t tn_stream_scratch_bytes() { return (int64_t)2 * 256 * 128 * 384 * 4 + 4096; }   // two raw tiles per workgroup, at most 256 workgroups (one per CU of an MI355X)
+int64_t tn_stream_scratch_bytes() { return (int64_t)2 * 256 * 128 * 384 * 4; }   // two raw tiles per workgroup, at most 256 workgroups (one per CU of an MI355X)
 
 // items[0..n): the weight-gradient GEMMs of one X form (mode 0 / 1 / 2 as above), all over the same M token rows.  N % 128 == 0, Kw % 384 == 0.
 int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int center, int w_per_channel, int w_qmin, int w_qmax, float* partial, int64_t partial_bytes,
@@ -2492,7 +2492,7 @@ int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int cent
     // rows in lockstep and share the X rows through their XCD's L2 (with free-running stream-K spans the neighbours drift apart by the span / tile mismatch: the full
     // backward's 252 grid-X tiles measured 1.85 us per step against 0.97).  Otherwise (144 fc2 tiles on 256 CUs) stream-K spans cut where they fall.
     const int splits = tiles > 0 && cus / tiles > 0 ? cus / tiles : 1;
-    const bool aligned = tiles > 0 && (int64_t)tiles * splits * 10 >= (int64_t)cus * 9;
+    const bool aligned = tiles > 0 && tiles <= cus && (int64_t)tiles * splits * 10 >= (int64_t)cus * 9;   // (more tiles than CUs: free spans over one workgroup per CU)
     const int upw_al = (a.steps + splits - 1) / splits;
     a.steps_pad = aligned ? upw_al * splits : a.steps;
     int units = 0;
@@ -2513,7 +2513,7 @@ int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int cent
     const int grid = aligned ? tiles * splits : (units < cus ? units : cus);
     a.units_total = units;
     a.units_per_wg = aligned ? upw_al : (units + grid - 1) / grid;
-    if ((int64_t)2 * grid * 128 * 384 * 4 + 4096 > partial_bytes) { set_error("tn_stream: scratch too small (%lld bytes)", (long long)partial_bytes); return 1; }
+    if ((int64_t)2 * grid * 128 * 384 * 4 > partial_bytes) { set_error("tn_stream: scratch too small (%lld bytes)", (long long)partial_bytes); return 1; }
     constexpr size_t lds0 = 4 * (64 * 256 + 64 * 384), lds1 = 3 * (64 * 256 + 64 * 384) + 256 * 32 * 4, lds2 = 2 * (64 * 256 + 64 * 768);
     static bool once = (allow_lds(k_tn_stream<0>, lds0), allow_lds(k_tn_stream<1>, lds1), allow_lds(k_tn_stream<2>, lds2), true);
     (void)once;
