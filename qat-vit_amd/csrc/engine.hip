@@ -94,7 +94,7 @@ static bool tn_stream_on() {
     return on;
 }
 static bool tn_stream_planes(const qatvit_cfg& c) {
-    return tn_stream_on() && c.embed_dim % 384 == 0 && c.mlp_hidden % 384 == 0 && c.depth * 2 <= 24 * 8;
+    return tn_stream_on() && c.embed_dim % 384 == 0 && c.mlp_hidden % 384 == 0;
 }
 
 static int make_plan(const qatvit_cfg& c, Plan* p) {
