@@ -282,3 +282,33 @@ def test_unsupported_configuration_keeps_the_pair_form(native_lib):
     ea = E.engine_of(a)
     assert not ea.dy16 and not ea._fwd_x16
     assert ea.lib.qatvit_student_dy16_supported(ctypes.byref(ea.cfg)) == 0
+
+
+def test_training_trajectory_one_plane_tracks_the_pair_form(native_lib):
+    """Ten optimizer steps (clip + AdamW, warm-up learning rates, a fresh batch every step) on two copies of a ViT-S-width depth-2 student: one-plane backward with the
+    deferred stream-K weight gradients against the pair form.  The delayed scales must follow gradients that change with the weights and the data (no fallback after the
+    calibrating step), every gradient stays finite, and the two loss curves stay together (fake-quant is discontinuous: not bit for bit - the bar is 2e-2 in the loss)."""
+    from qat_vit_amd.optim import ClipAdamW
+
+    a, b = _pair(11, depth=2)
+    g = torch.Generator().manual_seed(12)
+    ea, eb = E.bind(a, 16), E.bind(b, 16)
+    eb.dy16 = False
+    oa, ob = ClipAdamW(a.parameters(), lr=1e-3, weight_decay=1e-2), ClipAdamW(b.parameters(), lr=1e-3, weight_decay=1e-2)
+    la, lb = [], []
+    for k in range(10):
+        x = torch.randn(16, 3, 224, 224, generator=g).cuda() * (1.0 + 0.2 * k)     # the input scale drifts too
+        y = torch.randint(0, 10, (16,), generator=g).cuda()
+        for grp in list(oa.param_groups) + list(ob.param_groups):
+            grp["lr"] = 1e-3 * min(1.0, (k + 1) / 4)
+        for m, o, ls in ((a, oa, la), (b, ob, lb)):
+            o.zero_grad(set_to_none=True)
+            loss, _ = F.kd_ce_loss(m(x), None, y, 4.0, 0.5, 0.1)
+            loss.backward()
+            assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+            o.step(max_norm=1.0)
+            ls.append(loss.item())
+    assert ea._fwd_x16 and ea.dy16_fallbacks == 0, ea.dy16_fallbacks
+    worst = max(abs(u - v) for u, v in zip(la, lb))
+    print("loss, one-plane:", [round(v, 4) for v in la], "pair form:", [round(v, 4) for v in lb], "worst difference", worst)
+    assert worst < 2e-2, (la, lb)
