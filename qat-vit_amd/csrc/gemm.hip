@@ -2205,7 +2205,7 @@ struct TNStreamItem {
 };
 struct TNStreamArgs {
     TNStreamItem it[kTnStreamMax];
-    int n, M, steps, steps_pad, units_total, units_per_wg, center, w_per_channel, w_qmin, w_qmax;   // steps_pad: units per tile (>= steps: see launch_tn_stream)
+    int n, M, steps, steps_pad, units_total, units_per_wg, rounds, center, w_per_channel, w_qmin, w_qmax;   // rounds > 1: whole tiles round-robin (span v = w + r * gridDim)   // steps_pad: units per tile (>= steps: see launch_tn_stream)
     float* partial;         // [2 * gridDim][8 waves][24 fragments][64 lanes] float4
 };
 
@@ -2222,7 +2222,6 @@ __global__ __launch_bounds__(512) void k_tn_stream(const TNStreamArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave;
     const int w = xcd_remap(blockIdx.x, gridDim.x);
-    const int u_begin = w * a.units_per_wg, u_end = min(a.units_total, u_begin + a.units_per_wg);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     f16x8 ones;
 #pragma unroll
@@ -2230,6 +2229,8 @@ __global__ __launch_bounds__(512) void k_tn_stream(const TNStreamArgs a) {
     const uint32_t tab_lane = (uint32_t)(TAB + (lane & 31) * 4);
     struct Ops { f16x8 pf[TM]; f16x8 pb; uint2 qb[MODE == 2 ? 1 : TNT]; uint32_t v[MODE == 1 ? TNT * 8 : 1]; f16x8 qf[TNT]; };
     int g = 0, lut_of = -1;
+    for (int rr = 0; rr < a.rounds; ++rr) {
+    const int u_begin = min(a.units_total, (w + rr * (int)gridDim.x) * a.units_per_wg), u_end = min(a.units_total, u_begin + a.units_per_wg);
     for (int u = u_begin; u < u_end;) {
         while (g + 1 < a.n && a.it[g + 1].unit0 <= u) ++g;
         const TNStreamItem& it = a.it[g];
@@ -2429,6 +2430,7 @@ __global__ __launch_bounds__(512) void k_tn_stream(const TNStreamArgs a) {
         }
         u += nunits;
     }
+    }
     QV_NT_STAMP(200 + MODE, 3);
 }
 
@@ -2492,7 +2494,12 @@ int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int cent
     // rows in lockstep and share the X rows through their XCD's L2 (with free-running stream-K spans the neighbours drift apart by the span / tile mismatch: the full
     // backward's 252 grid-X tiles measured 1.85 us per step against 0.97).  Otherwise (144 fc2 tiles on 256 CUs) stream-K spans cut where they fall.
     const int splits = tiles > 0 && cus / tiles > 0 ? cus / tiles : 1;
-    const bool aligned = tiles > 0 && tiles <= cus && (int64_t)tiles * splits * 10 >= (int64_t)cus * 9;   // (more tiles than CUs: free spans over one workgroup per CU)
+    // More tiles than CUs (ViT-B: 1008): whole tiles round-robin, round r = tiles r * cus .. - every round starts its tiles together (lockstep sharing as in the aligned
+    // plan, no cut tile); taken when the last round is at least 60 % full or there are >= 3 rounds (QATVIT_TN_STREAM_RR=0: free spans)
+    static const bool rr_on = !(getenv("QATVIT_TN_STREAM_RR") && atoi(getenv("QATVIT_TN_STREAM_RR")) == 0);
+    const int rr_rounds = (tiles + cus - 1) / cus;
+    const bool rr = rr_on && tiles > cus && ((int64_t)tiles * 10 >= (int64_t)rr_rounds * cus * 8);
+    const bool aligned = rr || (tiles > 0 && tiles <= cus && (int64_t)tiles * splits * 10 >= (int64_t)cus * 9);
     const int upw_al = (a.steps + splits - 1) / splits;
     a.steps_pad = aligned ? upw_al * splits : a.steps;
     int units = 0;
@@ -2510,9 +2517,10 @@ int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int cent
         units += d.tiles * a.steps_pad;
         tiles += d.tiles;
     }
-    const int grid = aligned ? tiles * splits : (units < cus ? units : cus);
+    const int grid = rr ? cus : aligned ? tiles * splits : (units < cus ? units : cus);
     a.units_total = units;
     a.units_per_wg = aligned ? upw_al : (units + grid - 1) / grid;
+    a.rounds = rr ? rr_rounds : 1;
     if ((int64_t)2 * grid * 128 * 384 * 4 > partial_bytes) { set_error("tn_stream: scratch too small (%lld bytes)", (long long)partial_bytes); return 1; }
     constexpr size_t lds0 = 4 * (64 * 256 + 64 * 384), lds1 = 3 * (64 * 256 + 64 * 384) + 256 * 32 * 4, lds2 = 2 * (64 * 256 + 64 * 768);
     static bool once = (allow_lds(k_tn_stream<0>, lds0), allow_lds(k_tn_stream<1>, lds1), allow_lds(k_tn_stream<2>, lds2), true);
