@@ -8,5 +8,5 @@ trap 'cp ab/libqatvit_ship.so qat-vit_amd/libqatvit.so' EXIT
 for m in "$@"; do
   cp ab/libqatvit_st$m.so qat-vit_amd/libqatvit.so
   echo "== stamps of mode $m"
-  STAMP_STEPS=60 timeout -k 10 300 python3 tools/stamp_nt.py 2>/dev/null | grep -v '^{' | grep -E "workgroups|block 0 wave [04]:|k-loop" | cut -c1-250 | head -6
+  STAMP_STEPS=60 timeout -k 10 300 python3 tools/stamp_nt.py 2>/dev/null | grep -v '^{' | grep -E "workgroups|block 0 wave [04]:|k-loop" | cut -c1-250 | head -7
 done
