@@ -286,30 +286,33 @@ def test_unsupported_configuration_keeps_the_pair_form(native_lib):
 
 
 def test_training_trajectory_one_plane_tracks_the_pair_form(native_lib):
-    """Ten optimizer steps (clip + AdamW, warm-up learning rates, a fresh batch every step) on two copies of a ViT-S-width depth-2 student: one-plane backward with the
-    deferred stream-K weight gradients against the pair form.  The delayed scales must follow gradients that change with the weights and the data (no fallback after the
-    calibrating step), every gradient stays finite, and the two loss curves stay together (fake-quant is discontinuous: not bit for bit - the bar is 2e-2 in the loss)."""
+    """Ten optimizer steps (clip + AdamW, warm-up learning rates, a fresh batch every step, an input scale that drifts) of a ViT-S-width depth-2 student in the pair form;
+    at every step a second copy with the SAME weights and observer state runs the one-plane backward with the deferred stream-K weight gradients: the delayed scales must
+    follow gradients that change with the weights and the data (no fallback after the calibrating step) and every parameter gradient stays within 1e-3 of the pair form's.
+    (The copy is re-synchronised after every step: fake-quant is discontinuous, two free-running trajectories separate at the first flipped code - seen: 3.6e-3 in the loss
+    after ten steps in one run, 0.33 in another.)"""
     from qat_vit_amd.optim import ClipAdamW
 
     a, b = _pair(11, depth=2)
     g = torch.Generator().manual_seed(12)
     ea, eb = E.bind(a, 16), E.bind(b, 16)
     eb.dy16 = False
-    oa, ob = ClipAdamW(a.parameters(), lr=1e-3, weight_decay=1e-2), ClipAdamW(b.parameters(), lr=1e-3, weight_decay=1e-2)
-    la, lb = [], []
+    ob = ClipAdamW(b.parameters(), lr=1e-3, weight_decay=1e-2)
+    worst, worst_at = 0.0, ""
     for k in range(10):
         x = torch.randn(16, 3, 224, 224, generator=g).cuda() * (1.0 + 0.2 * k)     # the input scale drifts too
         y = torch.randint(0, 10, (16,), generator=g).cuda()
-        for grp in list(oa.param_groups) + list(ob.param_groups):
+        for grp in ob.param_groups:
             grp["lr"] = 1e-3 * min(1.0, (k + 1) / 4)
-        for m, o, ls in ((a, oa, la), (b, ob, lb)):
-            o.zero_grad(set_to_none=True)
-            loss, _ = F.kd_ce_loss(m(x), None, y, 4.0, 0.5, 0.1)
-            loss.backward()
-            assert all(torch.isfinite(p.grad).all() for p in m.parameters())
-            o.step(max_norm=1.0)
-            ls.append(loss.item())
+        oa_, ob_ = _step(a, x, y), _step(b, x, y)
+        assert torch.equal(oa_, ob_), k
+        for (n, p), q in zip(a.named_parameters(), b.parameters()):
+            assert torch.isfinite(p.grad).all(), (k, n)
+            e = rel_l2(p.grad.cpu().numpy(), q.grad.cpu().numpy())
+            if k > 0 and e > worst:
+                worst, worst_at = e, f"{n} (step {k})"
+        ob.step(max_norm=1.0)
+        a.load_state_dict(b.state_dict())            # same weights, same observer state for the next step (in place: the engine keeps its pointers)
     assert ea._fwd_x16 and ea.dy16_fallbacks == 0, ea.dy16_fallbacks
-    worst = max(abs(u - v) for u, v in zip(la, lb))
-    print("loss, one-plane:", [round(v, 4) for v in la], "pair form:", [round(v, 4) for v in lb], "worst difference", worst)
-    assert worst < 2e-2, (la, lb)
+    print(f"one-plane vs pair form over ten training steps, worst parameter gradient rel L2: {worst:.2e} at {worst_at}")
+    assert 1e-6 < worst < 1e-3, (worst, worst_at)
