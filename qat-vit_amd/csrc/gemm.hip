@@ -2490,6 +2490,21 @@ int launch_tn_stream(int mode, const TNStreamGemm* items, int n, int M, int cent
     a.n = n; a.M = M; a.steps = (M + 63) / 64; a.center = center; a.w_per_channel = w_per_channel; a.w_qmin = w_qmin; a.w_qmax = w_qmax; a.partial = partial;
     int tiles = 0;
     for (int i = 0; i < n; ++i) tiles += (items[i].N / 128) * (items[i].Kw / 384);
+    {   // A batch whose tiles do not tile the chip in lockstep (144 fc2 tiles on 256 CUs) as TWO aligned launches where a cut exists: free spans share nothing through L2
+        // (the fc2 launch fetched 4.7 GB for 1.4 GB of operands).  k GEMMs x s1 splits and n - k GEMMs x s2 splits, both >= 90 % of the CUs.
+        static const bool split2 = !(getenv("QATVIT_TN_STREAM_SPLIT2") && atoi(getenv("QATVIT_TN_STREAM_SPLIT2")) == 0);
+        auto fill_ok = [&](int t) { const int sp = t > 0 && cus / t > 0 ? cus / t : 1; return t > 0 && t <= cus && (int64_t)t * sp * 10 >= (int64_t)cus * 9; };
+        if (split2 && n >= 2 && tiles <= cus && !fill_ok(tiles)) {
+            int t1 = 0;
+            for (int k = 1; k < n; ++k) {
+                t1 += (items[k - 1].N / 128) * (items[k - 1].Kw / 384);
+                if (fill_ok(t1) && fill_ok(tiles - t1)) {
+                    if (launch_tn_stream(mode, items, k, M, center, w_per_channel, w_qmin, w_qmax, partial, partial_bytes, st)) return 1;
+                    return launch_tn_stream(mode, items + k, n - k, M, center, w_per_channel, w_qmin, w_qmax, partial, partial_bytes, st);
+                }
+            }
+        }
+    }
     // Span plan.  ALIGNED where whole tiles (x an integer number of token splits) nearly fill the chip: workgroup (tile, split) - the tiles of a GEMM then walk the token
     // rows in lockstep and share the X rows through their XCD's L2 (with free-running stream-K spans the neighbours drift apart by the span / tile mismatch: the full
     // backward's 252 grid-X tiles measured 1.85 us per step against 0.97).  Otherwise (144 fc2 tiles on 256 CUs) stream-K spans cut where they fall.
