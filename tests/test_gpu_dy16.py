@@ -126,6 +126,7 @@ def test_wgrad_one_plane_byte_grid_vs_fp64(native_lib, M, N, Kw, center, zp):
 @pytest.mark.parametrize("M,shapes", [(640, [(1536, 384)] * 12 + [(1152, 384)] * 10 + [(384, 768)] * 2),      # 282 tiles of 10 steps: whole tiles in registers AND cut tiles
                                       (640, [(1536, 384)] * 24),                                                # 288 tiles: more tiles than CUs, last round 12 % full - free spans over one workgroup per CU
                                       (640, [(2560, 384)] * 24),                                                # 480 tiles: whole tiles round-robin over two rounds
+                                      (1280, [(384, 1536)] * 12),                                               # 144 tiles (the fc2 batch): two aligned launches, 7 x 3 + 5 x 4 splits
                                       (6400, [(1536, 384), (1152, 384), (384, 384)]),                           # 24 tiles of 100 steps on ~256 workgroups: every tile cut ~10 times
                                       (25216, [(384, 1536), (128, 384)])])                                      # Kw tiles; a one-tile GEMM at the end
 def test_wgrad_stream_batch_vs_fp64(native_lib, mode, M, shapes):
