@@ -300,6 +300,11 @@ int qatvit_student_backward(const qatvit_cfg* cfg, void* const* params, const qa
 #define QATVIT_BWD_CALIBRATE 4  /* backward: the pair form, recording the maxima the next one-plane backward scales by (the forward ran WITHOUT QATVIT_FWD_X16) */
 int32_t qatvit_student_dy16_supported(const qatvit_cfg* cfg);
 /* h1q / h2q of every block from fp16 integers back to bf16 integers, in place (fallback after an overflow: the pair form reads bf16) */
+/* Host mirror of the one-plane backward's overflow flag: host_pinned = int32[2] in pinned host memory (hipHostMalloc / torch pin_memory), NULL to remove it.  Every
+ * backward call then writes {overflow flag, generation} there - the generation (a counter that changes with every call) after the flag, system scope - as soon as the
+ * gradient planes' maxima are known, i.e. BEFORE the call's deferred weight gradients run: a host that polls the generation instead of synchronising with the stream can
+ * queue the next step 2 - 3 ms earlier.  qatvit_student_init clears the mirror. */
+int qatvit_student_dy16_set_mirror(const qatvit_cfg* cfg, void* workspace, void* host_pinned, void* stream);
 int qatvit_student_dy16_to_pair(const qatvit_cfg* cfg, void* workspace, void* stream);
 int qatvit_student_forward_stages(const qatvit_cfg* cfg, void* const* params, const qatvit_fq* act_fq, const qatvit_fq* weight_fq,
                                   const float* images, float* logits, void* workspace, int32_t stage_from, int32_t stage_to, int32_t flags,

@@ -56,7 +56,27 @@ __global__ __launch_bounds__(256) void k_dy16_end(uint32_t* __restrict__ st, int
         const float am = __builtin_bit_cast(float, m), mul = __builtin_bit_cast(float, s[1]);
         if (check && !(am * mul <= 65504.0f)) atomicOr(&st[2], 1u);   // (a NaN maximum fails the comparison too)
     }
-    if (threadIdx.x == 0) st[0] = st[1];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st[0] = st[1];
+        // the host's mirror (header words 4 - 6: pinned-memory pointer, generation): the overflow flag, then - after a system-scope fence - a new generation number.
+        // The host polls the generation instead of synchronising with the stream: this kernel runs BEFORE the call's deferred weight gradients, so the host knows 2 - 3 ms
+        // before the backward is over that it may queue the next step behind it (measured: 0.7 - 1.1 ms of GPU idle per step with a stream synchronisation here).
+        uint32_t* const mirror = *reinterpret_cast<uint32_t* const*>(st + 4);
+        if (mirror) {
+            const uint32_t gen = st[6] + 1u;
+            st[6] = gen;
+            __hip_atomic_store(mirror, __hip_atomic_load(&st[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __atomic_thread_fence(__ATOMIC_RELEASE);      // (system scope: the store above is visible to the host before the one below)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(mirror + 1, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ void k_dy16_set_mirror(uint32_t* __restrict__ st, uint32_t* mirror) {
+    *reinterpret_cast<uint32_t**>(st + 4) = mirror;
+    st[6] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_absmax_bf16(const uint4* __restrict__ hi, int64_t n8, uint32_t* __restrict__ amax) {
@@ -108,6 +128,16 @@ int launch_dy16_begin(uint32_t* state, int nslots, const float* dlogits, int n_d
 }
 int launch_dy16_end(uint32_t* state, int nslots, int check_overflow, hipStream_t st) {
     k_dy16_end<<<1, 256, 0, st>>>(state, nslots, check_overflow);
+    return 0;
+}
+int launch_dy16_set_mirror(uint32_t* state, void* host_pinned, hipStream_t st) {
+    void* dptr = nullptr;
+    if (host_pinned && hipHostGetDevicePointer(&dptr, host_pinned, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("dy16_set_mirror: the pointer is not pinned host memory the device can address");
+        return 1;
+    }
+    k_dy16_set_mirror<<<1, 1, 0, st>>>(state, reinterpret_cast<uint32_t*>(dptr));
     return 0;
 }
 int launch_absmax_bf16(const void* hi, int64_t n, uint32_t* amax, hipStream_t st) {

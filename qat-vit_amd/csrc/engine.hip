@@ -986,6 +986,9 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
                 return 1;
         }
     }
+    // (the scale bookkeeping and the overflow flag first: they depend on the producers of the planes only, and the host's mirror of the flag - qatvit_student_dy16_set_mirror -
+    //  is written here, 2 - 3 ms before the deferred weight gradients below are done)
+    if (dy || cal) launch_dy16_end(dystate, nslots, dy ? 1 : 0, st);
     for (int m = 0; m < 3; ++m) {   // the collected weight gradients: one persistent launch (+ its fix-up) per X form and <= 24 GEMMs
         for (size_t o = 0; o < sg[m].size(); o += 24) {
             const int n = (int)std::min<size_t>(24, sg[m].size() - o);
@@ -993,7 +996,6 @@ static int bwd(const Ctx& x, const float* dlogits, void* const* grads, int stage
             if (launch_tn_stream(m, sg[m].data() + o, n, M, x.center(), c.w_per_channel, c.w_qmin, c.w_qmax, x.at<float>(p.tn_stream), tn_stream_scratch_bytes(), st)) return 1;
         }
     }
-    if (dy || cal) launch_dy16_end(dystate, nslots, dy ? 1 : 0, st);
     return 0;
 }
 
@@ -1111,6 +1113,16 @@ int32_t qatvit_student_dy16_supported(const qatvit_cfg* cfg) {
     Ctx x{*cfg, dims_of(*cfg), Plan(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (make_plan(*cfg, &x.p)) return 0;
     return dy16_supported(x) ? 1 : 0;
+}
+
+int qatvit_student_dy16_set_mirror(const qatvit_cfg* cfg, void* workspace, void* host_pinned, void* stream) {
+    QV_CHECK_ARG(cfg && workspace, "qatvit_student_dy16_set_mirror: null argument");
+    if (check_cfg(*cfg)) return 1;
+    Plan p;
+    if (make_plan(*cfg, &p)) return 1;
+    if (launch_dy16_set_mirror(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + p.dy16), host_pinned, (hipStream_t)stream)) return 1;
+    QV_CHECK_LAUNCH("qatvit_student_dy16_set_mirror");
+    return 0;
 }
 
 int qatvit_student_dy16_to_pair(const qatvit_cfg* cfg, void* workspace, void* stream) {

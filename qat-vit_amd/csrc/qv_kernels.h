@@ -235,6 +235,7 @@ int launch_wquant(const float* W, const float* qp, int per_channel, int qmin, in
 constexpr int kDyHdrWords = 64, kDySlotWords = 256, kDyAmaxStride = 32, kDyAmaxSlots = 8;
 inline int64_t dy16_state_bytes(int nslots) { return 4ll * (kDyHdrWords + (int64_t)nslots * kDySlotWords); }
 int launch_dy16_begin(uint32_t* state, int nslots, const float* dlogits, int n_dlogits, hipStream_t st);   // dlogits == nullptr: no rescaling
+int launch_dy16_set_mirror(uint32_t* state, void* host_pinned, hipStream_t st);   // pinned int32[2] {overflow flag, generation} written by k_dy16_end (nullptr: none)
 int launch_dy16_end(uint32_t* state, int nslots, int check_overflow, hipStream_t st);
 int launch_absmax_bf16(const void* hi, int64_t n, uint32_t* amax, hipStream_t st);      // calibration: max |hi part| of a bf16 (hi, lo) pair, n % 8 == 0
 int launch_q8_to_bf16int(const void* q8, const float* qp, int center, void* plane, int64_t n, hipStream_t st);

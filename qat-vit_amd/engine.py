@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 import warnings
 import weakref
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -254,6 +255,11 @@ class StudentEngine:
         self._dy16_calibrated = False
         self._fwd_x16 = False                    # how the most recent forward wrote h1q / h2q
         self.dy16_fallbacks = 0                  # backward passes repeated in the pair form after an overflow
+        # host mirror of the overflow flag (include/qatvit.h, qatvit_student_dy16_set_mirror): pinned int32 {flag, generation} the backward writes before its deferred
+        # weight gradients; the single-GPU backward polls it instead of synchronising with the stream.  QATVIT_DY16_MIRROR=0: the stream synchronisation.
+        self._mirror = self._mirror_np = None
+        self._mirror_on = os.environ.get("QATVIT_DY16_MIRROR", "1") != "0"
+        self._gen_issued = 0                     # backward calls issued since the mirror was (re)installed: the generation the device will have written after them
         self._reserve(batch)
         # ---- flat gradient buffer, laid out in backward-stage order so that finished buckets are contiguous
         self.layout = FlatGradLayout([p.numel() for p in ps], self.cfg.depth)
@@ -302,6 +308,29 @@ class StudentEngine:
         self._dy16_calibrated = False
         off = L.qatvit_student_tensor_offset(cp, b"dy16", 0)
         self._dy16_flag = self.workspace[off + 8:off + 12].view(torch.int32)   # header word 2: overflow
+        self._install_mirror(cp)
+
+    def _install_mirror(self, cp) -> None:
+        self._mirror = self._mirror_np = None
+        self._gen_issued = 0
+        if not (self._mirror_on and self.dy16):
+            return
+        try:
+            m = torch.zeros(2, dtype=torch.int32).pin_memory()
+        except RuntimeError:
+            return
+        if self.lib.qatvit_student_dy16_set_mirror(cp, self.workspace.data_ptr(), m.data_ptr(), native.stream_ptr()) != 0:
+            return                               # (not device-addressable here: the stream synchronisation stays)
+        self._mirror, self._mirror_np = m, m.numpy()
+
+    def _mirror_wait(self) -> Optional[bool]:
+        """Wait until the device has written the flag of the last issued backward call; None if it does not show up (the caller synchronises instead)."""
+        m, want, t0 = self._mirror_np, self._gen_issued & 0xffffffff, time.perf_counter()
+        while ((int(m[1]) - want) & 0xffffffff) >= 0x80000000:      # generation still behind the one this call writes
+            if time.perf_counter() - t0 > 10.0:
+                return None
+            time.sleep(0)
+        return bool(int(m[0]))
 
     # ------------------------------------------------------------------ FQ state arena
     def _rehome_fq_state(self):
@@ -373,6 +402,8 @@ class StudentEngine:
         def run(s0, s1):
             native.check(L.qatvit_student_backward_stages(cp, self._ptr_params, self._act_structs, self._w_structs, dlogits.data_ptr(), gptr,
                                                           self.workspace.data_ptr(), s0, s1, flags, st), "qatvit_student_backward")
+            if flags & (BWD_DY16 | BWD_CALIBRATE):
+                self._gen_issued += 1            # (every such call ends with k_dy16_end: one generation of the mirror)
 
         if self.pg is None:
             run(0, self.layout.last_stage)
@@ -387,7 +418,10 @@ class StudentEngine:
         if self.pg is not None:
             flag = flag.clone()
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.pg)
-        return bool(flag.item())
+        over = bool(flag.item())
+        if self._mirror_np is not None:          # the stream is drained: whatever wrote generations without this object counting (a hipGraph replay) is accounted for
+            self._gen_issued = int(self._mirror_np[1]) & 0xffffffff
+        return over
 
     def backward(self, dlogits: torch.Tensor, cfg: Optional[native.Cfg] = None, x16: Optional[bool] = None):
         c = cfg if cfg is not None else self.cfg
@@ -402,7 +436,12 @@ class StudentEngine:
         views = self._run_backward(dlogits, c, BWD_DY16)
         if torch.cuda.is_current_stream_capturing():    # a hipGraph capture cannot ask: GraphedStudentStep checks after each replay
             return views
-        if self.dy16_overflowed():
+        over = None
+        if self._mirror_np is not None and self.pg is None:
+            over = self._mirror_wait()           # the flag as soon as the device knows it: the deferred weight gradients are still running, the host goes on
+        if over is None:
+            over = self.dy16_overflowed()
+        if over:
             views = self.dy16_fallback(dlogits, c)
         return views
 
@@ -457,6 +496,8 @@ class StudentEngine:
         native.check(self.lib.qatvit_student_backward_stages(
             ctypes.byref(c), self._ptr_params, self._act_structs, self._w_structs, dlogits.contiguous().data_ptr() if dlogits is not None else None,
             gptr, self.workspace.data_ptr(), stage_from, stage_to, (STAGE_INJECT if inject else 0) | mode, native.stream_ptr()), "qatvit_student_backward_stages")
+        if mode & (BWD_DY16 | BWD_CALIBRATE):
+            self._gen_issued += 1
         return views
 
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "qatvit_student_tensor_offset": (c_int64, [c_void_p, c_char_p, c_int32]),
     "qatvit_student_dy16_supported": (c_int32, [c_void_p]),
     "qatvit_student_dy16_to_pair": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "qatvit_student_dy16_set_mirror": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "qatvit_teacher_workspace_bytes": (c_int64, [c_void_p]),
     "qatvit_teacher_forward": (c_int, [c_void_p] * 8),
     "qatvit_teacher_forward_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
