@@ -260,6 +260,7 @@ class StudentEngine:
         self._mirror = self._mirror_np = None
         self._mirror_on = os.environ.get("QATVIT_DY16_MIRROR", "1") != "0"
         self._gen_issued = 0                     # backward calls issued since the mirror was (re)installed: the generation the device will have written after them
+        self._agree_store, self._agree_round = None, 0   # (data-parallel: enable_data_parallel)
         self._reserve(batch)
         # ---- flat gradient buffer, laid out in backward-stage order so that finished buckets are contiguous
         self.layout = FlatGradLayout([p.numel() for p in ps], self.cfg.depth)
@@ -354,6 +355,47 @@ class StudentEngine:
         self.bucket_bytes = bucket_bytes
         for p in self.params:  # replicas start identical (DDP's constructor broadcast)
             dist.broadcast(p.data, src=0, group=self.pg)
+        # The ranks must agree on the overflow flag of a one-plane backward (all repeat it, with its collectives, or none does).  A one-element MAX all-reduce on the
+        # stream is known only when the whole backward is over - the host would come back to an idle GPU (0.6 ms per step).  With the pinned mirror every rank knows its
+        # own flag 2 - 3 ms earlier; they agree through the c10d key-value store the group was set up with (two counters per step: arrivals, overflows) while the GPUs
+        # still run the weight gradients.  QATVIT_DY16_STORE_AGREE=0 (or a store that is not reachable): the all-reduce.
+        self._agree_store, self._agree_round = None, 0
+        ranks = dist.get_process_group_ranks(self.pg)
+        tag = torch.tensor([id(self) & 0x7fffffff], dtype=torch.int64, device=self.device)
+        dist.broadcast(tag, src=ranks[0], group=self.pg)                    # one name for this engine's keys on every rank
+        if os.environ.get("QATVIT_DY16_STORE_AGREE", "1") != "0":
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+                self._agree_store = dist.PrefixStore(f"qatvit_dy16/{int(tag.item())}/{'-'.join(map(str, ranks))}", _get_default_store())
+                self._agree_store.add("probe", 0)
+            except Exception:  # noqa: BLE001
+                self._agree_store = None
+        can = torch.tensor([1 if self._agree_store is not None else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(can, op=dist.ReduceOp.MIN, group=self.pg)       # the store path on every rank or on none
+        if int(can.item()) == 0:
+            self._agree_store = None
+
+    def _agree_overflow(self, local: bool) -> bool:
+        """MAX over the group's ranks of the local overflow flags, through the key-value store (host only; every rank calls it once per one-plane backward)."""
+        st, k, world = self._agree_store, self._agree_round, dist.get_world_size(self.pg)
+        self._agree_round += 1
+        if local:
+            st.add(f"o{k}", 1)
+        n = st.add(f"a{k}", 1)                    # (after this rank's overflow count: once all have arrived every count is in)
+        t0 = time.perf_counter()
+        while n < world:
+            if time.perf_counter() - t0 > 60.0:
+                raise RuntimeError("one-plane backward: a rank of the data-parallel group did not report its overflow flag within 60 s")
+            time.sleep(0)
+            n = st.add(f"a{k}", 0)
+        over = st.add(f"o{k}", 0) > 0
+        if k >= 2 and dist.get_rank(self.pg) == 0:   # round k - 2 is behind every rank (each passed round k - 1 to get here)
+            for key in (f"a{k - 2}", f"o{k - 2}"):
+                try:
+                    st.delete_key(key)
+                except Exception:  # noqa: BLE001
+                    pass
+        return over
 
     def _broadcast_fq_state(self):
         broadcast_fq_state(self.fq_arena, self.pg)
@@ -437,8 +479,12 @@ class StudentEngine:
         if torch.cuda.is_current_stream_capturing():    # a hipGraph capture cannot ask: GraphedStudentStep checks after each replay
             return views
         over = None
-        if self._mirror_np is not None and self.pg is None:
-            over = self._mirror_wait()           # the flag as soon as the device knows it: the deferred weight gradients are still running, the host goes on
+        if self.pg is None:
+            if self._mirror_np is not None:
+                over = self._mirror_wait()       # the flag as soon as the device knows it: the deferred weight gradients are still running, the host goes on
+        elif self._agree_store is not None:      # (agreed on by the whole group in enable_data_parallel: every rank comes here or none)
+            local = self._mirror_wait() if self._mirror_np is not None else None
+            over = self._agree_overflow(bool(self._dy16_flag.item()) if local is None else local)
         if over is None:
             over = self.dy16_overflowed()
         if over:

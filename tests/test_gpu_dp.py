@@ -141,3 +141,86 @@ def test_engine_two_ranks_one_gpu(native_lib):
     for p in procs:
         p.join(60)
     assert all(ok for _, ok, _ in res), res
+
+
+def _worker_dy16(rank, world, port, q):
+    """Two ranks, a configuration the one-plane backward covers: calibrating step, one-plane step, then the scale history is wrecked on rank 1 ONLY - both ranks must
+    repeat that backward in the pair form (they agree on the flag through the c10d store, each from its pinned mirror) and end up with the same averaged gradients."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import ctypes
+        import warnings
+        import qat_vit_amd
+        from qat_vit_amd import functional as F
+        from qat_vit_amd.engine import engine_of
+        from tests.util import prepare
+
+        torch.manual_seed(5)
+        dp = prepare(qat_vit_amd.create_student("vit", num_classes=10, qat_wrapper=True, depth=2).cuda(), "qnnpack")
+        g = torch.Generator().manual_seed(200 + rank)
+        x = torch.randn(4, 3, 224, 224, generator=g).cuda()
+        y = torch.randint(0, 10, (4,), generator=g).cuda()
+        with torch.no_grad():
+            dp(x)
+        eng = engine_of(dp)
+        eng.enable_data_parallel(bucket_bytes=4 << 20)
+        msgs = []
+        ok = eng.dy16 and eng._agree_store is not None and eng._mirror_np is not None
+        if not ok:
+            msgs.append(f"dy16 {eng.dy16} store {eng._agree_store is not None} mirror {eng._mirror_np is not None}")
+
+        def step():
+            for t in dp.parameters():
+                t.grad = None
+            loss, _ = F.kd_ce_loss(dp(x), None, y, 4.0, 0.5, 0.1)
+            loss.backward()
+            torch.cuda.synchronize()
+
+        step(); step()                                       # calibrate, one-plane
+        ok &= eng._fwd_x16 and eng.dy16_fallbacks == 0
+        if rank == 1:                                        # every tensor's previous maximum 2^-60 on this rank: its planes overflow
+            c = eng.cfg
+            off = eng.lib.qatvit_student_tensor_offset(ctypes.byref(c), b"dy16", 0)
+            st = eng.workspace[off:off + 4 * (64 + 256 * 4 * c.depth)].view(torch.float32)
+            for t in range(4 * c.depth):
+                st[64 + 256 * t + 3] = 2.0 ** -60
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            step()
+        if eng.dy16_fallbacks != 1:
+            ok = False
+            msgs.append(f"rank {rank}: fallbacks {eng.dy16_fallbacks} (every rank must repeat the backward)")
+        flat = torch.cat([p.grad.detach().flatten() for p in dp.parameters()]).cpu()
+        if not torch.isfinite(flat).all():
+            ok = False
+            msgs.append("non-finite gradients after the fallback")
+        other = [None, None]
+        dist.all_gather_object(other, flat)
+        if not torch.equal(other[0], other[1]):
+            ok = False
+            msgs.append("the ranks hold different averaged gradients")
+        step()                                               # ... and the group is back on the one-plane form
+        ok &= eng._fwd_x16 and eng.dy16_fallbacks == 1
+        dist.barrier()
+        q.put((rank, bool(ok), msgs[:8]))
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, False, [traceback.format_exc()[-1500:]]))
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_agree_on_the_overflow_fallback(native_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dy16, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=480) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res), res
