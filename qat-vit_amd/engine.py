@@ -444,8 +444,8 @@ class StudentEngine:
         def run(s0, s1):
             native.check(L.qatvit_student_backward_stages(cp, self._ptr_params, self._act_structs, self._w_structs, dlogits.data_ptr(), gptr,
                                                           self.workspace.data_ptr(), s0, s1, flags, st), "qatvit_student_backward")
-            if flags & (BWD_DY16 | BWD_CALIBRATE):
-                self._gen_issued += 1            # (every such call ends with k_dy16_end: one generation of the mirror)
+            if flags & (BWD_DY16 | BWD_CALIBRATE) and not torch.cuda.is_current_stream_capturing():
+                self._gen_issued += 1            # (every such call ends with k_dy16_end: one generation of the mirror; a captured call counts when it is replayed)
 
         if self.pg is None:
             run(0, self.layout.last_stage)

@@ -94,7 +94,15 @@ class GraphedStudentStep:
         for p, g in zip(self.model.parameters(), self._grads):   # zero_grad(set_to_none=True) in the loop must not drop the static buffers
             p.grad = g
         self.graph.replay()
-        if self._x16 and self.engine.dy16_overflowed():
+        over = False
+        if self._x16:
+            eng = self.engine
+            got = None
+            if eng._mirror_np is not None and eng.pg is None:     # the replayed backward wrote one more generation of the flag mirror, before its weight gradients
+                eng._gen_issued += 1
+                got = eng._mirror_wait()
+            over = eng.dy16_overflowed() if got is None else got
+        if over:
             # a gradient outgrew its fp16 plane (engine.backward asks this itself in eager mode; a capture cannot): the backward again, eagerly, in the
             # pair form, from the logits the replay left - into the buffers .grad points at
             out = self.out.detach().requires_grad_(True)
