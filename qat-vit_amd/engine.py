@@ -361,12 +361,13 @@ class StudentEngine:
         # still run the weight gradients.  QATVIT_DY16_STORE_AGREE=0 (or a store that is not reachable): the all-reduce.
         self._agree_store, self._agree_round = None, 0
         ranks = dist.get_process_group_ranks(self.pg)
-        tag = torch.tensor([id(self) & 0x7fffffff], dtype=torch.int64, device=self.device)
+        self._dp_epoch = getattr(self, "_dp_epoch", 0) + 1                  # (a second enable_data_parallel on this engine must not meet the first one's counters)
+        tag = torch.tensor([id(self) & 0x7fffffff, self._dp_epoch], dtype=torch.int64, device=self.device)
         dist.broadcast(tag, src=ranks[0], group=self.pg)                    # one name for this engine's keys on every rank
         if os.environ.get("QATVIT_DY16_STORE_AGREE", "1") != "0":
             try:
                 from torch.distributed.distributed_c10d import _get_default_store
-                self._agree_store = dist.PrefixStore(f"qatvit_dy16/{int(tag.item())}/{'-'.join(map(str, ranks))}", _get_default_store())
+                self._agree_store = dist.PrefixStore(f"qatvit_dy16/{int(tag[0].item())}.{int(tag[1].item())}/{'-'.join(map(str, ranks))}", _get_default_store())
                 self._agree_store.add("probe", 0)
             except Exception:  # noqa: BLE001
                 self._agree_store = None
