@@ -19,7 +19,7 @@ KNOBS = {
     "QATVIT_QKV_2PASS=0": "bits",          # qkv GEMM once, fp32 output, attention quantises on load
     "QATVIT_F16_STRIP=0": "bits",          # fc2 dgrad + GELU backward of the one-plane backward on the general tall tile (epilogue 19) instead of the A-stationary strip kernel
     "QATVIT_DY16_MIRROR=0": "bits",        # the overflow flag read behind a stream synchronisation instead of from the pinned mirror the backward writes before its weight gradients
-    "QATVIT_LN_APPLY_ROWS=0": "bits",      # k_ln_apply_quant in its flat form (one float4 per thread) instead of one wave per row
+    "QATVIT_LN_APPLY_ROWS=1": "bits",      # k_ln_apply_quant as one wave per row instead of its flat form (one float4 per thread)
     "QATVIT_QP_LATE=0": "bits",            # a k_qparams launch behind every producer of statistics instead of the update inside the consumer kernel (72 launches per step)
     "QATVIT_I8_STRIP=0": "bits",           # the two-pass K = 384 GEMMs (qkv, fc1) on the general tall tile instead of the A-stationary strip kernel
     "QATVIT_I8=0": "bits",                 # grid x grid GEMMs on bf16 MFMA
